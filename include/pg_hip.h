@@ -1,0 +1,164 @@
+/*
+ * pg_hip.h — C-ABI of libpg_hip.so: the MI355X (gfx950) kernels behind the
+ * pytorch_generative.nn operator surface (masked conv + causal attention hot path).
+ *
+ * The reference (EugenHotaj/pytorch-generative) has no FFI: its arithmetic is torch
+ * (SURVEY.md §8b). Each entry point below therefore cites the reference *call site*
+ * whose torch op it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - plain pointers + sizes; all tensors fp32, dense NCHW ("L" = H*W contiguous).
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator);
+ *    the library never allocates, frees, retains, or synchronises (hipGraph-capturable).
+ *  - `stream` is a hipStream_t passed as void*.
+ *  - return 0 on success; <0 = argument error (PG_E*); >0 = hipError_t of the launch.
+ *    pg_last_error() returns a thread-local message for the last non-zero return.
+ *  - functions are re-entrant (called from the autograd thread as well as the main thread).
+ */
+#ifndef PG_HIP_H_
+#define PG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+#define PG_EINVAL (-1)  /* bad argument */
+#define PG_ESHAPE (-2)  /* shape outside what the kernels support (no silent fallback) */
+
+#define PG_MAX_TAPS 64
+
+/* activation ids (pg_act_*, conv prologues) */
+#define PG_ACT_NONE 0
+#define PG_ACT_RELU 1 /* nn.ReLU: models/autoregressive/pixel_cnn.py:33-50 */
+#define PG_ACT_ELU 2  /* F.elu alpha=1: models/autoregressive/pixel_snail.py:27-28 */
+#define PG_ACT_GELU 3 /* nn.GELU() exact erf: models/autoregressive/image_gpt.py:44 */
+
+/* gate kinds for pg_gated_* (nn/convolution.py:46-66) */
+#define PG_GATE_TANH 0     /* tanh(a)*sigmoid(b): gated_pixel_cnn.py:57 */
+#define PG_GATE_IDENTITY 1 /* a*sigmoid(b): pixel_snail.py:50 */
+
+int pg_abi_version(void);
+const char* pg_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Direct 2-D convolution over an explicit tap list (stride 1).
+ * Replaces torch.nn.Conv2d.forward as reached from
+ *   CausalConv2d.forward           nn/convolution.py:41-43  (taps = the mask's non-zero taps)
+ *   every nn.Conv2d on the path    gated_pixel_cnn.py:63-96, pixel_snail.py:41-55 (pad+crop
+ *                                  become tap offsets + the out extent), attention.py:105-118,
+ *                                  image_gpt.py:40-48 (1x1)
+ * out[n,co,r,c] = bias[co] + sum_ci sum_t wpk[ci][t][co] * act(in[n,ci,r+dr[t],c+dc[t]])
+ * (zero outside the input extent). `wpk` is the packed weight made by pg_pack_conv_weight.
+ * The same kernel is the data-gradient: call it with the transposed pack and negated taps.
+ * `res` (optional, may be NULL) is added to the result (fused residual).
+ * ------------------------------------------------------------------------------------- */
+int pg_conv2d_taps(const float* in, const float* wpk, const float* bias, const float* res,
+                   float* out, int N, int Cin, int IH, int IW, int Cout, int OH, int OW,
+                   int T, const int* tap_dr, const int* tap_dc, int in_act, void* stream);
+
+/* packed-weight helper: wpk[a][t][b] (b padded to b_pad, zero filled),
+ *   transpose==0: = w[b][a][tap_u[t]][tap_v[t]]   (forward:   a=Cin,  b=Cout)
+ *   transpose==1: = w[a][b][tap_u[t]][tap_v[t]]   (data grad: a=Cout, b=Cin)
+ * w is the torch layout (Cout, Cin, KH, KW) (nn/convolution.py:35-36). */
+int pg_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int KH, int KW, int T,
+                        const int* tap_u, const int* tap_v, int transpose, int b_pad,
+                        void* stream);
+/* number of floats pg_pack_conv_weight writes */
+size_t pg_packed_weight_floats(int a, int T, int b);
+/* padded extent of b the conv kernel expects */
+int pg_conv_b_pad(int b);
+
+/* Weight + bias gradient (MFMA f32 16x16x4, atomically ACCUMULATED into dw/db — caller
+ * zeroes them once per step). Replaces aten::convolution_backward's weight/bias outputs.
+ * dw[co][ci][tap_u[t]][tap_v[t]] += sum_{n,r,c} dy[n,co,r,c] * act(x[n,ci,r+dr[t],c+dc[t]])
+ * db[co] += sum dy  (db may be NULL).
+ * NOTE the reference's weight.grad is non-zero at masked taps (mask is applied to
+ * weight.data outside autograd, nn/convolution.py:42) — pass all KH*KW taps for exact parity. */
+int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int Cin,
+                    int IH, int IW, int Cout, int OH, int OW, int KH, int KW, int T,
+                    const int* tap_dr, const int* tap_dc, const int* tap_u, const int* tap_v,
+                    int in_act, void* stream);
+
+/* w *= mask in place: nn/convolution.py:42 `self.weight.data *= self.mask`. */
+int pg_mul_inplace(float* w, const float* mask, size_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * NCHW LayerNorm over C.  nn/convolution.py:69-75 (permute -> nn.LayerNorm(C) -> permute).
+ * eps as given (1e-5), biased variance, affine. mean/rstd: (N*L) each, saved for backward.
+ * ------------------------------------------------------------------------------------- */
+int pg_nchw_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                          float* mean, float* rstd, int N, int C, int L, float eps,
+                          void* stream);
+/* dgamma/dbeta are ACCUMULATED (atomics). */
+int pg_nchw_layernorm_bwd(const float* x, const float* gamma, const float* mean,
+                          const float* rstd, const float* dy, float* dx, float* dgamma,
+                          float* dbeta, int N, int C, int L, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused causal attention core.  nn/attention.py:147-160:
+ *   S = q k^T / sqrt(dk); masked_fill(mask==0,-inf); softmax; masked_fill(mask==0, 0); @ v
+ * with mask = tril(ones(L,L), -strict) (nn/attention.py:60-63), never materialised.
+ * q,k: (N, heads*dk, L) channel-major; v,o: (N, heads*dv, L); head h owns channels
+ * [h*d,(h+1)*d) (attention.py:134). *_bs = batch stride in floats (k and v are views into
+ * the _kv conv output, attention.py:144). lse2: (N, heads, L) log2-domain logsumexp saved for
+ * backward. A row with no allowed key (l=0, strict) yields zeros (attention.py:153-157).
+ * ------------------------------------------------------------------------------------- */
+int pg_causal_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse2,
+                       int N, int heads, int L, int dk, int dv, long q_bs, long k_bs, long v_bs,
+                       long o_bs, int strict, void* stream);
+/* dq/dk/dv written (not accumulated). delta: (N, heads, L) workspace. */
+int pg_causal_attn_bwd(const float* q, const float* k, const float* v, const float* o,
+                       const float* d_o, const float* lse2, float* delta, float* dq, float* dk,
+                       float* dv, int N, int heads, int L, int dk_dim, int dv_dim, long q_bs,
+                       long k_bs, long v_bs, long o_bs, long do_bs, long dq_bs, long dk_bs,
+                       long dv_bs, int strict, void* stream);
+
+/* (N,2,H,W) pixel-coordinate encoding, nn/attention.py:37-57 (torch.arange(-.5,.5,1/h)). */
+int pg_image_positional_encoding(float* out, int N, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Elementwise pieces of the path.
+ * ------------------------------------------------------------------------------------- */
+int pg_act_fwd(const float* x, float* y, size_t n, int act, void* stream);
+/* dx = dy * act'(x) */
+int pg_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, void* stream);
+/* GatedActivation: x (N,2C,L) -> y (N,C,L).  nn/convolution.py:62-66 */
+int pg_gated_fwd(const float* x, float* y, int N, int C, int L, int gate, void* stream);
+int pg_gated_bwd(const float* x, const float* dy, float* dx, int N, int C, int L, int gate,
+                 void* stream);
+/* out = a + b */
+int pg_add(const float* a, const float* b, float* out, size_t n, void* stream);
+/* y[n,i] = x[n,i] + p[i] (learned positional map, image_gpt.py:86,106); i < per */
+int pg_add_bcast_fwd(const float* x, const float* p, float* y, int N, size_t per, void* stream);
+/* dp[i] += sum_n dy[n,i] */
+int pg_add_bcast_bwd(const float* dy, float* dp, int N, size_t per, void* stream);
+
+/* BCE-with-logits summed over pixels, averaged over batch: image_gpt.py:158-162.
+ * loss[0] += (1/N) * sum_{n,i} [max(z,0) - z*x + log1p(exp(-|z|))]  (loss zeroed by caller) */
+int pg_bce_logits_fwd(const float* z, const float* x, float* loss, int N, size_t per,
+                      void* stream);
+/* dz = gscale[0] * (sigmoid(z) - x) / N */
+int pg_bce_logits_bwd(const float* z, const float* x, const float* gscale, float* dz, int N,
+                      size_t per, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimiser step as timed by the reference (trainer.py:183-191): global grad L2 norm
+ * (clip_grad_norm_) + torch.optim.Adam over ONE flat parameter/grad buffer.
+ * state (device, 8 floats): [0]=step count, [1]=lr, [2]=sum of squares (scratch),
+ *   [3]=grad norm (output), [4]=clip coefficient (output), [5]=lr multiplier per step,
+ *   [6]=max_norm, [7]=grad pre-scale (1/world after all-reduce)
+ * ------------------------------------------------------------------------------------- */
+int pg_sumsq_accum(const float* g, size_t n, float* state, void* stream);
+int pg_adam_prepare(float* state, void* stream);
+int pg_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* state,
+                 float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PG_HIP_H_ */

@@ -1,0 +1,131 @@
+"""Model-level restatement (torch-CPU) as pure functions of a reference-keyed state_dict.
+Test infrastructure only. Each function follows the cited reference forward()."""
+
+import torch
+import torch.nn.functional as F
+
+from oracle import ops
+
+
+def _conv(x, p, name, padding=0):
+    return F.conv2d(x, p[name + ".weight"], p.get(name + ".bias"), padding=padding)
+
+
+def _cconv(x, p, name, mask_center, padding):
+    return ops.causal_conv2d(x, p[name + ".weight"], p.get(name + ".bias"), mask_center, padding)
+
+
+def apply_masks_(p):
+    """The side effect of CausalConv2d.forward (nn/convolution.py:42): every weight that has a
+    sibling `.mask` buffer is multiplied by it IN PLACE (outside autograd)."""
+    with torch.no_grad():
+        for k in list(p.keys()):
+            if k.endswith(".mask"):
+                p[k[: -len("mask")] + "weight"].mul_(p[k])
+    return p
+
+
+# ------------------------------------------------------------------------------- ImageGPT
+def image_gpt(p, x, n_heads):
+    """models/autoregressive/image_gpt.py:105-109 (+ TransformerBlock.forward :50-52)."""
+    n_blocks = 1 + max(int(k.split(".")[1]) for k in p if k.startswith("_transformer."))
+    c = p["_input.weight"].shape[0]
+    h = _cconv(x + p["_pos"], p, "_input", True, 1)
+    for i in range(n_blocks):
+        pre = f"_transformer.{i}."
+        b = h
+        a = ops.nchw_layernorm(b, p[pre + "_ln1.weight"], p[pre + "_ln1.bias"])
+        b = b + ops.causal_attention(a, None, p, pre + "_attn.", n_heads, c, False)
+        m = ops.nchw_layernorm(b, p[pre + "_ln2.weight"], p[pre + "_ln2.bias"])
+        m = _conv(F.gelu(_conv(m, p, pre + "_out.0")), p, pre + "_out.2")
+        h = h + (b + m)  # the model loop adds x again (image_gpt.py:108)
+    return _conv(ops.nchw_layernorm(h, p["_ln.weight"], p["_ln.bias"]), p, "_out")
+
+
+# ------------------------------------------------------------------------------- PixelCNN
+def pixel_cnn(p, x):
+    """models/autoregressive/pixel_cnn.py:106-110 (+ CausalResidualBlock :52-53)."""
+    n_res = 1 + max(int(k.split(".")[1]) for k in p if k.startswith("_causal_layers."))
+    h = _cconv(x, p, "_input", True, 3)
+    for i in range(n_res):
+        pre = f"_causal_layers.{i}._net."
+        t = _conv(F.relu(h), p, pre + "1")
+        t = _cconv(F.relu(t), p, pre + "3", False, 1)
+        t = _conv(F.relu(t), p, pre + "5")
+        h = h + (h + t)  # doubled residual (pixel_cnn.py:109 with :53)
+    t = _conv(F.relu(h), p, "_head.1")
+    return _conv(F.relu(t), p, "_head.3")
+
+
+# -------------------------------------------------------------------------- GatedPixelCNN
+def _gated_layer(p, pre, v_in, h_in, k, mask_center):
+    """GatedPixelCNNLayer.forward, gated_pixel_cnn.py:99-130."""
+    _, _, h, w = v_in.shape
+    pad = (k - 1) // 2
+    v = F.conv2d(v_in, p[pre + "_vstack_1xN.weight"], p[pre + "_vstack_1xN.bias"], padding=(0, pad))
+    v = F.conv2d(v, p[pre + "_vstack_Nx1.weight"], p[pre + "_vstack_Nx1.bias"], padding=(pad + 1, 0))
+    v = v[:, :, :h, :]
+    link = _conv(v, p, pre + "_link")
+    v = ops.gated_activation(v + _conv(v_in, p, pre + "_vstack_1x1"), "tanh")
+    hs = F.conv2d(h_in, p[pre + "_hstack_1xN.weight"], p[pre + "_hstack_1xN.bias"],
+                  padding=(0, pad + int(mask_center)))[:, :, :, :w]
+    hs = ops.gated_activation(link + hs, "tanh")
+    skip = _conv(hs, p, pre + "_hstack_skip")
+    hs = _conv(hs, p, pre + "_hstack_residual")
+    if not mask_center:
+        hs = hs + h_in
+    return v, hs, skip
+
+
+def gated_pixel_cnn(p, x):
+    """models/autoregressive/gated_pixel_cnn.py:185-190."""
+    n_gated = 1 + max(int(k.split(".")[1]) for k in p if k.startswith("_gated_layers."))
+    v, hs, skips = _gated_layer(p, "_input.", x, x, 7, True)
+    for i in range(n_gated):
+        v, hs, skip = _gated_layer(p, f"_gated_layers.{i}.", v, hs, 3, False)
+        skips = skips + skip
+    t = _conv(F.relu(skips), p, "_head.1")
+    return _conv(F.relu(t), p, "_head.3")
+
+
+# ----------------------------------------------------------------------------- PixelSNAIL
+def _snail_residual(p, pre, x):
+    """ResidualBlock.forward, pixel_snail.py:52-56."""
+    _, c, h, w = x.shape
+    out = F.elu(F.conv2d(F.elu(x), p[pre + "_input_conv.weight"], p[pre + "_input_conv.bias"], padding=1))
+    out = out[:, :, :h, :w]
+    out = F.conv2d(out, p[pre + "_output_conv.weight"], p[pre + "_output_conv.bias"], padding=1)
+    return x + ops.gated_activation(out[:, :, :h, :w], "identity")
+
+
+def pixel_snail(p, x):
+    """models/autoregressive/pixel_snail.py:182-187 (+ PixelSNAILBlock.forward :103-119)."""
+    n_blocks = 1 + max(int(k.split(".")[1]) for k in p if k.startswith("_pixel_snail_blocks."))
+    img = x
+    h = _cconv(x, p, "_input", True, 1)
+
+    def ece(name, t):  # _elu_conv_elu, pixel_snail.py:27-28
+        return F.elu(_conv(F.elu(t), p, name))
+
+    for i in range(n_blocks):
+        pre = f"_pixel_snail_blocks.{i}."
+        n_res = 1 + max(int(k[len(pre + "_residual."):].split(".")[0]) for k in p
+                        if k.startswith(pre + "_residual."))
+        res = h
+        for j in range(n_res):
+            res = _snail_residual(p, f"{pre}_residual.{j}.", res)
+        pos = ops.image_positional_encoding(tuple(img.shape))
+        embed = p[pre + "_attention._q.weight"].shape[0]
+        attn = ops.causal_attention(torch.cat((pos, res), dim=1), img, p, pre + "_attention.", 1,
+                                    embed, True)
+        blk = ece(pre + "_out", ece(pre + "_residual_out", res) + ece(pre + "_attention_out", attn))
+        h = h + blk
+    return _conv(_conv(h, p, "_output.0"), p, "_output.1")
+
+
+FORWARDS = {
+    "image_gpt": image_gpt,
+    "pixel_cnn": pixel_cnn,
+    "gated_pixel_cnn": gated_pixel_cnn,
+    "pixel_snail": pixel_snail,
+}

@@ -1,0 +1,79 @@
+"""Builds libpg_hip.so (the gfx950 kernels + C-ABI) in-tree with hipcc.
+
+Usage: python build.py [--force]
+The .so lands in pytorch_generative_amd/lib/ (git-ignored, but it travels with gpurun).
+"""
+
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB_DIR = os.path.join(HERE, "pytorch_generative_amd", "lib")
+LIB = os.path.join(LIB_DIR, "libpg_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-fvisibility=hidden",
+    "-munsafe-fp-atomics",  # global_atomic_add_f32 instead of a CAS loop
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "pg_hip.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    srcp = os.path.join(CSRC, src)
+    if (
+        not force
+        and os.path.exists(obj)
+        and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _deps_mtime())
+    ):
+        return obj, False
+    cmd = [HIPCC, *FLAGS, "-c", srcp, "-o", obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{res.stdout}\n{res.stderr}")
+    if res.stderr.strip():
+        sys.stderr.write(res.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = _sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(r for _, r in results)
+    if rebuilt or force or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
+        if verbose:
+            print(f"[build] linked {LIB} from {len(objs)} objects")
+    elif verbose:
+        print(f"[build] {LIB} up to date")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

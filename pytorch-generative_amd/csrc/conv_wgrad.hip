@@ -1,0 +1,223 @@
+// conv_wgrad.hip — convolution weight/bias gradient on the fp32 matrix cores (gfx950).
+//
+// Replaces the weight/bias outputs of aten::convolution_backward that autograd reaches from
+// loss.backward() (reference trainer.py:180) for every conv on the path. NOTE: the reference
+// masks `weight.data` outside autograd (nn/convolution.py:42), so its weight.grad is the FULL
+// unmasked correlation — callers pass all KH*KW taps for CausalConv2d to keep grad-norm /
+// Adam-moment parity.
+//
+//   dw[co][ci][u_t][v_t] += sum_{n,r,c} dy[n,co,r,c] * act(x[n,ci,r+dr_t,c+dc_t])
+//   db[co]               += sum_{n,r,c} dy[n,co,r,c]
+//
+// This is a GEMM whose contraction axis is the pixel axis (N*OH*OW ~ 1e5..1e6) and whose
+// output is tiny (Cout x Cin x taps) — the one place on this path where MFMA is the natural
+// fit: v_mfma_f32_16x16x4_f32 is exact fp32 (bitwise an fmaf chain) at the full fp32 rate.
+//   A[i=lane&15][k=lane>>4] = dy[co_tile*16+i][pos+k]
+//   B[k=lane>>4][j=lane&15] = x [ci_tile*16+j][pos+k+tapoff]
+//   D[(lane>>4)*4+r][lane&15] accumulates dw[co][ci] for one tap.
+// dy / x tiles (x with halo, zero filled) are staged in LDS with channel strides == 2 (mod 32)
+// so both fragment reads are bank-conflict free. Each workgroup walks many pixel tiles and
+// flushes once with fp32 atomics (caller zeroes dw/db once per step).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_THREADS = 256;
+constexpr int CO_CHUNK = 64;  // dy channels staged per block
+constexpr int CI_CHUNK = 32;  // x channels staged per block (2 MFMA column tiles)
+constexpr int TC = 9;         // taps accumulated concurrently (3x3 full = one pass)
+constexpr int LDS_BUDGET_FLOATS = 15000;  // ~60 KB -> 2 workgroups / CU
+
+struct WgArgs {
+  const float* x; const float* dy; float* dw; float* db;
+  int N, Cin, IH, IW, Cout, OH, OW, KH, KW, T;
+  int TR, tiles_per_img, total_tiles, SW, xh, min_dr, min_dc;
+  int S_dy, S_x, npos, in_act;
+  int tapoff[PG_MAX_TAPS];
+  int tap_u[PG_MAX_TAPS];
+  int tap_v[PG_MAX_TAPS];
+};
+
+__global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int co0 = blockIdx.y * CO_CHUNK;
+  const int ci0 = blockIdx.z * CI_CHUNK;
+  const int nco = min(CO_CHUNK, a.Cout - co0);
+  const int nci = min(CI_CHUNK, a.Cin - ci0);
+  const int ncot_real = (nco + 15) >> 4;
+  const int ncot = ncot_real >= 3 ? 4 : ncot_real;  // 1, 2 or 4 co tiles across the 4 waves
+  const int ks = 4 / ncot;                          // K-split factor
+  const int cot = wave % ncot;
+  const int kpart = wave / ncot;
+  const int ncit = (nci + 15) >> 4;
+
+  float* dyl = lds;                                // [nco16][S_dy]
+  float* xl = lds + (size_t)ncot * 16 * a.S_dy;    // [ncit*16][S_x]
+  const int lds_floats = ncot * 16 * a.S_dy + ncit * 16 * a.S_x;
+  for (int i = tid; i < lds_floats; i += WG_THREADS) lds[i] = 0.f;
+
+  const int a_base = (cot * 16 + (lane & 15)) * a.S_dy + (lane >> 4);
+  const int b_base = (lane & 15) * a.S_x + (lane >> 4);
+  const bool do_bias = (a.db != nullptr) && (blockIdx.z == 0);
+
+  for (int t0 = 0; t0 < a.T; t0 += TC) {
+    const int tcount = min(TC, a.T - t0);
+    f32x4 acc[2][TC];
+    f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int t = 0; t < TC; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+      const int n = tile / a.tiles_per_img;
+      const int row0 = (tile - n * a.tiles_per_img) * a.TR;
+      __syncthreads();
+      // ---- stage dy rows: (channel,row) per wave iteration, lanes over columns
+      for (int rr = wave; rr < nco * a.TR; rr += 4) {
+        const int ch = rr / a.TR;
+        const int r = rr - ch * a.TR;
+        const bool rok = row0 + r < a.OH;
+        const float* src = a.dy + (((size_t)n * a.Cout + co0 + ch) * a.OH + (rok ? row0 + r : 0)) * a.OW;
+        float* dst = dyl + ch * a.S_dy + r * a.SW;
+        for (int c = lane; c < a.SW; c += 64) dst[c] = (rok && c < a.OW) ? src[c] : 0.f;
+      }
+      // ---- stage x rows (halo, zero filled, prologue activation applied once)
+      for (int rr = wave; rr < nci * a.xh; rr += 4) {
+        const int ch = rr / a.xh;
+        const int xr = rr - ch * a.xh;
+        const int ir = row0 + xr + a.min_dr;
+        const bool rok = ir >= 0 && ir < a.IH;
+        const float* src = a.x + (((size_t)n * a.Cin + ci0 + ch) * a.IH + (rok ? ir : 0)) * a.IW;
+        float* dst = xl + ch * a.S_x + xr * a.SW;
+        for (int c = lane; c < a.SW; c += 64) {
+          const int ic = c + a.min_dc;
+          dst[c] = (rok && ic >= 0 && ic < a.IW) ? pg_apply_act(src[ic], a.in_act) : 0.f;
+        }
+      }
+      __syncthreads();
+      // ---- MFMA over the tile's positions
+      if (cot < ncot_real) {
+#pragma unroll 2
+        for (int p0 = kpart * 4; p0 < a.npos; p0 += 4 * ks) {
+          const float av = dyl[a_base + p0];
+          if (do_bias && t0 == 0) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.0f, accb, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < TC; ++t) {
+            if (t < tcount) {
+              const int off = a.tapoff[t0 + t] + p0;
+              const float b0 = xl[b_base + off];
+              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0][t], 0, 0, 0);
+              if (ncit > 1) {
+                const float b1 = xl[b_base + 16 * a.S_x + off];
+                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1][t], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- flush this tap chunk
+    if (cot < ncot_real) {
+      const int co_b = co0 + cot * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (c < ncit) {
+          const int ci = ci0 + c * 16 + (lane & 15);
+#pragma unroll
+          for (int t = 0; t < TC; ++t) {
+            if (t < tcount && ci < a.Cin) {
+              const int u = a.tap_u[t0 + t], v = a.tap_v[t0 + t];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int co = co_b + r;
+                if (co < a.Cout)
+                  atomicAdd(&a.dw[(((size_t)co * a.Cin + ci) * a.KH + u) * a.KW + v], acc[c][t][r]);
+              }
+            }
+          }
+        }
+      }
+      if (do_bias && t0 == 0 && (lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co_b + r;
+          if (co < a.Cout) atomicAdd(&a.db[co], accb[r]);
+        }
+      }
+    }
+  }
+}
+
+inline int pad_stride(int s) {  // smallest s' >= s with s' % 32 == 2
+  int r = s % 32;
+  return r <= 2 ? s + (2 - r) : s + (34 - r);
+}
+
+}  // namespace
+
+PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int N,
+                              int Cin, int IH, int IW, int Cout, int OH, int OW, int KH, int KW,
+                              int T, const int* tap_dr, const int* tap_dc, const int* tap_u,
+                              const int* tap_v, int in_act, void* stream) {
+  PG_REQUIRE(x && dy && dw && tap_dr && tap_dc && tap_u && tap_v, PG_EINVAL,
+             "pg_conv2d_wgrad: null pointer");
+  PG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, PG_EINVAL,
+             "pg_conv2d_wgrad: non-positive dimension");
+  PG_REQUIRE(T >= 1 && T <= PG_MAX_TAPS, PG_ESHAPE, "pg_conv2d_wgrad: T=%d not in [1,%d]", T,
+             PG_MAX_TAPS);
+  PG_REQUIRE(in_act >= PG_ACT_NONE && in_act <= PG_ACT_GELU, PG_EINVAL, "pg_conv2d_wgrad: bad in_act");
+  WgArgs a;
+  a.x = x; a.dy = dy; a.dw = dw; a.db = db;
+  a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW;
+  a.KH = KH; a.KW = KW; a.T = T; a.in_act = in_act;
+  int min_dr = tap_dr[0], max_dr = tap_dr[0], min_dc = tap_dc[0], max_dc = tap_dc[0];
+  for (int t = 0; t < T; ++t) {
+    PG_REQUIRE(tap_u[t] >= 0 && tap_u[t] < KH && tap_v[t] >= 0 && tap_v[t] < KW, PG_EINVAL,
+               "pg_conv2d_wgrad: tap %d outside the %dx%d filter", t, KH, KW);
+    min_dr = tap_dr[t] < min_dr ? tap_dr[t] : min_dr;
+    max_dr = tap_dr[t] > max_dr ? tap_dr[t] : max_dr;
+    min_dc = tap_dc[t] < min_dc ? tap_dc[t] : min_dc;
+    max_dc = tap_dc[t] > max_dc ? tap_dc[t] : max_dc;
+  }
+  const int hr = max_dr - min_dr, hc = max_dc - min_dc;
+  a.min_dr = min_dr; a.min_dc = min_dc;
+  a.SW = OW + hc;
+  const int nco = Cout < CO_CHUNK ? ((Cout + 15) / 16) * 16 : CO_CHUNK;
+  const int nco_alloc = nco == 48 ? 64 : nco;
+  const int nci = Cin < CI_CHUNK ? ((Cin + 15) / 16) * 16 : CI_CHUNK;
+  // per-row cost in floats: (nco+nci)*SW ; fixed: nci*(hr*SW + hc + 48) + nco*48
+  const int fixed = nci * (hr * a.SW + hc + 48) + nco_alloc * 48;
+  int TR = (LDS_BUDGET_FLOATS - fixed) / ((nco_alloc + nci) * a.SW);
+  PG_REQUIRE(TR >= 1, PG_ESHAPE, "pg_conv2d_wgrad: row of %d (+%d halo) too wide for LDS", OW, hc);
+  if (TR > OH) TR = OH;
+  a.TR = TR;
+  a.xh = TR + hr;
+  a.tiles_per_img = (OH + TR - 1) / TR;
+  a.total_tiles = N * a.tiles_per_img;
+  const int kq = 16;  // npos multiple of 4*ks for every ks in {1,2,4}
+  a.npos = ((TR * a.SW + kq - 1) / kq) * kq;
+  a.S_dy = pad_stride(a.npos);
+  a.S_x = pad_stride(a.npos + hr * a.SW + hc + 4);
+  for (int t = 0; t < T; ++t) {
+    a.tapoff[t] = (tap_dr[t] - min_dr) * a.SW + (tap_dc[t] - min_dc);
+    a.tap_u[t] = tap_u[t];
+    a.tap_v[t] = tap_v[t];
+  }
+  const int co_chunks = (Cout + CO_CHUNK - 1) / CO_CHUNK;
+  const int ci_chunks = (Cin + CI_CHUNK - 1) / CI_CHUNK;
+  int G = 1024 / (co_chunks * ci_chunks);
+  if (G < 1) G = 1;
+  if (G > a.total_tiles) G = a.total_tiles;
+  const size_t shmem = ((size_t)nco_alloc * a.S_dy + (size_t)nci * a.S_x) * sizeof(float);
+  PG_REQUIRE(shmem <= 160 * 1024, PG_ESHAPE, "pg_conv2d_wgrad: LDS %zu B over budget", shmem);
+  dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
+  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(WG_THREADS), shmem, (hipStream_t)stream, a);
+  PG_LAUNCH_CHECK("pg_conv2d_wgrad");
+  return 0;
+}

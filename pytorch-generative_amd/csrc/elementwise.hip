@@ -1,0 +1,320 @@
+// elementwise.hip — the memory-bound pieces of the hot path (fp32, float4 grid-stride).
+//
+// Reference call sites: ReLU/ELU/GELU (pixel_cnn.py:33-50, pixel_snail.py:27-28,
+// image_gpt.py:44), GatedActivation (nn/convolution.py:62-66), residual adds
+// (image_gpt.py:50-52,107-108), the learned positional map (image_gpt.py:86,106),
+// `weight.data *= mask` (nn/convolution.py:42), image_positional_encoding
+// (nn/attention.py:37-57) and the BCE-with-logits loss (image_gpt.py:158-162).
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+inline int ew_blocks(size_t n_items) {
+  size_t b = (n_items + EW_THREADS - 1) / EW_THREADS;
+  const size_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride beyond that
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <int ACT>
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                               int vec) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const size_t n4 = n >> 2;
+    for (; i < n4; i += stride) {
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      v.x = pg_apply_act(v.x, ACT); v.y = pg_apply_act(v.y, ACT);
+      v.z = pg_apply_act(v.z, ACT); v.w = pg_apply_act(v.w, ACT);
+      reinterpret_cast<float4*>(y)[i] = v;
+    }
+    // tail
+    for (size_t t = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+      y[t] = pg_apply_act(x[t], ACT);
+  } else {
+    for (; i < n; i += stride) y[i] = pg_apply_act(x[i], ACT);
+  }
+}
+
+template <int ACT>
+__global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                               float* __restrict__ dx, size_t n, int vec) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const size_t n4 = n >> 2;
+    for (; i < n4; i += stride) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      float4 g = reinterpret_cast<const float4*>(dy)[i];
+      g.x *= pg_act_grad(v.x, ACT); g.y *= pg_act_grad(v.y, ACT);
+      g.z *= pg_act_grad(v.z, ACT); g.w *= pg_act_grad(v.w, ACT);
+      reinterpret_cast<float4*>(dx)[i] = g;
+    }
+    for (size_t t = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+      dx[t] = dy[t] * pg_act_grad(x[t], ACT);
+  } else {
+    for (; i < n; i += stride) dx[i] = dy[i] * pg_act_grad(x[i], ACT);
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// x: (N, 2C, L) -> y: (N, C, L); item = (n, c, l)
+__global__ void gated_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                 size_t CL, size_t total, int gate) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t n = i / CL;
+    const size_t r = i - n * CL;
+    const float a = x[n * 2 * CL + r];
+    const float b = x[n * 2 * CL + CL + r];
+    const float f = gate == PG_GATE_TANH ? tanhf(a) : a;
+    y[i] = f * sigmoidf_(b);
+  }
+}
+
+__global__ void gated_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                 float* __restrict__ dx, int C, size_t CL, size_t total,
+                                 int gate) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t n = i / CL;
+    const size_t r = i - n * CL;
+    const float a = x[n * 2 * CL + r];
+    const float b = x[n * 2 * CL + CL + r];
+    const float g = dy[i];
+    const float s = sigmoidf_(b);
+    float f, df;
+    if (gate == PG_GATE_TANH) {
+      f = tanhf(a);
+      df = 1.f - f * f;
+    } else {
+      f = a;
+      df = 1.f;
+    }
+    dx[n * 2 * CL + r] = g * df * s;
+    dx[n * 2 * CL + CL + r] = g * f * s * (1.f - s);
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                           float* __restrict__ out, size_t n, int vec) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const size_t n4 = n >> 2;
+    for (; i < n4; i += stride) {
+      const float4 u = reinterpret_cast<const float4*>(a)[i];
+      const float4 v = reinterpret_cast<const float4*>(b)[i];
+      reinterpret_cast<float4*>(out)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+    for (size_t t = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+      out[t] = a[t] + b[t];
+  } else {
+    for (; i < n; i += stride) out[i] = a[i] + b[i];
+  }
+}
+
+__global__ void mul_inplace_kernel(float* __restrict__ w, const float* __restrict__ m, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] *= m[i];
+}
+
+__global__ void add_bcast_fwd_kernel(const float* __restrict__ x, const float* __restrict__ p,
+                                     float* __restrict__ y, size_t per, size_t total) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+    y[i] = x[i] + p[i % per];
+}
+
+// dp[i] += sum_n dy[n, i]; one thread per i (coalesced across i), loop over n.
+__global__ void add_bcast_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dp, int N,
+                                     size_t per) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += dy[(size_t)n * per + i];
+  dp[i] += s;
+}
+
+// torch.arange(-0.5, 0.5, 1/h) is computed as start + i*step in the accumulate type
+// (double for a float32 result on CPU), then rounded to float32.
+__global__ void posenc_kernel(float* __restrict__ out, int N, int H, int W) {
+  const size_t HW = (size_t)H * W;
+  const size_t total = (size_t)N * 2 * HW;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t r = i % (2 * HW);
+    const int ch = (int)(r / HW);
+    const int hw = (int)(r - (size_t)ch * HW);
+    const int row = hw / W, col = hw - row * W;
+    const double step = ch == 0 ? 1.0 / (double)H : 1.0 / (double)W;
+    const int idx = ch == 0 ? row : col;
+    out[i] = (float)(-0.5 + (double)idx * step);
+  }
+}
+
+// loss[0] += (1/N) sum [max(z,0) - z*x + log1p(exp(-|z|))]
+__global__ void bce_fwd_kernel(const float* __restrict__ z, const float* __restrict__ x,
+                               float* __restrict__ loss, size_t total, float invN) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const float zi = z[i], xi = x[i];
+    s += fmaxf(zi, 0.f) - zi * xi + log1pf(expf(-fabsf(zi)));
+  }
+  s = pg_wave_sum(s);
+  __shared__ float part[EW_THREADS / 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) part[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < EW_THREADS / 64; ++w) t += part[w];
+    atomicAdd(loss, t * invN);
+  }
+}
+
+__global__ void bce_bwd_kernel(const float* __restrict__ z, const float* __restrict__ x,
+                               const float* __restrict__ gscale, float* __restrict__ dz,
+                               size_t total, float invN) {
+  const float g = gscale[0] * invN;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+    dz[i] = g * (sigmoidf_(z[i]) - x[i]);
+}
+
+}  // namespace
+
+#define EW_STREAM ((hipStream_t)stream)
+
+PG_EXPORT int pg_act_fwd(const float* x, float* y, size_t n, int act, void* stream) {
+  PG_REQUIRE(x && y, PG_EINVAL, "pg_act_fwd: null pointer");
+  if (n == 0) return 0;
+  const int vec = aligned16(x) && aligned16(y);
+  const int blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+  switch (act) {
+    case PG_ACT_RELU: hipLaunchKernelGGL(act_fwd_kernel<PG_ACT_RELU>, dim3(blocks), dim3(EW_THREADS), 0, EW_STREAM, x, y, n, vec); break;
+    case PG_ACT_ELU:  hipLaunchKernelGGL(act_fwd_kernel<PG_ACT_ELU>,  dim3(blocks), dim3(EW_THREADS), 0, EW_STREAM, x, y, n, vec); break;
+    case PG_ACT_GELU: hipLaunchKernelGGL(act_fwd_kernel<PG_ACT_GELU>, dim3(blocks), dim3(EW_THREADS), 0, EW_STREAM, x, y, n, vec); break;
+    default: PG_REQUIRE(false, PG_EINVAL, "pg_act_fwd: bad act %d", act);
+  }
+  PG_LAUNCH_CHECK("pg_act_fwd");
+  return 0;
+}
+
+PG_EXPORT int pg_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act,
+                         void* stream) {
+  PG_REQUIRE(x && dy && dx, PG_EINVAL, "pg_act_bwd: null pointer");
+  if (n == 0) return 0;
+  const int vec = aligned16(x) && aligned16(dy) && aligned16(dx);
+  const int blocks = ew_blocks(vec ? (n + 3) / 4 : n);
+  switch (act) {
+    case PG_ACT_RELU: hipLaunchKernelGGL(act_bwd_kernel<PG_ACT_RELU>, dim3(blocks), dim3(EW_THREADS), 0, EW_STREAM, x, dy, dx, n, vec); break;
+    case PG_ACT_ELU:  hipLaunchKernelGGL(act_bwd_kernel<PG_ACT_ELU>,  dim3(blocks), dim3(EW_THREADS), 0, EW_STREAM, x, dy, dx, n, vec); break;
+    case PG_ACT_GELU: hipLaunchKernelGGL(act_bwd_kernel<PG_ACT_GELU>, dim3(blocks), dim3(EW_THREADS), 0, EW_STREAM, x, dy, dx, n, vec); break;
+    default: PG_REQUIRE(false, PG_EINVAL, "pg_act_bwd: bad act %d", act);
+  }
+  PG_LAUNCH_CHECK("pg_act_bwd");
+  return 0;
+}
+
+PG_EXPORT int pg_gated_fwd(const float* x, float* y, int N, int C, int L, int gate, void* stream) {
+  PG_REQUIRE(x && y, PG_EINVAL, "pg_gated_fwd: null pointer");
+  PG_REQUIRE(N > 0 && C > 0 && L > 0, PG_EINVAL, "pg_gated_fwd: bad dims");
+  PG_REQUIRE(gate == PG_GATE_TANH || gate == PG_GATE_IDENTITY, PG_EINVAL, "pg_gated_fwd: bad gate");
+  const size_t CL = (size_t)C * L, total = (size_t)N * CL;
+  hipLaunchKernelGGL(gated_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, EW_STREAM, x, y,
+                     C, CL, total, gate);
+  PG_LAUNCH_CHECK("pg_gated_fwd");
+  return 0;
+}
+
+PG_EXPORT int pg_gated_bwd(const float* x, const float* dy, float* dx, int N, int C, int L,
+                           int gate, void* stream) {
+  PG_REQUIRE(x && dy && dx, PG_EINVAL, "pg_gated_bwd: null pointer");
+  PG_REQUIRE(N > 0 && C > 0 && L > 0, PG_EINVAL, "pg_gated_bwd: bad dims");
+  PG_REQUIRE(gate == PG_GATE_TANH || gate == PG_GATE_IDENTITY, PG_EINVAL, "pg_gated_bwd: bad gate");
+  const size_t CL = (size_t)C * L, total = (size_t)N * CL;
+  hipLaunchKernelGGL(gated_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, EW_STREAM, x, dy,
+                     dx, C, CL, total, gate);
+  PG_LAUNCH_CHECK("pg_gated_bwd");
+  return 0;
+}
+
+PG_EXPORT int pg_add(const float* a, const float* b, float* out, size_t n, void* stream) {
+  PG_REQUIRE(a && b && out, PG_EINVAL, "pg_add: null pointer");
+  if (n == 0) return 0;
+  const int vec = aligned16(a) && aligned16(b) && aligned16(out);
+  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(vec ? (n + 3) / 4 : n)), dim3(EW_THREADS), 0,
+                     EW_STREAM, a, b, out, n, vec);
+  PG_LAUNCH_CHECK("pg_add");
+  return 0;
+}
+
+PG_EXPORT int pg_mul_inplace(float* w, const float* mask, size_t n, void* stream) {
+  PG_REQUIRE(w && mask, PG_EINVAL, "pg_mul_inplace: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(mul_inplace_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, EW_STREAM, w, mask, n);
+  PG_LAUNCH_CHECK("pg_mul_inplace");
+  return 0;
+}
+
+PG_EXPORT int pg_add_bcast_fwd(const float* x, const float* p, float* y, int N, size_t per,
+                               void* stream) {
+  PG_REQUIRE(x && p && y, PG_EINVAL, "pg_add_bcast_fwd: null pointer");
+  PG_REQUIRE(N > 0 && per > 0, PG_EINVAL, "pg_add_bcast_fwd: bad dims");
+  const size_t total = (size_t)N * per;
+  hipLaunchKernelGGL(add_bcast_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, EW_STREAM, x,
+                     p, y, per, total);
+  PG_LAUNCH_CHECK("pg_add_bcast_fwd");
+  return 0;
+}
+
+PG_EXPORT int pg_add_bcast_bwd(const float* dy, float* dp, int N, size_t per, void* stream) {
+  PG_REQUIRE(dy && dp, PG_EINVAL, "pg_add_bcast_bwd: null pointer");
+  PG_REQUIRE(N > 0 && per > 0, PG_EINVAL, "pg_add_bcast_bwd: bad dims");
+  hipLaunchKernelGGL(add_bcast_bwd_kernel, dim3((unsigned)((per + EW_THREADS - 1) / EW_THREADS)),
+                     dim3(EW_THREADS), 0, EW_STREAM, dy, dp, N, per);
+  PG_LAUNCH_CHECK("pg_add_bcast_bwd");
+  return 0;
+}
+
+PG_EXPORT int pg_image_positional_encoding(float* out, int N, int H, int W, void* stream) {
+  PG_REQUIRE(out, PG_EINVAL, "pg_image_positional_encoding: null pointer");
+  PG_REQUIRE(N > 0 && H > 0 && W > 0, PG_EINVAL, "pg_image_positional_encoding: bad dims");
+  const size_t total = (size_t)N * 2 * H * W;
+  hipLaunchKernelGGL(posenc_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, EW_STREAM, out, N, H, W);
+  PG_LAUNCH_CHECK("pg_image_positional_encoding");
+  return 0;
+}
+
+PG_EXPORT int pg_bce_logits_fwd(const float* z, const float* x, float* loss, int N, size_t per,
+                                void* stream) {
+  PG_REQUIRE(z && x && loss, PG_EINVAL, "pg_bce_logits_fwd: null pointer");
+  PG_REQUIRE(N > 0 && per > 0, PG_EINVAL, "pg_bce_logits_fwd: bad dims");
+  const size_t total = (size_t)N * per;
+  int blocks = ew_blocks(total);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(blocks), dim3(EW_THREADS), 0, EW_STREAM, z, x, loss, total,
+                     1.f / (float)N);
+  PG_LAUNCH_CHECK("pg_bce_logits_fwd");
+  return 0;
+}
+
+PG_EXPORT int pg_bce_logits_bwd(const float* z, const float* x, const float* gscale, float* dz,
+                                int N, size_t per, void* stream) {
+  PG_REQUIRE(z && x && gscale && dz, PG_EINVAL, "pg_bce_logits_bwd: null pointer");
+  PG_REQUIRE(N > 0 && per > 0, PG_EINVAL, "pg_bce_logits_bwd: bad dims");
+  const size_t total = (size_t)N * per;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, EW_STREAM, z, x,
+                     gscale, dz, total, 1.f / (float)N);
+  PG_LAUNCH_CHECK("pg_bce_logits_bwd");
+  return 0;
+}

@@ -1,0 +1,104 @@
+"""ctypes binding of libpg_hip.so (the C-ABI declared in include/pg_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call returns a
+non-zero status, a RuntimeError/ValueError is raised. (The CPU oracle under /oracle is test
+infrastructure and is never imported from here.)
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpg_hip.so")
+
+ABI_VERSION = 1
+
+c_f = ctypes.c_void_p  # device float* (passed as integer address)
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_z = ctypes.c_size_t
+c_s = ctypes.c_void_p  # hipStream_t
+c_ip = ctypes.POINTER(ctypes.c_int)  # host int array
+c_flt = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/pg_hip.h one to one.
+SIGNATURES = {
+    "pg_abi_version": (c_i, []),
+    "pg_last_error": (ctypes.c_char_p, []),
+    "pg_conv2d_taps": (
+        c_i,
+        [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_s],
+    ),
+    "pg_pack_conv_weight": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_i, c_s]),
+    "pg_packed_weight_floats": (c_z, [c_i, c_i, c_i]),
+    "pg_conv_b_pad": (c_i, [c_i]),
+    "pg_conv2d_wgrad": (
+        c_i,
+        [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_ip,
+         c_ip, c_i, c_s],
+    ),
+    "pg_mul_inplace": (c_i, [c_f, c_f, c_z, c_s]),
+    "pg_nchw_layernorm_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_flt, c_s]),
+    "pg_nchw_layernorm_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_s]),
+    "pg_causal_attn_fwd": (
+        c_i,
+        [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_i, c_s],
+    ),
+    "pg_causal_attn_bwd": (
+        c_i,
+        [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l,
+         c_l, c_l, c_l, c_l, c_l, c_i, c_s],
+    ),
+    "pg_image_positional_encoding": (c_i, [c_f, c_i, c_i, c_i, c_s]),
+    "pg_act_fwd": (c_i, [c_f, c_f, c_z, c_i, c_s]),
+    "pg_act_bwd": (c_i, [c_f, c_f, c_f, c_z, c_i, c_s]),
+    "pg_gated_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_s]),
+    "pg_gated_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_s]),
+    "pg_add": (c_i, [c_f, c_f, c_f, c_z, c_s]),
+    "pg_add_bcast_fwd": (c_i, [c_f, c_f, c_f, c_i, c_z, c_s]),
+    "pg_add_bcast_bwd": (c_i, [c_f, c_f, c_i, c_z, c_s]),
+    "pg_bce_logits_fwd": (c_i, [c_f, c_f, c_f, c_i, c_z, c_s]),
+    "pg_bce_logits_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_z, c_s]),
+    "pg_sumsq_accum": (c_i, [c_f, c_z, c_f, c_s]),
+    "pg_adam_prepare": (c_i, [c_f, c_s]),
+    "pg_adam_step": (c_i, [c_f, c_f, c_f, c_f, c_z, c_f, c_flt, c_flt, c_flt, c_s]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libpg_hip.so (once) and binds every symbol of the header. Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libpg_hip.so not found at {LIB_PATH}. Build it with "
+            "`python pytorch-generative_amd/build.py` (or __graft_entry__.build()). "
+            "There is no CPU/ATen fallback for the HIP operator path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.pg_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libpg_hip.so ABI version {got} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """Maps a C-ABI status to the Python exceptions of the reference's error convention."""
+    if rc == 0:
+        return
+    msg = load().pg_last_error().decode("utf-8", "replace")
+    if rc < 0:
+        raise ValueError(f"{what}: {msg} (status {rc})")
+    raise RuntimeError(f"{what}: HIP error {rc}: {msg}")
+
+
+def int_array(values):
+    return (ctypes.c_int * len(values))(*values)

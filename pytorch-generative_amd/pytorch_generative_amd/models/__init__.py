@@ -1,0 +1,8 @@
+"""Model constructors of the hot path (same names/signatures as pytorch_generative.models)."""
+
+from pytorch_generative_amd.models.gated_pixel_cnn import GatedPixelCNN
+from pytorch_generative_amd.models.image_gpt import ImageGPT
+from pytorch_generative_amd.models.pixel_cnn import PixelCNN
+from pytorch_generative_amd.models.pixel_snail import PixelSNAIL
+
+__all__ = ["GatedPixelCNN", "ImageGPT", "PixelCNN", "PixelSNAIL"]

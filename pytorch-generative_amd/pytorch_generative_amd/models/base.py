@@ -1,0 +1,69 @@
+"""Model base classes (behavioural mirror of the reference's models/base.py:28-120).
+
+* GenerativeModel remembers the (C, H, W) of the first 4-D batch it is called with in lazily
+  registered `_c/_h/_w` buffers (they are part of the state_dict, base.py:41-61).
+* AutoregressiveModel.sample() fills pixels in raster order, one full forward per pixel,
+  replacing only entries < 0 of `conditioned_on` (base.py:97-120).
+"""
+
+import abc
+
+import torch
+from torch import distributions, nn
+
+
+def _bernoulli_from_logits(logits):
+    return distributions.Bernoulli(logits=logits).sample()
+
+
+class GenerativeModel(abc.ABC, nn.Module):
+    def __call__(self, x, *args, **kwargs):
+        if getattr(self, "_c", None) is None and x.dim() == 4:
+            self._register_shape(*x.shape[1:])
+        return super().__call__(x, *args, **kwargs)
+
+    def _register_shape(self, c, h, w):
+        for name, value in (("_c", c), ("_h", h), ("_w", w)):
+            self.register_buffer(name, value if torch.is_tensor(value) else torch.tensor(value))
+
+    def load_state_dict(self, state_dict, strict=True):
+        if "_c" in state_dict and not getattr(self, "_c", None):
+            self._register_shape(state_dict["_c"], state_dict["_h"], state_dict["_w"])
+        return super().load_state_dict(state_dict, strict)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @abc.abstractmethod
+    def sample(self, n_samples):
+        ...
+
+
+class AutoregressiveModel(GenerativeModel):
+    def __init__(self, sample_fn=None):
+        """sample_fn: fn(logits) -> sample; defaults to Bernoulli(logits)."""
+        super().__init__()
+        self._sample_fn = sample_fn or _bernoulli_from_logits
+
+    def _start_canvas(self, n_samples, conditioned_on):
+        assert (
+            n_samples is not None or conditioned_on is not None
+        ), 'Must provided one, and only one, of "n_samples" or "conditioned_on"'
+        if conditioned_on is not None:
+            return conditioned_on.clone()
+        shape = (n_samples, int(self._c), int(self._h), int(self._w))
+        return torch.full(shape, -1.0, device=self.device)
+
+    @torch.no_grad()
+    def sample(self, n_samples=None, conditioned_on=None):
+        """Generates samples; entries of `conditioned_on` that are >= 0 are kept as given."""
+        canvas = self._start_canvas(n_samples, conditioned_on)
+        n, c, h, w = canvas.shape
+        for row in range(h):
+            for col in range(w):
+                logits = self.forward(canvas)[:, :, row, col]
+                drawn = self._sample_fn(logits).view(n, c)
+                current = canvas[:, :, row, col]
+                canvas[:, :, row, col] = torch.where(current < 0, drawn, current)
+        return canvas

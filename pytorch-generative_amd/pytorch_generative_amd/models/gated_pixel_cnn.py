@@ -1,0 +1,109 @@
+"""Gated PixelCNN on the MI355X operator path
+(reference models/autoregressive/gated_pixel_cnn.py:31-190).
+
+The pad-then-crop convolutions of the reference ((k//2+1)x1 with padding k//2+1 cropped to the
+first h rows, 1x(k//2+1) with padding k//2+mask_center cropped to the first w columns) are
+expressed as tap offsets + an output extent, so the cropped rows/columns are never computed.
+"""
+
+from torch import nn
+
+from pytorch_generative_amd import nn as pg_nn
+from pytorch_generative_amd import ops
+from pytorch_generative_amd.models import base
+
+
+class GatedPixelCNNLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, mask_center=False):
+        super().__init__()
+        assert kernel_size % 2 == 1, "kernel_size cannot be even"
+        self._in_channels = in_channels
+        self._out_channels = out_channels
+        self._activation = pg_nn.GatedActivation()
+        self._kernel_size = kernel_size
+        self._padding = (kernel_size - 1) // 2
+        self._mask_center = mask_center
+
+        self._vstack_1xN = pg_nn.Conv2d(
+            in_channels=in_channels,
+            out_channels=out_channels,
+            kernel_size=(1, kernel_size),
+            padding=(0, self._padding),
+        )
+        self._vstack_Nx1 = pg_nn.Conv2d(
+            in_channels=out_channels,
+            out_channels=2 * out_channels,
+            kernel_size=(kernel_size // 2 + 1, 1),
+            padding=(self._padding + 1, 0),
+        )
+        self._vstack_1x1 = pg_nn.Conv2d(
+            in_channels=in_channels, out_channels=2 * out_channels, kernel_size=1
+        )
+        self._link = pg_nn.Conv2d(
+            in_channels=2 * out_channels, out_channels=2 * out_channels, kernel_size=1
+        )
+        self._hstack_1xN = pg_nn.Conv2d(
+            in_channels=in_channels,
+            out_channels=2 * out_channels,
+            kernel_size=(1, kernel_size // 2 + 1),
+            padding=(0, self._padding + int(mask_center)),
+        )
+        self._hstack_residual = pg_nn.Conv2d(
+            in_channels=out_channels, out_channels=out_channels, kernel_size=1
+        )
+        self._hstack_skip = pg_nn.Conv2d(
+            in_channels=out_channels, out_channels=out_channels, kernel_size=1
+        )
+
+    def forward(self, vstack_input, hstack_input):
+        _, _, h, w = vstack_input.shape
+        # vertical stack
+        vconv = self._vstack_Nx1(self._vstack_1xN(vstack_input), crop=(h, w))
+        link = self._link(vconv)
+        vstack = self._activation(self._vstack_1x1(vstack_input, res=vconv))
+        # horizontal stack
+        hstack = self._activation(self._hstack_1xN(hstack_input, crop=(h, w), res=link))
+        skip = self._hstack_skip(hstack)
+        # a causal (mask_center) layer must not see its own input through the residual
+        hstack = self._hstack_residual(hstack, res=None if self._mask_center else hstack_input)
+        return vstack, hstack, skip
+
+
+class GatedPixelCNN(base.AutoregressiveModel):
+    def __init__(
+        self,
+        in_channels=1,
+        out_channels=1,
+        n_gated=10,
+        gated_channels=128,
+        head_channels=32,
+        sample_fn=None,
+    ):
+        super().__init__(sample_fn)
+        self._input = GatedPixelCNNLayer(
+            in_channels=in_channels, out_channels=gated_channels, kernel_size=7, mask_center=True
+        )
+        self._gated_layers = nn.ModuleList(
+            [
+                GatedPixelCNNLayer(
+                    in_channels=gated_channels,
+                    out_channels=gated_channels,
+                    kernel_size=3,
+                    mask_center=False,
+                )
+                for _ in range(n_gated)
+            ]
+        )
+        self._head = nn.Sequential(
+            nn.ReLU(),
+            pg_nn.Conv2d(in_channels=gated_channels, out_channels=head_channels, kernel_size=1),
+            nn.ReLU(),
+            pg_nn.Conv2d(in_channels=head_channels, out_channels=out_channels, kernel_size=1),
+        )
+
+    def forward(self, x):
+        vstack, hstack, skip_connections = self._input(x, x)
+        for gated_layer in self._gated_layers:
+            vstack, hstack, skip = gated_layer(vstack, hstack)
+            skip_connections = ops.add(skip_connections, skip)
+        return self._head[3](self._head[1](skip_connections, in_act="relu"), in_act="relu")

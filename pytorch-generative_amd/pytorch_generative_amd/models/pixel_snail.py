@@ -1,0 +1,121 @@
+"""PixelSNAIL on the MI355X operator path
+(reference models/autoregressive/pixel_snail.py:27-187).
+
+2x2 convolutions with padding 1 cropped to [:h, :w] become four tap offsets
+(-1,-1),(-1,0),(0,-1),(0,0); ELU is fused into the 2x2 kernels' LDS staging; the positional
+encoding is generated on the device once and cached.
+"""
+
+import torch
+from torch import nn
+
+from pytorch_generative_amd import nn as pg_nn
+from pytorch_generative_amd import ops
+from pytorch_generative_amd.models import base
+
+
+def _elu_conv_elu(conv, x):
+    return ops.elu(conv(ops.elu(x)))
+
+
+class ResidualBlock(nn.Module):
+    """Residual block with a gated (identity * sigmoid) activation."""
+
+    def __init__(self, n_channels):
+        super().__init__()
+        self._input_conv = pg_nn.Conv2d(
+            in_channels=n_channels, out_channels=n_channels, kernel_size=2, padding=1
+        )
+        self._output_conv = pg_nn.Conv2d(
+            in_channels=n_channels, out_channels=2 * n_channels, kernel_size=2, padding=1
+        )
+        self._activation = pg_nn.GatedActivation(activation_fn=nn.Identity())
+
+    def forward(self, x):
+        _, _, h, w = x.shape
+        # reference: elu(conv(elu(x)))[:, :, :h, :w] -> conv[:, :, :h, :w] -> gate -> + x
+        out = self._input_conv(x, crop=(h, w), in_act="elu")
+        out = self._output_conv(out, crop=(h, w), in_act="elu")
+        return ops.add(x, self._activation(out))
+
+
+class PixelSNAILBlock(nn.Module):
+    def __init__(
+        self,
+        n_channels,
+        input_img_channels=1,
+        n_residual_blocks=2,
+        attention_key_channels=4,
+        attention_value_channels=32,
+    ):
+        super().__init__()
+
+        def conv(in_channels):
+            return pg_nn.Conv2d(in_channels, out_channels=n_channels, kernel_size=1)
+
+        self._residual = nn.Sequential(
+            *[ResidualBlock(n_channels) for _ in range(n_residual_blocks)]
+        )
+        self._attention = pg_nn.CausalAttention(
+            in_channels=n_channels + 2,
+            embed_channels=attention_key_channels,
+            out_channels=attention_value_channels,
+            mask_center=True,
+            extra_input_channels=input_img_channels,
+        )
+        self._residual_out = conv(n_channels)
+        self._attention_out = conv(attention_value_channels)
+        self._out = conv(n_channels)
+
+    def forward(self, x, input_img):
+        res = self._residual(x)
+        pos = pg_nn.image_positional_encoding(input_img.shape, res.device)
+        attn = self._attention(torch.cat((pos, res), dim=1), input_img)
+        res = _elu_conv_elu(self._residual_out, res)
+        attn = _elu_conv_elu(self._attention_out, attn)
+        return _elu_conv_elu(self._out, ops.add(res, attn))
+
+
+class PixelSNAIL(base.AutoregressiveModel):
+    def __init__(
+        self,
+        in_channels=1,
+        out_channels=1,
+        n_channels=64,
+        n_pixel_snail_blocks=8,
+        n_residual_blocks=2,
+        attention_key_channels=4,
+        attention_value_channels=32,
+        sample_fn=None,
+    ):
+        super().__init__(sample_fn)
+        self._input = pg_nn.CausalConv2d(
+            mask_center=True,
+            in_channels=in_channels,
+            out_channels=n_channels,
+            kernel_size=3,
+            padding=1,
+        )
+        self._pixel_snail_blocks = nn.ModuleList(
+            [
+                PixelSNAILBlock(
+                    n_channels=n_channels,
+                    input_img_channels=in_channels,
+                    n_residual_blocks=n_residual_blocks,
+                    attention_key_channels=attention_key_channels,
+                    attention_value_channels=attention_value_channels,
+                )
+                for _ in range(n_pixel_snail_blocks)
+            ]
+        )
+        self._output = nn.Sequential(
+            pg_nn.Conv2d(in_channels=n_channels, out_channels=n_channels // 2, kernel_size=1),
+            pg_nn.Conv2d(in_channels=n_channels // 2, out_channels=out_channels, kernel_size=1),
+        )
+
+    def forward(self, x):
+        input_img = x
+        x = self._input(x)
+        for block in self._pixel_snail_blocks:
+            x = ops.add(x, block(x, input_img))
+        return self._output[1](self._output[0](x))

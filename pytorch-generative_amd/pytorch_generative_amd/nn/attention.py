@@ -1,0 +1,71 @@
+"""Attention-side operators of the hot path, on hand-written gfx950 kernels.
+
+Mirrors CausalAttention (reference nn/attention.py:66-161) and image_positional_encoding
+(:37-57). The L x L score / mask tensors of the reference are never materialised.
+"""
+
+import functools
+
+import torch
+from torch import nn
+
+from pytorch_generative_amd import ops
+from pytorch_generative_amd.nn.convolution import Conv2d
+
+
+@functools.lru_cache(maxsize=32)
+def _posenc_cached(shape, device):
+    return ops.image_positional_encoding(shape, device)
+
+
+def image_positional_encoding(shape, device=None):
+    """(N, 2, H, W) tensor of (row, col) pixel coordinates scaled to [-.5, .5).
+
+    Generated on the GPU and cached per (shape, device) — the reference builds it on the CPU
+    and copies it to the device once per block per step (pixel_snail.py:113).
+    """
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return _posenc_cached(tuple(int(s) for s in shape), torch.device(device))
+
+
+class CausalAttention(nn.Module):
+    """Autoregressively masked multi-head self attention over the pixels of an image."""
+
+    def __init__(
+        self,
+        in_channels,
+        n_heads=1,
+        embed_channels=None,
+        out_channels=None,
+        mask_center=False,
+        extra_input_channels=0,
+    ):
+        super().__init__()
+        self._n_heads = n_heads
+        self._embed_channels = embed_channels or in_channels
+        self._out_channels = out_channels or in_channels
+        self._mask_center = mask_center
+        self._q = Conv2d(in_channels=in_channels, out_channels=self._embed_channels, kernel_size=1)
+        self._kv = Conv2d(
+            in_channels=in_channels + extra_input_channels,
+            out_channels=self._embed_channels + self._out_channels,
+            kernel_size=1,
+        )
+        self._proj = Conv2d(
+            in_channels=self._out_channels, out_channels=self._out_channels, kernel_size=1
+        )
+
+    def forward(self, x, extra_x=None, *, res=None):
+        """x feeds q, k and v; extra_x (optional) is concatenated for k and v only.
+
+        `res` (extension) is added to the projected output inside the projection kernel.
+        """
+        q = self._q(x)
+        if extra_x is not None:
+            x = torch.cat((x, extra_x), dim=1)
+        kv = self._kv(x)
+        out = ops.causal_attention(
+            q, kv, self._n_heads, self._embed_channels, self._out_channels, self._mask_center
+        )
+        return self._proj(out, res=res)

@@ -1,0 +1,488 @@
+"""torch.autograd bindings of the HIP kernels (the only arithmetic on the hot path).
+
+Every function here launches kernels from libpg_hip.so on torch's *current* HIP stream with
+raw device pointers (so a whole training step can be captured into a hipGraph). PyTorch is
+used for memory (caching allocator), streams and the autograd tape only.
+
+Weight gradients: if a parameter carries a `_pg_grad` tensor (a view into the trainer's flat
+gradient buffer, zeroed once per step) the backward kernels accumulate straight into it with
+fp32 atomics and autograd sees `None` for that parameter — no per-parameter AccumulateGrad
+kernels, and the flat buffer is what RCCL all-reduces. Without `_pg_grad` the usual
+`param.grad` protocol is followed.
+"""
+
+import math
+
+import torch
+
+from pytorch_generative_amd import _lib
+
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_GELU = 0, 1, 2, 3
+GATE_TANH, GATE_IDENTITY = 0, 1
+_ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "elu": ACT_ELU, "gelu": ACT_GELU}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name}: expected a tensor on the MI355X (cuda) device, got {t.device}; "
+            "the HIP operator path has no CPU fallback"
+        )
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _sink(param):
+    """Returns the direct gradient sink of a parameter (or None)."""
+    return getattr(param, "_pg_grad", None) if param is not None else None
+
+
+# --------------------------------------------------------------------------------------------
+# convolution over a tap list
+# --------------------------------------------------------------------------------------------
+class ConvSpec:
+    """Static description of one stride-1 convolution as tap lists.
+
+    out[r, c] = sum_t w[:, :, u_t, v_t] . x[r + u_t - pad_h, c + v_t - pad_w]
+    `active` restricts the forward/data-grad taps (the causal mask's non-zero entries,
+    reference nn/convolution.py:35-39). The weight gradient always covers `wgrad_taps`
+    (all taps by default: the reference's weight.grad is unmasked, nn/convolution.py:42).
+    """
+
+    def __init__(self, kh, kw, pad_h, pad_w, active=None, wgrad_all=True):
+        self.kh, self.kw, self.pad_h, self.pad_w = kh, kw, pad_h, pad_w
+        all_taps = [(u, v) for u in range(kh) for v in range(kw)]
+        act = all_taps if active is None else [t for t in all_taps if t in set(active)]
+        if not act:
+            raise ValueError("ConvSpec: no active taps")
+        if len(all_taps) > 64:
+            raise ValueError(f"ConvSpec: {kh}x{kw} kernel has more than 64 taps")
+        self.fwd_taps = act
+        self.wg_taps = all_taps if wgrad_all else act
+        ia = _lib.int_array
+        self.f_dr = ia([u - pad_h for u, _ in act])
+        self.f_dc = ia([v - pad_w for _, v in act])
+        self.f_ndr = ia([pad_h - u for u, _ in act])
+        self.f_ndc = ia([pad_w - v for _, v in act])
+        self.f_u = ia([u for u, _ in act])
+        self.f_v = ia([v for _, v in act])
+        self.w_dr = ia([u - pad_h for u, _ in self.wg_taps])
+        self.w_dc = ia([v - pad_w for _, v in self.wg_taps])
+        self.w_u = ia([u for u, _ in self.wg_taps])
+        self.w_v = ia([v for _, v in self.wg_taps])
+
+    def full_out(self, h, w):
+        return h + 2 * self.pad_h - self.kh + 1, w + 2 * self.pad_w - self.kw + 1
+
+
+def _pack(lib, weight, spec, transpose):
+    cout, cin, kh, kw = weight.shape
+    a, b = (cout, cin) if transpose else (cin, cout)
+    t = len(spec.fwd_taps)
+    b_pad = lib.pg_conv_b_pad(b)
+    wpk = torch.empty(a * t * b_pad, device=weight.device, dtype=torch.float32)
+    _lib.check(
+        lib.pg_pack_conv_weight(
+            weight.data_ptr(), wpk.data_ptr(), cout, cin, kh, kw, t, spec.f_u, spec.f_v,
+            int(transpose), b_pad, _stream(),
+        ),
+        "pg_pack_conv_weight",
+    )
+    return wpk
+
+
+class _ConvTaps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, spec, out_hw, in_act, gw, gb):
+        lib = _lib.load()
+        x = _chk(x, "conv2d.x")
+        weight = _chk(weight, "conv2d.weight")
+        n, cin, ih, iw = x.shape
+        cout = weight.shape[0]
+        if weight.shape[1] != cin:
+            raise ValueError(f"conv2d: weight expects {weight.shape[1]} input channels, got {cin}")
+        oh, ow = out_hw
+        if bias is not None:
+            bias = _chk(bias, "conv2d.bias")
+        if res is not None:
+            res = _chk(res, "conv2d.res")
+            if tuple(res.shape) != (n, cout, oh, ow):
+                raise ValueError("conv2d: residual shape mismatch")
+        wpk = _pack(lib, weight, spec, transpose=False)
+        out = torch.empty((n, cout, oh, ow), device=x.device, dtype=torch.float32)
+        _lib.check(
+            lib.pg_conv2d_taps(
+                x.data_ptr(), wpk.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih, iw,
+                cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, _stream(),
+            ),
+            "pg_conv2d_taps",
+        )
+        ctx.save_for_backward(x, weight)
+        ctx.spec, ctx.in_act, ctx.has_bias, ctx.has_res = spec, in_act, bias is not None, res is not None
+        ctx.gw, ctx.gb = gw, gb
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        spec = ctx.spec
+        dy = _chk(dy, "conv2d.dy")
+        n, cin, ih, iw = x.shape
+        _, cout, oh, ow = dy.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wpk_t = _pack(lib, weight, spec, transpose=True)
+            dx = torch.empty_like(x)
+            _lib.check(
+                lib.pg_conv2d_taps(
+                    dy.data_ptr(), wpk_t.data_ptr(), 0, 0, dx.data_ptr(), n, cout, oh, ow, cin, ih,
+                    iw, len(spec.fwd_taps), spec.f_ndr, spec.f_ndc, ACT_NONE, _stream(),
+                ),
+                "pg_conv2d_taps(dgrad)",
+            )
+            if ctx.in_act != ACT_NONE:
+                _lib.check(
+                    lib.pg_act_bwd(x.data_ptr(), dx.data_ptr(), dx.data_ptr(), dx.numel(),
+                                   ctx.in_act, _stream()),
+                    "pg_act_bwd",
+                )
+        need_w = ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            gw, gb = ctx.gw, ctx.gb
+            if gw is None:
+                dw = torch.zeros_like(weight)
+                gw_t = dw
+            else:
+                gw_t = gw
+            if need_b:
+                if gb is None:
+                    db = torch.zeros(cout, device=x.device, dtype=torch.float32)
+                    gb_t = db
+                else:
+                    gb_t = gb
+            else:
+                gb_t = None
+            _lib.check(
+                lib.pg_conv2d_wgrad(
+                    x.data_ptr(), dy.data_ptr(), gw_t.data_ptr(), _p(gb_t), n, cin, ih, iw, cout,
+                    oh, ow, spec.kh, spec.kw, len(spec.wg_taps), spec.w_dr, spec.w_dc, spec.w_u,
+                    spec.w_v, ctx.in_act, _stream(),
+                ),
+                "pg_conv2d_wgrad",
+            )
+        dres = dy if ctx.has_res else None
+        return dx, dw, db, dres, None, None, None, None, None
+
+
+def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
+                weight_param=None, bias_param=None):
+    """y = conv(act(x)) + bias (+ res), cropped to out_hw (defaults to the full extent)."""
+    if out_hw is None:
+        out_hw = spec.full_out(x.shape[2], x.shape[3])
+    full = spec.full_out(x.shape[2], x.shape[3])
+    if out_hw[0] > full[0] or out_hw[1] > full[1] or min(out_hw) < 1:
+        raise ValueError(f"conv2d: requested output {out_hw} exceeds the full extent {full}")
+    return _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act,
+                           _sink(weight_param), _sink(bias_param))
+
+
+# --------------------------------------------------------------------------------------------
+# NCHW LayerNorm
+# --------------------------------------------------------------------------------------------
+class _NCHWLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, gg, gb):
+        lib = _lib.load()
+        x = _chk(x, "layernorm.x")
+        n, c, h, w = x.shape
+        if gamma.numel() != c:
+            raise ValueError(f"NCHWLayerNorm: normalized_shape {gamma.numel()} != channels {c}")
+        y = torch.empty_like(x)
+        mean = torch.empty(n * h * w, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        _lib.check(
+            lib.pg_nchw_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                      mean.data_ptr(), rstd.data_ptr(), n, c, h * w, eps, _stream()),
+            "pg_nchw_layernorm_fwd",
+        )
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.gg, ctx.gb = gg, gb
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = _chk(dy, "layernorm.dy")
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        dg = db = None
+        gg, gb = ctx.gg, ctx.gb
+        if gg is None:
+            dg = torch.zeros(c, device=x.device, dtype=torch.float32)
+            gg = dg
+        if gb is None:
+            db = torch.zeros(c, device=x.device, dtype=torch.float32)
+            gb = db
+        _lib.check(
+            lib.pg_nchw_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), gg.data_ptr(),
+                                      gb.data_ptr(), n, c, h * w, _stream()),
+            "pg_nchw_layernorm_bwd",
+        )
+        return dx, dg, db, None, None, None
+
+
+def nchw_layernorm(x, weight, bias, eps=1e-5):
+    return _NCHWLayerNorm.apply(x, weight, bias, float(eps), _sink(weight), _sink(bias))
+
+
+# --------------------------------------------------------------------------------------------
+# causal attention core
+# --------------------------------------------------------------------------------------------
+class _CausalAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kv, n_heads, embed, vdim, strict):
+        lib = _lib.load()
+        q = _chk(q, "attention.q")
+        kv = _chk(kv, "attention.kv")
+        n, e, h, w = q.shape
+        if e != embed or kv.shape[1] != embed + vdim:
+            raise ValueError("attention: channel mismatch between q / kv and embed / value dims")
+        if embed % n_heads or vdim % n_heads:
+            raise ValueError("attention: channels not divisible by n_heads")
+        L = h * w
+        dk, dv = embed // n_heads, vdim // n_heads
+        o = torch.empty((n, vdim, h, w), device=q.device, dtype=torch.float32)
+        lse2 = torch.empty((n, n_heads, L), device=q.device, dtype=torch.float32)
+        k_ptr = kv.data_ptr()
+        v_ptr = kv.data_ptr() + 4 * embed * L
+        _lib.check(
+            lib.pg_causal_attn_fwd(q.data_ptr(), k_ptr, v_ptr, o.data_ptr(), lse2.data_ptr(), n,
+                                   n_heads, L, dk, dv, embed * L, (embed + vdim) * L,
+                                   (embed + vdim) * L, vdim * L, int(strict), _stream()),
+            "pg_causal_attn_fwd",
+        )
+        ctx.save_for_backward(q, kv, o, lse2)
+        ctx.cfg = (n_heads, embed, vdim, int(strict))
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        lib = _lib.load()
+        q, kv, o, lse2 = ctx.saved_tensors
+        n_heads, embed, vdim, strict = ctx.cfg
+        d_o = _chk(d_o, "attention.d_o")
+        n, _, h, w = q.shape
+        L = h * w
+        dk, dv = embed // n_heads, vdim // n_heads
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        delta = torch.empty_like(lse2)
+        kvs = (embed + vdim) * L
+        _lib.check(
+            lib.pg_causal_attn_bwd(
+                q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * embed * L, o.data_ptr(),
+                d_o.data_ptr(), lse2.data_ptr(), delta.data_ptr(), dq.data_ptr(), dkv.data_ptr(),
+                dkv.data_ptr() + 4 * embed * L, n, n_heads, L, dk, dv, embed * L, kvs, kvs,
+                vdim * L, vdim * L, embed * L, kvs, kvs, strict, _stream(),
+            ),
+            "pg_causal_attn_bwd",
+        )
+        return dq, dkv, None, None, None, None
+
+
+def causal_attention(q, kv, n_heads, embed_channels, value_channels, mask_center):
+    """softmax(mask(q k^T / sqrt(d_k))) v over raster-ordered pixels; kv = cat(k, v) on dim 1."""
+    return _CausalAttention.apply(q, kv, n_heads, embed_channels, value_channels, bool(mask_center))
+
+
+# --------------------------------------------------------------------------------------------
+# elementwise
+# --------------------------------------------------------------------------------------------
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        lib = _lib.load()
+        x = _chk(x, "act.x")
+        y = torch.empty_like(x)
+        _lib.check(lib.pg_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), act, _stream()), "pg_act_fwd")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = _chk(dy, "act.dy")
+        dx = torch.empty_like(x)
+        _lib.check(lib.pg_act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), ctx.act,
+                                  _stream()), "pg_act_bwd")
+        return dx, None
+
+
+def relu(x):
+    return _Act.apply(x, ACT_RELU)
+
+
+def elu(x):
+    return _Act.apply(x, ACT_ELU)
+
+
+def gelu(x):
+    return _Act.apply(x, ACT_GELU)
+
+
+class _Gated(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gate):
+        lib = _lib.load()
+        x = _chk(x, "gated.x")
+        n, c2, h, w = x.shape
+        assert c2 % 2 == 0, "x must have an even number of channels."
+        y = torch.empty((n, c2 // 2, h, w), device=x.device, dtype=torch.float32)
+        _lib.check(lib.pg_gated_fwd(x.data_ptr(), y.data_ptr(), n, c2 // 2, h * w, gate, _stream()),
+                   "pg_gated_fwd")
+        ctx.save_for_backward(x)
+        ctx.gate = gate
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = _chk(dy, "gated.dy")
+        n, c2, h, w = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(lib.pg_gated_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, c2 // 2, h * w,
+                                    ctx.gate, _stream()), "pg_gated_bwd")
+        return dx, None
+
+
+def gated_activation(x, gate):
+    return _Gated.apply(x, gate)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        a = _chk(a, "add.a")
+        b = _chk(b, "add.b")
+        if a.shape != b.shape:
+            raise ValueError(f"add: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        out = torch.empty_like(a)
+        _lib.check(lib.pg_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "pg_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _AddBcast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, gp):
+        lib = _lib.load()
+        x = _chk(x, "add_bcast.x")
+        p = _chk(p, "add_bcast.p")
+        per = p.numel()
+        if x.numel() % per or tuple(x.shape[1:]) != tuple(p.shape[-(x.dim() - 1):]):
+            raise ValueError(f"add_bcast: {tuple(p.shape)} does not broadcast over {tuple(x.shape)}")
+        y = torch.empty_like(x)
+        _lib.check(lib.pg_add_bcast_fwd(x.data_ptr(), p.data_ptr(), y.data_ptr(), x.shape[0], per,
+                                        _stream()), "pg_add_bcast_fwd")
+        ctx.gp = gp
+        ctx.pshape = p.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = _chk(dy, "add_bcast.dy")
+        dp = None
+        gp = ctx.gp
+        if ctx.needs_input_grad[1]:
+            if gp is None:
+                dp = torch.zeros(ctx.pshape, device=dy.device, dtype=torch.float32)
+                gp = dp
+            per = gp.numel()
+            _lib.check(lib.pg_add_bcast_bwd(dy.data_ptr(), gp.data_ptr(), dy.shape[0], per, _stream()),
+                       "pg_add_bcast_bwd")
+        return (dy if ctx.needs_input_grad[0] else None), dp, None
+
+
+def add_broadcast_batch(x, p):
+    """x + p where p has batch dim 1 (the learned positional map of ImageGPT)."""
+    return _AddBcast.apply(x, p, _sink(p))
+
+
+def image_positional_encoding(shape, device):
+    lib = _lib.load()
+    n, _, h, w = shape
+    out = torch.empty((n, 2, h, w), device=device, dtype=torch.float32)
+    if not out.is_cuda:
+        raise RuntimeError("image_positional_encoding: the HIP path needs a cuda device")
+    _lib.check(lib.pg_image_positional_encoding(out.data_ptr(), n, h, w, _stream()),
+               "pg_image_positional_encoding")
+    return out
+
+
+def mul_inplace_(w, mask):
+    lib = _lib.load()
+    if not (w.is_cuda and mask.is_cuda and w.is_contiguous() and mask.is_contiguous()):
+        raise RuntimeError("mul_inplace_: expects contiguous cuda tensors")
+    _lib.check(lib.pg_mul_inplace(w.data_ptr(), mask.data_ptr(), w.numel(), _stream()), "pg_mul_inplace")
+    return w
+
+
+# --------------------------------------------------------------------------------------------
+# loss
+# --------------------------------------------------------------------------------------------
+class _BCEWithLogitsSumMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, x):
+        lib = _lib.load()
+        z = _chk(z, "bce.logits")
+        x = _chk(x, "bce.targets")
+        if z.numel() != x.numel():
+            raise ValueError("bce: logits/targets size mismatch")
+        n = z.shape[0]
+        loss = torch.zeros(1, device=z.device, dtype=torch.float32)
+        _lib.check(lib.pg_bce_logits_fwd(z.data_ptr(), x.data_ptr(), loss.data_ptr(), n,
+                                         z.numel() // n, _stream()), "pg_bce_logits_fwd")
+        ctx.save_for_backward(z, x)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        z, x = ctx.saved_tensors
+        g = _chk(g.reshape(1), "bce.grad")
+        n = z.shape[0]
+        dz = torch.empty_like(z)
+        _lib.check(lib.pg_bce_logits_bwd(z.data_ptr(), x.data_ptr(), g.data_ptr(), dz.data_ptr(), n,
+                                         z.numel() // n, _stream()), "pg_bce_logits_bwd")
+        return dz, None
+
+
+def bce_with_logits_sum_mean(logits, targets):
+    """F.binary_cross_entropy_with_logits(reduction='none').sum(pixels).mean(batch)
+    (reference image_gpt.py:158-162 and every other AR reproduce())."""
+    return _BCEWithLogitsSumMean.apply(logits, targets)
