@@ -1,0 +1,239 @@
+"""bench.py — training throughput of the hot path on MI355X (driver contract: see README/DESIGN).
+
+    python bench.py --gpus 1 --steps K --warmup W          # single GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = the reference's Trainer._train_one_batch (trainer.py:173-193): zero_grad, forward,
+BCE-with-logits loss, backward, global grad norm, Adam, lr decay — on one resident batch of
+synthetic binarised-MNIST-shaped images, replayed from a hipGraph. Workload: BASELINE.json
+configs[1], ImageGPT 8 blocks / 4 heads / 16 embedding channels on 28x28x1 (fp32: the reference
+is fp32 end to end and parity is gated at 1e-4; see DESIGN.md for the bf16 note).
+Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "pytorch-generative_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MODEL_KW = dict(in_channels=1, out_channels=1, in_size=28, n_transformer_blocks=8,
+                n_attention_heads=4, n_embedding_channels=16)
+LR, LR_DECAY = 5e-3, 0.999977  # reference reproduce(): image_gpt.py:155-156
+HEADS, DK, DV, L = 4, 4, 4, 784
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix == vector peak (no TF32 on gfx950)
+
+
+def synthetic_batch(batch, rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    return torch.bernoulli(torch.full((batch, 1, 28, 28), 0.1307), generator=g)
+
+
+def attention_kernel_roofline(batch, device, iters=10):
+    """Times the dominant kernel (the causal-attention backward: dQ and dK/dV launches of
+    pg_causal_attn_bwd) live with HIP events on the stream it is launched on, at the bench's
+    exact shapes and on random data. Algorithmic FLOPs per launch are defined in DESIGN.md:
+    pairs = N*heads*L*(L+1)/2 allowed (query,key) pairs;
+    dQ pass 2*(2dk+dv) = 24 flop/pair... see DESIGN.md §kernels."""
+    from pytorch_generative_amd import ops
+
+    e = HEADS * DK
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(batch, e, 28, 28, generator=g).to(device).requires_grad_(True)
+    kv = torch.randn(batch, 2 * e, 28, 28, generator=g).to(device).requires_grad_(True)
+    d_o = torch.randn(batch, e, 28, 28, generator=g).to(device)
+    stream = torch.cuda.current_stream()
+    # forward
+    o = ops.causal_attention(q, kv, HEADS, e, e, False)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * iters + 2)]
+    for i in range(iters):
+        ev[2 * i].record(stream)
+        o = ops.causal_attention(q, kv, HEADS, e, e, False)
+        ev[2 * i + 1].record(stream)
+    torch.cuda.synchronize()
+    fwd_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(iters)) / iters
+    bwd_ms = 0.0
+    for i in range(iters):
+        o = ops.causal_attention(q, kv, HEADS, e, e, False)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        o.backward(d_o)
+        b.record(stream)
+        torch.cuda.synchronize()
+        bwd_ms += a.elapsed_time(b)
+        q.grad = kv.grad = None
+    bwd_ms /= iters
+    pairs = batch * HEADS * L * (L + 1) / 2
+    flop_fwd = pairs * (2 * DK + 2 * DV)                      # QK^T + PV
+    flop_bwd = pairs * ((2 * DK + 2 * DV + 2 * DK) + (2 * DK + 2 * DV + 2 * DV + 2 * DK))
+    return {
+        "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
+        "fwd_tflops": flop_fwd / fwd_ms / 1e9, "bwd_tflops": flop_bwd / bwd_ms / 1e9,
+        "flop_fwd": flop_fwd, "flop_bwd": flop_bwd,
+    }
+
+
+def cpu_baseline(batch=16, steps=2):
+    """The oracle's restatement of the same training step on the host cores (kind 'port': the
+    reference is Python and cannot travel to the GPU box; the oracle dispatches the same torch
+    CPU primitives). Bounded sample: 1 warm-up + `steps` timed steps at a reduced batch."""
+    from oracle import models as omodels
+    from oracle import train as otrain
+
+    import pytorch_generative_amd as pg
+
+    torch.manual_seed(0)
+    model = pg.models.ImageGPT(**MODEL_KW)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = synthetic_batch(batch, 0)
+    opt_state = otrain.new_opt_state()
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        _, loss, grads = otrain.loss_and_grads(omodels.image_gpt, state, x, n_heads=HEADS)
+        otrain.adam_step_(state, grads, opt_state, lr=LR)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps
+    return {
+        "value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"oracle train step (torch-CPU fp32), batch {batch}, {steps} timed steps after 1 warm-up, "
+                  f"{dt * 1e3:.0f} ms/step",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+    import pytorch_generative_amd as pg
+    from pytorch_generative_amd import graph, ops, optim, parallel
+
+    torch.manual_seed(0)  # identical initial weights on every rank (then broadcast anyway)
+    model = pg.models.ImageGPT(**MODEL_KW).to(device)
+    model.train()
+    opt = optim.FlatAdam(model.parameters(), lr=LR, lr_decay=LR_DECAY)
+    reducer = None
+    if world > 1:
+        reducer = parallel.FlatGradAllReduce(opt)
+        reducer.broadcast_parameters(src=0)
+    x = synthetic_batch(args.batch, rank).to(device)
+    loss_fn = lambda xx, preds: ops.bce_with_logits_sum_mean(preds, xx)  # noqa: E731
+
+    if args.no_graph:
+        def step():
+            opt.zero_grad()
+            loss = loss_fn(x, model(x))
+            loss.backward()
+            if reducer is not None:
+                reducer.all_reduce()
+            opt.step()
+            return loss.detach()
+    else:
+        gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
+        step = lambda: gstep()  # noqa: E731
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        global_batch = args.batch * world
+        value = global_batch * args.steps / elapsed
+        out = {
+            "metric": "training images/sec (ImageGPT 8-block/4-head/16-embed, 28x28x1)",
+            "value": value,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[1]: ImageGPT 8 blocks / 4 heads / 16 embed on "
+                            "28x28x1 binarised-MNIST-shaped synthetic; one step = zero_grad + fwd + "
+                            "BCE + bwd + global grad-norm + Adam + lr decay (reference trainer.py:173-193)",
+                "per_gpu_batch": args.batch,
+                "global_batch": global_batch,
+                "parallelism": f"dp{world}",
+                "launch": "eager" if args.no_graph else "hipGraph replay",
+            },
+            "loss_nats_per_image": loss_val,
+            "bits_per_dim": loss_val / (784 * 0.6931471805599453),
+        }
+        if world == 1:
+            r = attention_kernel_roofline(args.batch, device)
+            out["roofline"] = {
+                "bound": "mfma",
+                "kernel": "pg_causal_attn_bwd (attn_bwd_dq_kernel<4,4> + attn_bwd_dkv_kernel<4,4>)",
+                "achieved": r["bwd_tflops"],
+                "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": r["bwd_tflops"] / FP32_PEAK_TFLOPS,
+                "traffic": None,
+                "launch_ms": r["bwd_ms"],
+                "flop_per_launch": r["flop_bwd"],
+                "fwd_kernel": {"achieved": r["fwd_tflops"], "launch_ms": r["fwd_ms"],
+                               "frac": r["fwd_tflops"] / FP32_PEAK_TFLOPS},
+            }
+            # whole-step view against SURVEY §8(d)'s per-image algorithmic work (1.223 GF, 26.2 MB)
+            out["roofline"]["step_tflops"] = value * 1.223e9 / 1e12
+            out["roofline"]["step_hbm_gbps_algorithmic"] = value * 26.2e6 / 1e9
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,279 @@
+"""GPU: every HIP kernel, called through the C-ABI (ctypes ops), against the CPU oracle on the
+same seeded inputs. Tolerance for fp32 results: 1e-4 relative to the tensor's max magnitude
+(BASELINE.json north_star); masks / positional encodings are bit-exact."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _util
+from oracle import ops as oops
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from pytorch_generative_amd import _lib
+
+    _lib.load()  # fail loudly if the extension is missing
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # (N, Cin, H, W, Cout, kh, kw, ph, pw, crop, active, in_act, use_res, use_bias)
+    (2, 1, 28, 28, 16, 3, 3, 1, 1, None, "A", None, False, True),       # ImageGPT input conv
+    (2, 3, 32, 32, 64, 3, 3, 1, 1, None, "A", None, False, True),       # PixelSNAIL input conv
+    (2, 1, 28, 28, 64, 7, 7, 3, 3, None, "A", None, False, True),       # PixelCNN input conv
+    (2, 32, 28, 28, 32, 3, 3, 1, 1, None, "B", "relu", False, True),    # PixelCNN residual conv
+    (2, 64, 32, 32, 128, 2, 2, 1, 1, "hw", None, "elu", False, True),   # PixelSNAIL 2x2 (cropped)
+    (2, 16, 12, 12, 32, 1, 3, 0, 1, None, None, None, False, True),     # gated vstack 1xN
+    (2, 16, 12, 12, 32, 2, 1, 2, 0, "hw", None, None, False, True),     # gated vstack Nx1 (crop rows)
+    (2, 16, 12, 12, 32, 1, 2, 0, 1, "hw", None, None, True, True),      # gated hstack 1xN + link res
+    (2, 3, 12, 12, 32, 1, 4, 0, 4, "hw", None, None, False, True),      # gated input layer (k=7, mask_center)
+    (3, 16, 28, 28, 64, 1, 1, 0, 0, None, None, None, False, True),     # 1x1 (vector path)
+    (3, 64, 28, 28, 16, 1, 1, 0, 0, None, None, "gelu", True, True),    # 1x1 + fused gelu + residual
+    (2, 69, 32, 32, 36, 1, 1, 0, 0, None, None, None, False, True),     # SNAIL _kv 69->36 (ragged channels)
+    (2, 5, 7, 7, 3, 1, 1, 0, 0, None, None, "relu", False, False),      # L % 4 != 0 scalar path, no bias
+    (2, 5, 9, 11, 7, 3, 3, 1, 1, None, "B", None, True, True),          # odd sizes, OW % 4 != 0
+    (1, 4, 64, 64, 8, 3, 3, 1, 1, None, None, None, False, True),       # 64x64: several row tiles
+]
+
+
+def _active(kind, kh, kw):
+    if kind is None:
+        return None
+    m = oops.causal_mask(kh, kw, kind == "A")
+    return [(u, v) for u in range(kh) for v in range(kw) if m[u, v] != 0]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:9]))
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    from pytorch_generative_amd import ops
+
+    n, cin, h, w, cout, kh, kw, ph, pw, crop, active, in_act, use_res, use_bias = case
+    x = _rand(n, cin, h, w, seed=1)
+    wt = _rand(cout, cin, kh, kw, seed=2, scale=0.2)
+    b = _rand(cout, seed=3) if use_bias else None
+    act_fn = {None: lambda t: t, "relu": F.relu, "elu": F.elu, "gelu": F.gelu}[in_act]
+    taps = _active(active, kh, kw)
+    mask = torch.ones(kh, kw) if taps is None else oops.causal_mask(kh, kw, active == "A")
+    spec = ops.ConvSpec(kh, kw, ph, pw, active=taps, wgrad_all=True)
+    oh, ow = (h, w) if crop == "hw" else spec.full_out(h, w)
+    res = _rand(n, cout, oh, ow, seed=4) if use_res else None
+
+    # oracle (reference semantics: weight already masked in place -> full wgrad)
+    xo = x.clone().requires_grad_(True)
+    wo = (wt * mask).clone().requires_grad_(True)
+    bo = b.clone().requires_grad_(True) if use_bias else None
+    yo = F.conv2d(act_fn(xo), wo, bo, padding=(ph, pw))[:, :, :oh, :ow]
+    if use_res:
+        yo = yo + res
+    dy = _rand(*yo.shape, seed=5)
+    yo.backward(dy)
+
+    xg = x.to(dev).requires_grad_(True)
+    wg = (wt * mask).to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True) if use_bias else None
+    yg = ops.conv2d_taps(xg, wg, bg, spec, out_hw=(oh, ow),
+                         in_act=ops._ACT_IDS[in_act], res=None if res is None else res.to(dev))
+    _util.assert_close(yg, yo, TOL, "conv fwd")
+    yg.backward(dy.to(dev))
+    _util.assert_close(xg.grad, xo.grad, TOL, "conv dgrad")
+    _util.assert_close(wg.grad, wo.grad, TOL, "conv wgrad")
+    if use_bias:
+        _util.assert_close(bg.grad, bo.grad, TOL, "conv bgrad")
+
+
+def test_conv_weight_grad_sink_accumulates(dev):
+    """With a `_pg_grad` sink the wgrad kernel accumulates into it and autograd sees None."""
+    from pytorch_generative_amd import nn as pg_nn
+
+    torch.manual_seed(0)
+    conv = pg_nn.Conv2d(8, 8, kernel_size=1).to(dev)
+    x = _rand(2, 8, 8, 8, seed=1).to(dev)
+    conv(x).sum().backward()
+    g_ref = conv.weight.grad.clone()
+    conv.weight.grad = None
+    conv.weight._pg_grad = torch.ones_like(conv.weight)
+    conv.bias._pg_grad = torch.zeros_like(conv.bias)
+    conv(x).sum().backward()
+    assert conv.weight.grad is None
+    _util.assert_close(conv.weight._pg_grad - 1.0, g_ref, TOL, "sink")
+
+
+@pytest.mark.parametrize("n,c,h,w", [(3, 16, 28, 28), (2, 8, 7, 7), (2, 64, 9, 9), (1, 70, 5, 5)])
+def test_nchw_layernorm(dev, n, c, h, w):
+    from pytorch_generative_amd import ops
+
+    x = _rand(n, c, h, w, seed=1, scale=3.0) + 0.5
+    gam, bet = _rand(c, seed=2) + 1.0, _rand(c, seed=3)
+    dy = _rand(n, c, h, w, seed=4)
+    xo, go, bo = (t.clone().requires_grad_(True) for t in (x, gam, bet))
+    yo = oops.nchw_layernorm(xo, go, bo)
+    yo.backward(dy)
+    xg, gg, bg = (t.to(dev).requires_grad_(True) for t in (x, gam, bet))
+    yg = ops.nchw_layernorm(xg, gg, bg, 1e-5)
+    assert yg.is_contiguous()
+    _util.assert_close(yg, yo, TOL, "ln fwd")
+    yg.backward(dy.to(dev))
+    _util.assert_close(xg.grad, xo.grad, TOL, "ln dx")
+    _util.assert_close(gg.grad, go.grad, TOL, "ln dgamma")
+    _util.assert_close(bg.grad, bo.grad, TOL, "ln dbeta")
+
+
+ATTN_CASES = [
+    # (N, heads, dk, dv, H, W, strict)
+    (2, 4, 4, 4, 28, 28, False),   # ImageGPT baseline block
+    (2, 1, 4, 32, 32, 32, True),   # PixelSNAIL block
+    (2, 2, 32, 32, 12, 12, False),  # ImageGPT reproduce() shape (2 heads x 32)
+    (2, 2, 2, 2, 7, 7, False),     # reference MultipleChannelsTests (L=49, ragged chunks)
+    (1, 1, 4, 4, 5, 5, True),      # L < 64, strict, L % 8 != 0
+    (2, 3, 8, 16, 9, 7, True),     # odd everything
+    (1, 2, 48, 40, 8, 8, False),   # padded head dims (64-template)
+    (1, 1, 4, 4, 18, 18, True),    # L = 324: more than one 256-query block
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=lambda c: "-".join(str(int(v)) for v in c))
+def test_causal_attention_core(dev, case):
+    from pytorch_generative_amd import ops
+
+    n, heads, dk, dv, h, w, strict = case
+    e, v = heads * dk, heads * dv
+    q = _rand(n, e, h, w, seed=1)
+    kv = _rand(n, e + v, h, w, seed=2)
+    d_o = _rand(n, v, h, w, seed=3)
+    qo, kvo = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    oo = oops.causal_attention_core(qo, kvo[:, :e], kvo[:, e:], heads, strict)
+    oo.backward(d_o)
+    qg, kvg = q.to(dev).requires_grad_(True), kv.to(dev).requires_grad_(True)
+    og = ops.causal_attention(qg, kvg, heads, e, v, strict)
+    _util.assert_close(og, oo, TOL, "attn fwd")
+    if strict:  # the row with no allowed key is exactly zero (reference: NaN -> masked_fill 0)
+        assert torch.equal(og[:, :, 0, 0].cpu(), torch.zeros(n, v))
+    og.backward(d_o.to(dev))
+    _util.assert_close(qg.grad, qo.grad, TOL, "attn dq")
+    _util.assert_close(kvg.grad[:, :e], kvo.grad[:, :e], TOL, "attn dk")
+    _util.assert_close(kvg.grad[:, e:], kvo.grad[:, e:], TOL, "attn dv")
+
+
+def test_attention_large_scores_stay_finite(dev):
+    """Online-softmax rescale branch: a spike late in the key sequence forces the running max to
+    jump; compare with the oracle on the same data."""
+    from pytorch_generative_amd import ops
+
+    q = _rand(1, 4, 16, 16, seed=1)
+    kv = _rand(1, 8, 16, 16, seed=2)
+    kv[0, :4, 9, 3] = 40.0   # one huge key
+    q[0, :, 12, 0] = 30.0    # one query that loves it
+    oo = oops.causal_attention_core(q, kv[:, :4], kv[:, 4:], 1, False)
+    og = ops.causal_attention(q.to(dev), kv.to(dev), 1, 4, 4, False)
+    assert torch.isfinite(og).all()
+    _util.assert_close(og, oo, TOL, "attn spike")
+
+
+def test_attention_uniform_values_property(dev):
+    """Full size property (L=1024, N=8): with V constant over positions the output equals V for
+    every query that has at least one allowed key, whatever q/k are."""
+    from pytorch_generative_amd import ops
+
+    n, e, v, h, w = 8, 4, 32, 32, 32
+    q = _rand(n, e, h, w, seed=1, scale=3.0).to(dev)
+    kv = _rand(n, e + v, h, w, seed=2, scale=3.0).to(dev)
+    const = _rand(n, v, 1, 1, seed=3).to(dev)
+    kv[:, e:] = const
+    out = ops.causal_attention(q, kv, 1, e, v, True)
+    want = const.expand(n, v, h, w).clone()
+    want[:, :, 0, 0] = 0
+    assert float((out - want).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("act", ["relu", "elu", "gelu"])
+def test_activations(dev, act):
+    from pytorch_generative_amd import ops
+
+    fn = {"relu": F.relu, "elu": F.elu, "gelu": F.gelu}[act]
+    x = _rand(3, 5, 7, 9, seed=1, scale=2.0)
+    dy = _rand(3, 5, 7, 9, seed=2)
+    xo = x.clone().requires_grad_(True)
+    yo = fn(xo)
+    yo.backward(dy)
+    xg = x.to(dev).requires_grad_(True)
+    yg = getattr(ops, act)(xg)
+    _util.assert_close(yg, yo, 1e-5, act)
+    yg.backward(dy.to(dev))
+    _util.assert_close(xg.grad, xo.grad, 1e-5, act + " grad")
+
+
+@pytest.mark.parametrize("kind", ["tanh", "identity"])
+def test_gated_activation(dev, kind):
+    from pytorch_generative_amd import ops
+
+    x = _rand(2, 12, 6, 5, seed=1)
+    dy = _rand(2, 6, 6, 5, seed=2)
+    xo = x.clone().requires_grad_(True)
+    yo = oops.gated_activation(xo, kind)
+    yo.backward(dy)
+    xg = x.to(dev).requires_grad_(True)
+    yg = ops.gated_activation(xg, ops.GATE_TANH if kind == "tanh" else ops.GATE_IDENTITY)
+    _util.assert_close(yg, yo, 1e-5, "gate")
+    yg.backward(dy.to(dev))
+    _util.assert_close(xg.grad, xo.grad, 1e-5, "gate grad")
+
+
+def test_add_and_broadcast_add(dev):
+    from pytorch_generative_amd import ops
+
+    a, b = _rand(2, 3, 5, 7, seed=1), _rand(2, 3, 5, 7, seed=2)
+    assert torch.equal(ops.add(a.to(dev), b.to(dev)).cpu(), a + b)
+    p = _rand(1, 3, 5, 7, seed=3)
+    dy = _rand(2, 3, 5, 7, seed=4)
+    pg = p.to(dev).requires_grad_(True)
+    y = ops.add_broadcast_batch(a.to(dev), pg)
+    assert torch.equal(y.cpu(), a + p)
+    y.backward(dy.to(dev))
+    _util.assert_close(pg.grad, dy.sum(0, keepdim=True), 1e-6, "dpos")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 32, 32), (1, 1, 28, 28), (2, 3, 8, 8), (1, 3, 64, 64)])
+def test_positional_encoding_bit_exact(dev, shape):
+    from pytorch_generative_amd import nn as pg_nn
+
+    got = pg_nn.image_positional_encoding(shape, dev).cpu()
+    assert torch.equal(got, oops.image_positional_encoding(shape))
+
+
+def test_causal_mask_buffers_bit_exact_and_inplace_masking(dev):
+    from pytorch_generative_amd import nn as pg_nn
+
+    for k, mc in [(3, True), (3, False), (7, True), (5, False)]:
+        conv = pg_nn.CausalConv2d(mc, 2, 3, kernel_size=k, padding=k // 2).to(dev)
+        assert torch.equal(conv.mask[0, 0].cpu(), oops.causal_mask(k, k, mc))
+        w0 = conv.weight.detach().clone()
+        conv(torch.zeros(1, 2, 8, 8, device=dev))
+        # reference side effect: weight.data *= mask on every forward (nn/convolution.py:42)
+        assert torch.equal(conv.weight.detach(), w0 * conv.mask)
+
+
+def test_bce_loss(dev):
+    from pytorch_generative_amd import ops
+
+    z = _rand(4, 1, 28, 28, seed=1, scale=3.0)
+    x = torch.bernoulli(torch.full((4, 1, 28, 28), 0.13), generator=torch.Generator().manual_seed(2))
+    zo = z.clone().requires_grad_(True)
+    lo = oops.bce_sum_mean(zo, x)
+    lo.backward()
+    zg = z.to(dev).requires_grad_(True)
+    lg = ops.bce_with_logits_sum_mean(zg, x.to(dev))
+    _util.assert_close(lg, lo, 1e-5, "bce")
+    lg.backward()
+    _util.assert_close(zg.grad, zo.grad, 1e-5, "bce grad")

@@ -1,0 +1,126 @@
+"""CPU: host-side logic — the C-ABI library loads and exports every symbol the header declares,
+the module surface matches the reference's state_dict layout, argument errors follow the
+reference's convention, and the flat-gradient all-reduce is correct under gloo (world_size 2)."""
+
+import os
+import re
+
+import pytest
+import torch
+
+import _util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from pytorch_generative_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "pg_hip.h")).read()
+    declared = set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pg_abi_version() == _lib.ABI_VERSION
+    assert lib.pg_conv_b_pad(1) == 16 and lib.pg_conv_b_pad(17) == 32
+    assert lib.pg_packed_weight_floats(3, 5, 20) == 3 * 5 * 32
+
+
+def test_argument_errors_without_gpu(lib):
+    """Status codes -> exceptions; no kernel is launched for rejected arguments."""
+    from pytorch_generative_amd import _lib
+
+    ia = _lib.int_array
+    rc = lib.pg_conv2d_taps(0, 0, 0, 0, 0, 1, 1, 4, 4, 1, 4, 4, 1, ia([0]), ia([0]), 0, 0)
+    assert rc == -1
+    with pytest.raises(ValueError, match="null pointer"):
+        _lib.check(rc, "pg_conv2d_taps")
+    rc = lib.pg_causal_attn_fwd(1, 1, 1, 1, 1, 2, 1, 16, 128, 4, 0, 0, 0, 0, 0, 0)
+    assert rc == -2  # head dim 128 unsupported: explicit error, no silent fallback
+    with pytest.raises(ValueError, match="unsupported"):
+        _lib.check(rc, "pg_causal_attn_fwd")
+
+
+@pytest.mark.parametrize("name", _util.golden_names())
+def test_state_dict_layout_matches_reference(name):
+    import pytorch_generative_amd as pg
+
+    g = _util.load_golden(name)
+    model = getattr(pg.models, g["ctor"])(**g["kwargs"])
+    want = {k: tuple(v.shape) for k, v in g["state0"].items() if k not in ("_c", "_h", "_w")}
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert got == want
+    sd = dict(g["state0"])  # a checkpoint saved after training also holds the lazy buffers
+    _, c, h, w = g["x"].shape
+    sd.update({"_c": torch.tensor(c), "_h": torch.tensor(h), "_w": torch.tensor(w)})
+    model.load_state_dict(sd, strict=True)
+    assert (int(model._c), int(model._h), int(model._w)) == (c, h, w)
+    for k, v in g["state0"].items():
+        if k.endswith(".mask"):
+            assert torch.equal(model.state_dict()[k], v), k  # causal masks bit-exact
+
+
+def test_hip_path_has_no_cpu_fallback():
+    import pytorch_generative_amd as pg
+
+    conv = pg.nn.CausalConv2d(True, 1, 4, kernel_size=3, padding=1)
+    with pytest.raises(RuntimeError, match="cuda"):
+        conv(torch.zeros(1, 1, 8, 8))
+    with pytest.raises(ValueError):
+        pg.nn.Conv2d(1, 1, 3, stride=2)
+    with pytest.raises(ValueError):
+        pg.nn.GatedActivation(activation_fn=torch.relu)
+
+
+def test_conv_spec_taps():
+    from pytorch_generative_amd import ops
+
+    s = ops.ConvSpec(2, 2, 1, 1)  # PixelSNAIL 2x2 pad 1 (cropped): taps (-1,-1)...(0,0)
+    assert sorted(zip(s.f_dr, s.f_dc)) == [(-1, -1), (-1, 0), (0, -1), (0, 0)]
+    s = ops.ConvSpec(3, 3, 1, 1, active=[(0, 0), (0, 1), (0, 2), (1, 0)])
+    assert len(s.fwd_taps) == 4 and len(s.wg_taps) == 9
+    assert list(zip(s.f_ndr, s.f_ndc))[0] == (1, 1)
+    s = ops.ConvSpec(2, 1, 2, 0)  # gated vstack (k//2+1)x1, padding k//2+1 for k=3
+    assert sorted(s.f_dr) == [-2, -1] and s.full_out(8, 8) == (11, 8)
+
+
+def _gloo_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pytorch_generative_amd import parallel
+
+    class _Opt:  # the two attributes FlatGradAllReduce needs, on CPU
+        def __init__(self):
+            self.flat_grad = torch.full((10,), float(rank + 1))
+            self.flat_param = torch.full((10,), float(rank))
+            self.prescale = None
+
+        def set_grad_prescale(self, s):
+            self.prescale = s
+
+    opt = _Opt()
+    red = parallel.FlatGradAllReduce(opt)
+    red.broadcast_parameters(src=0)
+    red.all_reduce()
+    ok = (opt.prescale == 1.0 / world and torch.equal(opt.flat_param, torch.zeros(10))
+          and torch.equal(opt.flat_grad, torch.full((10,), 3.0)))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert dict(ret) == {0: True, 1: True}
