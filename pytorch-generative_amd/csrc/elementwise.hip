@@ -143,8 +143,23 @@ __global__ void add_bcast_bwd_kernel(const float* __restrict__ dy, float* __rest
   dp[i] += s;
 }
 
-// torch.arange(-0.5, 0.5, 1/h) is computed as start + i*step in the accumulate type
-// (double for a float32 result on CPU), then rounded to float32.
+// torch.arange(-0.5, 0.5, 1/h) on torch-CPU (the reference builds the encoding on the host,
+// nn/attention.py:53-54) is NOT simply (float)(start + i*step): ATen's vectorised loop handles
+// the first floor(n/16)*16 elements as 8-wide vectors, each computed as
+//   (float) fma(j, step, (double)(float) fma(b0, step, start)),  b0 = 8*(i/8), j = i - b0
+// and the remaining < 16 elements as (float) fma(i, step, start), all in double with fused
+// multiply-adds (verified bit-exact for every h in 2..600 on this image's AVX-512 torch build).
+__device__ __forceinline__ float arange_like_torch_cpu(int i, int n, double step) {
+  const double start = -0.5;
+  const int nvec = (n / 16) * 16;
+  if (i < nvec) {
+    const int b0 = (i / 8) * 8;
+    const float base = (float)fma((double)b0, step, start);
+    return (float)fma((double)(i - b0), step, (double)base);
+  }
+  return (float)fma((double)i, step, start);
+}
+
 __global__ void posenc_kernel(float* __restrict__ out, int N, int H, int W) {
   const size_t HW = (size_t)H * W;
   const size_t total = (size_t)N * 2 * HW;
@@ -154,9 +169,8 @@ __global__ void posenc_kernel(float* __restrict__ out, int N, int H, int W) {
     const int ch = (int)(r / HW);
     const int hw = (int)(r - (size_t)ch * HW);
     const int row = hw / W, col = hw - row * W;
-    const double step = ch == 0 ? 1.0 / (double)H : 1.0 / (double)W;
-    const int idx = ch == 0 ? row : col;
-    out[i] = (float)(-0.5 + (double)idx * step);
+    out[i] = ch == 0 ? arange_like_torch_cpu(row, H, 1.0 / (double)H)
+                     : arange_like_torch_cpu(col, W, 1.0 / (double)W);
   }
 }
 

@@ -69,7 +69,7 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = g
         st = torch.zeros(8, dtype=torch.float32)
         st[_LR], st[_LRMUL] = lr, lr_decay
-        st[_MAXNORM] = 1e50 if max_norm is None else max_norm  # saturates to +inf in fp32: never clips
+        st[_MAXNORM] = float("inf") if max_norm is None else max_norm  # 1e50 overflows fp32: never clips
         st[_PRESCALE] = 1.0
         self.state_block = st.to(dev)
         self._host_lr = lr

@@ -103,7 +103,7 @@ class Trainer:
             self._reducer.broadcast_parameters(src=0)
         if self._flat:
             max_norm = clip_grad_norm or skip_grad_norm
-            optimizer.state_block[pg_optim._MAXNORM] = 1e50 if max_norm is None else float(max_norm)
+            optimizer.state_block[pg_optim._MAXNORM] = float("inf") if max_norm is None else float(max_norm)
 
         self._step = 0
         self._epoch = 0
