@@ -8,23 +8,26 @@
 // host->device on every forward; here nothing L*L ever exists (online softmax; the mask is
 // the predicate key <= query - strict).
 //
-// CDNA4 mapping (head dims here are tiny: d_k = d_v = 4 for ImageGPT, 4/32 for PixelSNAIL, so
-// an MFMA tile would be mostly padding):
-//  * one lane owns one query row (forward, dQ) or one key row (dK/dV); its q / o / running
-//    max+sum live in VGPRs for the whole kernel.
-//  * the row being streamed (keys in fwd/dQ, queries in dK/dV) is WAVE-UNIFORM, so it is
-//    read through the scalar unit (s_load_dwordxN straight from the channel-major (d, L)
-//    layout the 1x1 convs emit) and enters the FMAs as SGPR operands: no LDS, no barriers,
-//    no transposes. Loop bounds are wave-uniform (readfirstlane) so the causal triangle is
-//    skipped per wave, and only the 64-wide diagonal band pays for per-lane predicates.
-//  * exp via v_exp_f32 in the log2 domain (scale*log2(e) folded into q).
+// CDNA4 mapping (head dims on this path are tiny: d_k = d_v = 4 for ImageGPT, 4/32 for
+// PixelSNAIL — an MFMA tile would be mostly padding, and exp dominates):
+//  * "row-owner" formulation: one lane owns QPL (=2) query rows (forward, dQ) or key rows
+//    (dK/dV); q / o / running max+sum / gradients of its rows stay in VGPRs for the whole kernel.
+//  * the opposite operand (keys+values in fwd/dQ, queries+dO+lse+delta in dK/dV) is streamed
+//    through LDS in tiles of [KT rows][row-interleaved channels]; every lane of a wave reads the
+//    SAME row at the same time, i.e. LDS broadcast reads (ds_read_b128, conflict free), and the
+//    row is reused by both of the lane's own rows. (Measured on MI355X: the first version read the
+//    streamed rows through the scalar cache (s_load_dwordx8 -> SGPR operands); it was bound by
+//    scalar-load latency / issue — LDS tiles + 2 rows per lane run 1.4x faster.)
+//  * loop bounds are wave-uniform (readfirstlane), so the causal triangle is skipped per wave
+//    and only the diagonal band pays for per-lane predicates.
+//  * exp via v_exp_f32 in the log2 domain (scale*log2(e) folded into q resp. k).
 #include "common.h"
 
 namespace {
 
-constexpr int AT_THREADS = 256;
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float POS_BIG = 1.0e30f;
+constexpr int QPL = 2;  // rows owned per lane
 
 struct AttnArgs {
   const float* q; const float* k; const float* v; const float* o; const float* d_o;
@@ -33,255 +36,317 @@ struct AttnArgs {
   int N, heads, L, dk_dim, dv_dim, strict;
   long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;
   float scale, scale2;  // 1/sqrt(dk), log2(e)/sqrt(dk)
+  int nwaves;           // waves per block; a block owns 64*QPL*nwaves consecutive rows
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int DK, int DV> struct ChunkOf {
-  static constexpr int value = (DK + DV <= 8) ? 8 : ((DK + DV <= 16) ? 4 : 2);
+template <int DK, int DV> struct Cfg {
+  static constexpr int RS = DK + DV;        // floats per staged key row (fwd / dQ)
+  static constexpr int RS2 = DK + DV + 4;   // floats per staged query row (dK/dV): q|dO|lse|delta|pad
+  static constexpr int CH = (RS <= 8) ? 8 : ((RS <= 16) ? 4 : 2);
+  static constexpr int KT = (RS <= 16) ? 256 : ((RS <= 48) ? 128 : 64);  // rows per LDS tile
 };
 
-// Load CH consecutive positions of D channel rows (row stride L) starting at `pos`. The
-// addresses are wave-uniform, so this becomes D s_load_dwordx{CH} instructions. Padded
-// channels (i >= dim) re-read the last real row (their multiplier is zero / result unused).
-template <int D, int CH, bool CLAMP>
-__device__ __forceinline__ void load_rows(float (&dst)[D][CH], const float* __restrict__ base,
-                                          int dim, int L, int pos) {
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    const float* r = base + (size_t)(i < dim ? i : dim - 1) * L;
-    if (CLAMP) {
-#pragma unroll
-      for (int c = 0; c < CH; ++c) dst[i][c] = r[min(pos + c, L - 1)];
-    } else {
-      const float* rp = r + pos;
-#pragma unroll
-      for (int c = 0; c < CH; ++c) dst[i][c] = rp[c];
+// Stage KT rows [m0, m0+KT) of two channel-major sources (a: DA chans, b: DB chans) into the
+// row-interleaved LDS tile. Global reads are coalesced along the row index; padded channels and
+// rows >= L are zero filled.
+template <int DA, int DB, int RS, int KT>
+__device__ __forceinline__ void stage_rows(float* __restrict__ tile, const float* __restrict__ a,
+                                           int da, const float* __restrict__ b, int db, int L,
+                                           int m0, int tid, int nthreads) {
+  for (int idx = tid; idx < (DA + DB) * KT; idx += nthreads) {
+    const int c = idx / KT;
+    const int m = idx - c * KT;
+    const int gm = m0 + m;
+    float val = 0.f;
+    if (gm < L) {
+      if (c < DA) {
+        if (c < da) val = a[(size_t)c * L + gm];
+      } else if (c - DA < db) {
+        val = b[(size_t)(c - DA) * L + gm];
+      }
     }
+    tile[m * RS + c] = val;
   }
 }
 
-template <int CH, bool CLAMP>
-__device__ __forceinline__ void load_row1(float (&dst)[CH], const float* __restrict__ r, int L,
-                                          int pos) {
+template <int D>
+__device__ __forceinline__ void read_row(float (&dst)[D], const float* __restrict__ src) {
+  static_assert(D % 4 == 0, "row pieces are float4 multiples");
 #pragma unroll
-  for (int c = 0; c < CH; ++c) dst[c] = CLAMP ? r[min(pos + c, L - 1)] : r[pos + c];
+  for (int i = 0; i < D / 4; ++i) {
+    const float4 t = reinterpret_cast<const float4*>(src)[i];
+    dst[4 * i] = t.x; dst[4 * i + 1] = t.y; dst[4 * i + 2] = t.z; dst[4 * i + 3] = t.w;
+  }
 }
 
 // ------------------------------------------------------------------------------ forward
-template <int DK, int DV, int CH, bool MASKED, bool CLAMP>
-__device__ __forceinline__ void fwd_chunk(const float (&qv)[DK], float (&acc)[DV], float& mrun,
-                                          float& lsum, const float* __restrict__ kp,
-                                          const float* __restrict__ vp, int dk, int dv, int L,
-                                          int m, int my_last) {
-  float kk[DK][CH], vv[DV][CH];
-  load_rows<DK, CH, CLAMP>(kk, kp, dk, L, m);
-  load_rows<DV, CH, CLAMP>(vv, vp, dv, L, m);
-  float s[CH];
-  float cmax = NEG_BIG;
+template <int DK, int DV, bool MASKED>
+__device__ __forceinline__ void fwd_chunk(const float* __restrict__ rows, int mglob,
+                                          const float (&qv)[QPL][DK], float (&acc)[QPL][DV],
+                                          float (&mrun)[QPL], float (&lsum)[QPL],
+                                          const int (&my_last)[QPL]) {
+  constexpr int CH = Cfg<DK, DV>::CH, RS = Cfg<DK, DV>::RS;
+  float kk[CH][DK], vv[CH][DV];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < DK; ++i) t = fmaf(qv[i], kk[i][c], t);
-    if (MASKED) t = (m + c) <= my_last ? t : NEG_BIG;
-    s[c] = t;
-    cmax = fmaxf(cmax, t);
+    read_row<DK>(kk[c], rows + c * RS);
+    read_row<DV>(vv[c], rows + c * RS + DK);
   }
-  const float mnew = fmaxf(mrun, cmax);
-  const float alpha = fast_exp2(mrun - mnew);
-  lsum *= alpha;
 #pragma unroll
-  for (int j = 0; j < DV; ++j) acc[j] *= alpha;
+  for (int u = 0; u < QPL; ++u) {
+    float s[CH];
+    float cmax = NEG_BIG;
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    float p = fast_exp2(s[c] - mnew);
-    if (MASKED) p = (m + c) <= my_last ? p : 0.f;
-    lsum += p;
+    for (int c = 0; c < CH; ++c) {
+      float t = qv[u][0] * kk[c][0];
 #pragma unroll
-    for (int j = 0; j < DV; ++j) acc[j] = fmaf(p, vv[j][c], acc[j]);
+      for (int i = 1; i < DK; ++i) t = fmaf(qv[u][i], kk[c][i], t);
+      if (MASKED) t = (mglob + c) <= my_last[u] ? t : NEG_BIG;
+      s[c] = t;
+      cmax = fmaxf(cmax, t);
+    }
+    const float mnew = fmaxf(mrun[u], cmax);
+    const float alpha = fast_exp2(mrun[u] - mnew);
+    lsum[u] *= alpha;
+#pragma unroll
+    for (int j = 0; j < DV; ++j) acc[u][j] *= alpha;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float p = fast_exp2(s[c] - mnew);
+      if (MASKED) p = (mglob + c) <= my_last[u] ? p : 0.f;
+      lsum[u] += p;
+#pragma unroll
+      for (int j = 0; j < DV; ++j) acc[u][j] = fmaf(p, vv[c][j], acc[u][j]);
+    }
+    mrun[u] = mnew;
   }
-  mrun = mnew;
 }
 
 template <int DK, int DV>
-__global__ void __launch_bounds__(AT_THREADS) attn_fwd_kernel(const AttnArgs a) {
-  constexpr int CH = ChunkOf<DK, DV>::value;
-  const int qb = gridDim.x - 1 - blockIdx.x;  // heaviest (largest l) blocks first
+__global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs a) {
+  using C = Cfg<DK, DV>;
+  extern __shared__ float4 lds4[];
+  float* tile = reinterpret_cast<float*>(lds4);
   const int h = blockIdx.y, n = blockIdx.z;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   const int L = a.L;
-  const int l0 = qb * AT_THREADS + wave * 64;
-  if (l0 >= L) return;
-  const int l = l0 + (threadIdx.x & 63);
-  const bool valid = l < L;
-  const int lc = valid ? l : L - 1;
+  const int rows_per_block = 64 * QPL * a.nwaves;
+  const int qb = gridDim.x - 1 - blockIdx.x;  // heaviest blocks first
+  const int b0 = qb * rows_per_block;
+  const int l0 = b0 + wave * 64 * QPL;        // first row of this wave
+  const bool wave_on = l0 < L;
 
   const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * a.dk_dim * L;
   const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * a.dk_dim * L;
   const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * a.dv_dim * L;
 
-  float qv[DK];
+  int lq[QPL], my_last[QPL];
+  float qv[QPL][DK], acc[QPL][DV], mrun[QPL], lsum[QPL];
 #pragma unroll
-  for (int i = 0; i < DK; ++i) qv[i] = i < a.dk_dim ? qp[(size_t)i * L + lc] * a.scale2 : 0.f;
+  for (int u = 0; u < QPL; ++u) {
+    lq[u] = l0 + u * 64 + lane;
+    const int lc = min(lq[u], L - 1);
+    my_last[u] = lc - a.strict;
+    mrun[u] = NEG_BIG;
+    lsum[u] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DK; ++i) qv[u][i] = (wave_on && i < a.dk_dim) ? qp[(size_t)i * L + lc] * a.scale2 : 0.f;
+#pragma unroll
+    for (int j = 0; j < DV; ++j) acc[u][j] = 0.f;
+  }
+  // wave-uniform key ranges
+  const int wl_max = min(l0 + 64 * QPL - 1, L - 1);
+  const int m_end = wave_on ? wl_max - a.strict + 1 : 0;           // keys needed by some lane
+  const int m_full = wave_on ? max(0, l0 - a.strict + 1) : 0;      // keys allowed for every lane
+  const int blk_end = min(b0 + rows_per_block - 1, L - 1) - a.strict + 1;  // keys the block needs
 
-  float mrun = NEG_BIG, lsum = 0.f;
-  float acc[DV];
-#pragma unroll
-  for (int j = 0; j < DV; ++j) acc[j] = 0.f;
+  for (int m0 = 0; m0 < blk_end; m0 += C::KT) {
+    __syncthreads();
+    stage_rows<DK, DV, C::RS, C::KT>(tile, kp, a.dk_dim, vp, a.dv_dim, L, m0, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int t_end = min(m0 + C::KT, m_end);
+    int m = m0;
+    const int t_full = min(t_end, (m_full / C::CH) * C::CH);
+    for (; m < t_full; m += C::CH)
+      fwd_chunk<DK, DV, false>(tile + (m - m0) * C::RS, m, qv, acc, mrun, lsum, my_last);
+    for (; m < t_end; m += C::CH)  // diagonal band (rows >= L in the tile are zero filled)
+      fwd_chunk<DK, DV, true>(tile + (m - m0) * C::RS, m, qv, acc, mrun, lsum, my_last);
+  }
 
-  const int lmax = min(l0 + 63, L - 1);
-  const int m_end = lmax - a.strict + 1;            // keys [0, m_end) are needed by some lane
-  int m_full = l0 - a.strict + 1;                   // keys [0, m_full) are allowed for every lane
-  m_full = m_full < 0 ? 0 : (m_full / CH) * CH;
-  const int my_last = lc - a.strict;                // last allowed key of this lane
-
-  int m = 0;
-  for (; m < m_full; m += CH)
-    fwd_chunk<DK, DV, CH, false, false>(qv, acc, mrun, lsum, kp, vp, a.dk_dim, a.dv_dim, L, m, my_last);
-  // diagonal band: per-lane predicate
-  for (; m + CH <= L && m < m_end; m += CH)
-    fwd_chunk<DK, DV, CH, true, false>(qv, acc, mrun, lsum, kp, vp, a.dk_dim, a.dv_dim, L, m, my_last);
-  // ragged last chunk (L % CH != 0): clamped (still wave-uniform) indices
-  for (; m < m_end; m += CH)
-    fwd_chunk<DK, DV, CH, true, true>(qv, acc, mrun, lsum, kp, vp, a.dk_dim, a.dv_dim, L, m, my_last);
-
-  if (!valid) return;
-  const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-  float* op = a.o_out + (size_t)n * a.o_bs + (size_t)h * a.dv_dim * L + l;
 #pragma unroll
-  for (int j = 0; j < DV; ++j)
-    if (j < a.dv_dim) op[(size_t)j * L] = acc[j] * inv;
-  a.lse2_out[((size_t)n * a.heads + h) * L + l] = lsum > 0.f ? mrun + log2f(lsum) : POS_BIG;
-}
-
-// --------------------------------------------------------------------------- backward: dQ
-template <int DK, int DV, int CH, bool MASKED, bool CLAMP>
-__device__ __forceinline__ void dq_chunk(const float (&qv)[DK], const float (&gv)[DV],
-                                         float (&dqv)[DK], float lse, float delta,
-                                         const float* __restrict__ kp,
-                                         const float* __restrict__ vp, int dk, int dv, int L,
-                                         int m, int my_last) {
-  float kk[DK][CH], vv[DV][CH];
-  load_rows<DK, CH, CLAMP>(kk, kp, dk, L, m);
-  load_rows<DV, CH, CLAMP>(vv, vp, dv, L, m);
+  for (int u = 0; u < QPL; ++u) {
+    if (lq[u] < L) {
+      const float inv = lsum[u] > 0.f ? 1.f / lsum[u] : 0.f;
+      float* op = a.o_out + (size_t)n * a.o_bs + (size_t)h * a.dv_dim * L + lq[u];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    float t = 0.f, dp = 0.f;
-#pragma unroll
-    for (int i = 0; i < DK; ++i) t = fmaf(qv[i], kk[i][c], t);
-#pragma unroll
-    for (int j = 0; j < DV; ++j) dp = fmaf(gv[j], vv[j][c], dp);
-    float p = fast_exp2(t - lse);
-    if (MASKED) p = (m + c) <= my_last ? p : 0.f;
-    const float ds = p * (dp - delta);
-#pragma unroll
-    for (int i = 0; i < DK; ++i) dqv[i] = fmaf(ds, kk[i][c], dqv[i]);
+      for (int j = 0; j < DV; ++j)
+        if (j < a.dv_dim) op[(size_t)j * L] = acc[u][j] * inv;
+      a.lse2_out[((size_t)n * a.heads + h) * L + lq[u]] =
+          lsum[u] > 0.f ? mrun[u] + log2f(lsum[u]) : POS_BIG;
+    }
   }
 }
 
-// lane = query. Also writes delta[l] = sum_j do[l,j]*o[l,j] for the dK/dV pass.
+// --------------------------------------------------------------------------- backward: dQ
+template <int DK, int DV, bool MASKED>
+__device__ __forceinline__ void dq_chunk(const float* __restrict__ rows, int mglob,
+                                         const float (&qv)[QPL][DK], const float (&gv)[QPL][DV],
+                                         float (&dqv)[QPL][DK], const float (&lse)[QPL],
+                                         const float (&delta)[QPL], const int (&my_last)[QPL]) {
+  constexpr int CH = Cfg<DK, DV>::CH, RS = Cfg<DK, DV>::RS;
+  float kk[CH][DK], vv[CH][DV];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    read_row<DK>(kk[c], rows + c * RS);
+    read_row<DV>(vv[c], rows + c * RS + DK);
+  }
+#pragma unroll
+  for (int u = 0; u < QPL; ++u) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float t = qv[u][0] * kk[c][0];
+#pragma unroll
+      for (int i = 1; i < DK; ++i) t = fmaf(qv[u][i], kk[c][i], t);
+      float dp = gv[u][0] * vv[c][0];
+#pragma unroll
+      for (int j = 1; j < DV; ++j) dp = fmaf(gv[u][j], vv[c][j], dp);
+      float p = fast_exp2(t - lse[u]);
+      if (MASKED) p = (mglob + c) <= my_last[u] ? p : 0.f;
+      const float ds = p * (dp - delta[u]);
+#pragma unroll
+      for (int i = 0; i < DK; ++i) dqv[u][i] = fmaf(ds, kk[c][i], dqv[u][i]);
+    }
+  }
+}
+
+// lane = QPL queries. Also writes delta[l] = sum_j do[l,j]*o[l,j] for the dK/dV pass.
 template <int DK, int DV>
-__global__ void __launch_bounds__(AT_THREADS) attn_bwd_dq_kernel(const AttnArgs a) {
-  constexpr int CH = ChunkOf<DK, DV>::value;
-  const int qb = gridDim.x - 1 - blockIdx.x;
+__global__ void __launch_bounds__(512) attn_bwd_dq_kernel(const AttnArgs a) {
+  using C = Cfg<DK, DV>;
+  extern __shared__ float4 lds4[];
+  float* tile = reinterpret_cast<float*>(lds4);
   const int h = blockIdx.y, n = blockIdx.z;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   const int L = a.L;
-  const int l0 = qb * AT_THREADS + wave * 64;
-  if (l0 >= L) return;
-  const int l = l0 + (threadIdx.x & 63);
-  const bool valid = l < L;
-  const int lc = valid ? l : L - 1;
+  const int rows_per_block = 64 * QPL * a.nwaves;
+  const int qb = gridDim.x - 1 - blockIdx.x;
+  const int b0 = qb * rows_per_block;
+  const int l0 = b0 + wave * 64 * QPL;
+  const bool wave_on = l0 < L;
 
   const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * a.dk_dim * L;
   const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * a.dk_dim * L;
   const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * a.dv_dim * L;
   const float* op = a.o + (size_t)n * a.o_bs + (size_t)h * a.dv_dim * L;
   const float* gp = a.d_o + (size_t)n * a.do_bs + (size_t)h * a.dv_dim * L;
-
-  float qv[DK], dqv[DK], gv[DV];
-#pragma unroll
-  for (int i = 0; i < DK; ++i) {
-    qv[i] = i < a.dk_dim ? qp[(size_t)i * L + lc] * a.scale2 : 0.f;
-    dqv[i] = 0.f;
-  }
-  float delta = 0.f;
-#pragma unroll
-  for (int j = 0; j < DV; ++j) {
-    gv[j] = j < a.dv_dim ? gp[(size_t)j * L + lc] : 0.f;
-    const float ov = j < a.dv_dim ? op[(size_t)j * L + lc] : 0.f;
-    delta = fmaf(gv[j], ov, delta);
-  }
   const size_t row = ((size_t)n * a.heads + h) * L;
-  const float lse = a.lse2_in[row + lc];
-  if (valid) a.delta[row + l] = delta;
 
-  const int lmax = min(l0 + 63, L - 1);
-  const int m_end = lmax - a.strict + 1;
-  int m_full = l0 - a.strict + 1;
-  m_full = m_full < 0 ? 0 : (m_full / CH) * CH;
-  const int my_last = lc - a.strict;
-
-  int m = 0;
-  for (; m < m_full; m += CH)
-    dq_chunk<DK, DV, CH, false, false>(qv, gv, dqv, lse, delta, kp, vp, a.dk_dim, a.dv_dim, L, m, my_last);
-  for (; m + CH <= L && m < m_end; m += CH)
-    dq_chunk<DK, DV, CH, true, false>(qv, gv, dqv, lse, delta, kp, vp, a.dk_dim, a.dv_dim, L, m, my_last);
-  for (; m < m_end; m += CH)
-    dq_chunk<DK, DV, CH, true, true>(qv, gv, dqv, lse, delta, kp, vp, a.dk_dim, a.dv_dim, L, m, my_last);
-
-  if (!valid) return;
-  float* dqp = a.dq + (size_t)n * a.dq_bs + (size_t)h * a.dk_dim * L + l;
+  int lq[QPL], my_last[QPL];
+  float qv[QPL][DK], dqv[QPL][DK], gv[QPL][DV], lse[QPL], delta[QPL];
 #pragma unroll
-  for (int i = 0; i < DK; ++i)
-    if (i < a.dk_dim) dqp[(size_t)i * L] = dqv[i] * a.scale;
+  for (int u = 0; u < QPL; ++u) {
+    lq[u] = l0 + u * 64 + lane;
+    const int lc = min(lq[u], L - 1);
+    my_last[u] = lc - a.strict;
+#pragma unroll
+    for (int i = 0; i < DK; ++i) {
+      qv[u][i] = (wave_on && i < a.dk_dim) ? qp[(size_t)i * L + lc] * a.scale2 : 0.f;
+      dqv[u][i] = 0.f;
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+      const bool ok = wave_on && j < a.dv_dim;
+      gv[u][j] = ok ? gp[(size_t)j * L + lc] : 0.f;
+      const float ov = ok ? op[(size_t)j * L + lc] : 0.f;
+      d = fmaf(gv[u][j], ov, d);
+    }
+    delta[u] = d;
+    lse[u] = wave_on ? a.lse2_in[row + lc] : POS_BIG;
+    if (lq[u] < L) a.delta[row + lq[u]] = d;
+  }
+  const int wl_max = min(l0 + 64 * QPL - 1, L - 1);
+  const int m_end = wave_on ? wl_max - a.strict + 1 : 0;
+  const int m_full = wave_on ? max(0, l0 - a.strict + 1) : 0;
+  const int blk_end = min(b0 + rows_per_block - 1, L - 1) - a.strict + 1;
+
+  for (int m0 = 0; m0 < blk_end; m0 += C::KT) {
+    __syncthreads();
+    stage_rows<DK, DV, C::RS, C::KT>(tile, kp, a.dk_dim, vp, a.dv_dim, L, m0, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int t_end = min(m0 + C::KT, m_end);
+    int m = m0;
+    const int t_full = min(t_end, (m_full / C::CH) * C::CH);
+    for (; m < t_full; m += C::CH)
+      dq_chunk<DK, DV, false>(tile + (m - m0) * C::RS, m, qv, gv, dqv, lse, delta, my_last);
+    for (; m < t_end; m += C::CH)
+      dq_chunk<DK, DV, true>(tile + (m - m0) * C::RS, m, qv, gv, dqv, lse, delta, my_last);
+  }
+#pragma unroll
+  for (int u = 0; u < QPL; ++u) {
+    if (lq[u] < L) {
+      float* dqp = a.dq + (size_t)n * a.dq_bs + (size_t)h * a.dk_dim * L + lq[u];
+#pragma unroll
+      for (int i = 0; i < DK; ++i)
+        if (i < a.dk_dim) dqp[(size_t)i * L] = dqv[u][i] * a.scale;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------ backward: dK, dV
-template <int DK, int DV, int CH, bool MASKED, bool CLAMP>
-__device__ __forceinline__ void dkv_chunk(const float (&kv)[DK], const float (&vv)[DV],
-                                          float (&dkv)[DK], float (&dvv)[DV],
-                                          const float* __restrict__ qp,
-                                          const float* __restrict__ gp,
-                                          const float* __restrict__ lsep,
-                                          const float* __restrict__ dlp, int dk, int dv, int L,
-                                          int lq, int my_first) {
-  float qq[DK][CH], gg[DV][CH], ls[CH], dl[CH];
-  load_rows<DK, CH, CLAMP>(qq, qp, dk, L, lq);
-  load_rows<DV, CH, CLAMP>(gg, gp, dv, L, lq);
-  load_row1<CH, CLAMP>(ls, lsep, L, lq);
-  load_row1<CH, CLAMP>(dl, dlp, L, lq);
+// staged query row: [q(DK) | dO(DV) | lse2 | delta | pad pad]
+template <int DK, int DV, bool MASKED>
+__device__ __forceinline__ void dkv_chunk(const float* __restrict__ rows, int lglob, int L,
+                                          const float (&kv)[QPL][DK], const float (&vv)[QPL][DV],
+                                          float (&dkv)[QPL][DK], float (&dvv)[QPL][DV],
+                                          const int (&my_first)[QPL]) {
+  constexpr int CH = Cfg<DK, DV>::CH, RS2 = Cfg<DK, DV>::RS2;
+  float qq[CH][DK], gg[CH][DV], ld[CH][4];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    float t = 0.f, dp = 0.f;
+    read_row<DK>(qq[c], rows + c * RS2);
+    read_row<DV>(gg[c], rows + c * RS2 + DK);
+    read_row<4>(ld[c], rows + c * RS2 + DK + DV);
+  }
 #pragma unroll
-    for (int i = 0; i < DK; ++i) t = fmaf(kv[i], qq[i][c], t);
+  for (int u = 0; u < QPL; ++u) {
 #pragma unroll
-    for (int j = 0; j < DV; ++j) dp = fmaf(vv[j], gg[j][c], dp);
-    float p = fast_exp2(t - ls[c]);
-    if (MASKED) p = ((lq + c) >= my_first && (lq + c) < L) ? p : 0.f;
-    const float ds = p * (dp - dl[c]);
+    for (int c = 0; c < CH; ++c) {
+      float t = kv[u][0] * qq[c][0];
 #pragma unroll
-    for (int j = 0; j < DV; ++j) dvv[j] = fmaf(p, gg[j][c], dvv[j]);
+      for (int i = 1; i < DK; ++i) t = fmaf(kv[u][i], qq[c][i], t);
+      float dp = vv[u][0] * gg[c][0];
 #pragma unroll
-    for (int i = 0; i < DK; ++i) dkv[i] = fmaf(ds, qq[i][c], dkv[i]);
+      for (int j = 1; j < DV; ++j) dp = fmaf(vv[u][j], gg[c][j], dp);
+      float p = fast_exp2(t - ld[c][0]);
+      if (MASKED) p = ((lglob + c) >= my_first[u] && (lglob + c) < L) ? p : 0.f;
+      const float ds = p * (dp - ld[c][1]);
+#pragma unroll
+      for (int j = 0; j < DV; ++j) dvv[u][j] = fmaf(p, gg[c][j], dvv[u][j]);
+#pragma unroll
+      for (int i = 0; i < DK; ++i) dkv[u][i] = fmaf(ds, qq[c][i], dkv[u][i]);
+    }
   }
 }
 
-// lane = key m; streams the queries l >= m + strict through the scalar unit.
+// lane = QPL keys; streams the queries l >= key + strict through LDS tiles.
 template <int DK, int DV>
-__global__ void __launch_bounds__(AT_THREADS) attn_bwd_dkv_kernel(const AttnArgs a) {
-  constexpr int CH = ChunkOf<DK, DV>::value;
-  const int kb = blockIdx.x;  // smallest keys (most queries) first
+__global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(const AttnArgs a) {
+  using C = Cfg<DK, DV>;
+  extern __shared__ float4 lds4[];
+  float* tile = reinterpret_cast<float*>(lds4);
   const int h = blockIdx.y, n = blockIdx.z;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   const int L = a.L;
-  const int m0 = kb * AT_THREADS + wave * 64;
-  if (m0 >= L) return;
-  const int mkey = m0 + (threadIdx.x & 63);
-  const bool valid = mkey < L;
-  const int mc_ = valid ? mkey : L - 1;
+  const int rows_per_block = 64 * QPL * a.nwaves;
+  const int b0 = blockIdx.x * rows_per_block;  // smallest keys (most queries) first
+  const int m0w = b0 + wave * 64 * QPL;
+  const bool wave_on = m0w < L;
 
   const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * a.dk_dim * L;
   const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * a.dk_dim * L;
@@ -291,71 +356,120 @@ __global__ void __launch_bounds__(AT_THREADS) attn_bwd_dkv_kernel(const AttnArgs
   const float* lsep = a.lse2_in + row;
   const float* dlp = a.delta + row;
 
-  float kv[DK], dkv[DK], vv[DV], dvv[DV];
+  int mk[QPL], my_first[QPL];
+  float kv[QPL][DK], dkv[QPL][DK], vv[QPL][DV], dvv[QPL][DV];
 #pragma unroll
-  for (int i = 0; i < DK; ++i) {
-    kv[i] = i < a.dk_dim ? kp[(size_t)i * L + mc_] * a.scale2 : 0.f;
-    dkv[i] = 0.f;
+  for (int u = 0; u < QPL; ++u) {
+    mk[u] = m0w + u * 64 + lane;
+    const int mc = min(mk[u], L - 1);
+    my_first[u] = mc + a.strict;
+#pragma unroll
+    for (int i = 0; i < DK; ++i) {
+      kv[u][i] = (wave_on && i < a.dk_dim) ? kp[(size_t)i * L + mc] * a.scale2 : 0.f;
+      dkv[u][i] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+      vv[u][j] = (wave_on && j < a.dv_dim) ? vp[(size_t)j * L + mc] : 0.f;
+      dvv[u][j] = 0.f;
+    }
   }
-#pragma unroll
-  for (int j = 0; j < DV; ++j) {
-    vv[j] = j < a.dv_dim ? vp[(size_t)j * L + mc_] : 0.f;
-    dvv[j] = 0.f;
+  // wave-uniform query ranges: band [w_lo, w_full) needs predicates, [w_full, L) is unmasked
+  const int w_lo = ((m0w + a.strict) / C::CH) * C::CH;
+  const int w_full = ((min(m0w + 64 * QPL - 1, L - 1) + a.strict + C::CH - 1) / C::CH) * C::CH;
+  const int L_full_end = (L / C::CH) * C::CH;
+  const int blk_lo = ((b0 + a.strict) / C::KT) * C::KT;  // first tile the block needs
+
+  for (int t0 = blk_lo; t0 < L; t0 += C::KT) {
+    __syncthreads();
+    // q | dO
+    for (int idx = threadIdx.x; idx < (DK + DV) * C::KT; idx += blockDim.x) {
+      const int c = idx / C::KT;
+      const int m = idx - c * C::KT;
+      const int gl = t0 + m;
+      float val = 0.f;
+      if (gl < L) {
+        if (c < DK) {
+          if (c < a.dk_dim) val = qp[(size_t)c * L + gl];
+        } else if (c - DK < a.dv_dim) {
+          val = gp[(size_t)(c - DK) * L + gl];
+        }
+      }
+      tile[m * C::RS2 + c] = val;
+    }
+    // lse2 | delta (rows >= L get lse = +BIG -> p = 0)
+    for (int m = threadIdx.x; m < C::KT; m += blockDim.x) {
+      const int gl = t0 + m;
+      tile[m * C::RS2 + DK + DV] = gl < L ? lsep[gl] : POS_BIG;
+      tile[m * C::RS2 + DK + DV + 1] = gl < L ? dlp[gl] : 0.f;
+    }
+    __syncthreads();
+    if (!wave_on) continue;
+    const int t_end = min(t0 + C::KT, L);
+    int lq = max(t0, w_lo);
+    // leading band
+    const int band_end = min(t_end, w_full);
+    for (; lq < band_end; lq += C::CH)
+      dkv_chunk<DK, DV, true>(tile + (lq - t0) * C::RS2, lq, L, kv, vv, dkv, dvv, my_first);
+    const int full_end = min(t_end, L_full_end);
+    for (; lq < full_end; lq += C::CH)
+      dkv_chunk<DK, DV, false>(tile + (lq - t0) * C::RS2, lq, L, kv, vv, dkv, dvv, my_first);
+    for (; lq < t_end; lq += C::CH)  // ragged tail (zero / +BIG filled rows beyond L)
+      dkv_chunk<DK, DV, true>(tile + (lq - t0) * C::RS2, lq, L, kv, vv, dkv, dvv, my_first);
   }
 
-  // queries l >= key + strict. Band [m0+strict, l_full) needs predicates; [l_full, L) is
-  // allowed for every lane of the wave.
-  const int my_first = mc_ + a.strict;
-  int lq = ((m0 + a.strict) / CH) * CH;
-  int l_full = ((m0 + 63 + a.strict + CH - 1) / CH) * CH;
-  const int l_band_end = l_full < L ? l_full : L;
-  const int L_full_end = (L / CH) * CH;
-
-  for (; lq + CH <= L && lq < l_band_end; lq += CH)
-    dkv_chunk<DK, DV, CH, true, false>(kv, vv, dkv, dvv, qp, gp, lsep, dlp, a.dk_dim, a.dv_dim, L, lq, my_first);
-  for (; lq < L_full_end; lq += CH)
-    dkv_chunk<DK, DV, CH, false, false>(kv, vv, dkv, dvv, qp, gp, lsep, dlp, a.dk_dim, a.dv_dim, L, lq, my_first);
-  // ragged tail (L % CH != 0)
-  for (; lq < L; lq += CH)
-    dkv_chunk<DK, DV, CH, true, true>(kv, vv, dkv, dvv, qp, gp, lsep, dlp, a.dk_dim, a.dv_dim, L, lq, my_first);
-
-  if (!valid) return;
-  float* dkp = a.dk + (size_t)n * a.dk_bs + (size_t)h * a.dk_dim * L + mkey;
-  float* dvp = a.dv + (size_t)n * a.dv_bs + (size_t)h * a.dv_dim * L + mkey;
 #pragma unroll
-  for (int i = 0; i < DK; ++i)
-    if (i < a.dk_dim) dkp[(size_t)i * L] = dkv[i] * a.scale;
+  for (int u = 0; u < QPL; ++u) {
+    if (mk[u] < L) {
+      float* dkp = a.dk + (size_t)n * a.dk_bs + (size_t)h * a.dk_dim * L + mk[u];
+      float* dvp = a.dv + (size_t)n * a.dv_bs + (size_t)h * a.dv_dim * L + mk[u];
 #pragma unroll
-  for (int j = 0; j < DV; ++j)
-    if (j < a.dv_dim) dvp[(size_t)j * L] = dvv[j];
+      for (int i = 0; i < DK; ++i)
+        if (i < a.dk_dim) dkp[(size_t)i * L] = dkv[u][i] * a.scale;
+#pragma unroll
+      for (int j = 0; j < DV; ++j)
+        if (j < a.dv_dim) dvp[(size_t)j * L] = dvv[u][j];
+    }
+  }
 }
 
 enum { K_FWD = 0, K_DQ = 1, K_DKV = 2 };
 
 template <int DK, int DV>
-void launch_one(int which, const AttnArgs& a, dim3 grid, hipStream_t st) {
-  if (which == K_FWD) hipLaunchKernelGGL((attn_fwd_kernel<DK, DV>), grid, dim3(AT_THREADS), 0, st, a);
-  else if (which == K_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<DK, DV>), grid, dim3(AT_THREADS), 0, st, a);
-  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DK, DV>), grid, dim3(AT_THREADS), 0, st, a);
+void launch_one(int which, const AttnArgs& a, dim3 grid, dim3 block, hipStream_t st) {
+  using C = Cfg<DK, DV>;
+  if (which == K_FWD)
+    hipLaunchKernelGGL((attn_fwd_kernel<DK, DV>), grid, block, C::KT * C::RS * sizeof(float), st, a);
+  else if (which == K_DQ)
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DK, DV>), grid, block, C::KT * C::RS * sizeof(float), st, a);
+  else
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DK, DV>), grid, block, C::KT * C::RS2 * sizeof(float), st, a);
 }
 
 template <int DK>
-int launch_dv(int which, const AttnArgs& a, dim3 grid, hipStream_t st) {
+int launch_dv(int which, const AttnArgs& a, dim3 grid, dim3 block, hipStream_t st) {
   const int dv = a.dv_dim;
-  if (dv <= 4) launch_one<DK, 4>(which, a, grid, st);
-  else if (dv <= 16) launch_one<DK, 16>(which, a, grid, st);
-  else if (dv <= 32) launch_one<DK, 32>(which, a, grid, st);
-  else if (dv <= 64) launch_one<DK, 64>(which, a, grid, st);
+  if (dv <= 4) launch_one<DK, 4>(which, a, grid, block, st);
+  else if (dv <= 16) launch_one<DK, 16>(which, a, grid, block, st);
+  else if (dv <= 32) launch_one<DK, 32>(which, a, grid, block, st);
+  else if (dv <= 64) launch_one<DK, 64>(which, a, grid, block, st);
   else return PG_ESHAPE;
   return 0;
 }
 
-int launch_attn(int which, const AttnArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)((a.L + AT_THREADS - 1) / AT_THREADS), (unsigned)a.heads, (unsigned)a.N);
+int launch_attn(int which, AttnArgs& a, hipStream_t st) {
+  // one block owns 128*nwaves consecutive rows; small L -> one block per (n, head)
+  const int rows_per_wave = 64 * QPL;
+  int nwaves = (a.L + rows_per_wave - 1) / rows_per_wave;
+  if (nwaves > 8) nwaves = 8;
+  a.nwaves = nwaves;
+  const int rows_per_block = rows_per_wave * nwaves;
+  dim3 grid((unsigned)((a.L + rows_per_block - 1) / rows_per_block), (unsigned)a.heads, (unsigned)a.N);
+  dim3 block((unsigned)(64 * nwaves));
   const int dk = a.dk_dim;
-  if (dk <= 4) return launch_dv<4>(which, a, grid, st);
-  if (dk <= 16) return launch_dv<16>(which, a, grid, st);
-  if (dk <= 64) return launch_dv<64>(which, a, grid, st);
+  if (dk <= 4) return launch_dv<4>(which, a, grid, block, st);
+  if (dk <= 16) return launch_dv<16>(which, a, grid, block, st);
+  if (dk <= 64) return launch_dv<64>(which, a, grid, block, st);
   return PG_ESHAPE;
 }
 

@@ -154,6 +154,109 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
   }
 }
 
+// ---- 1x1 fast path: fragments straight from global memory, no LDS --------------------------
+// dw[co][ci] += sum_p dy[co][p] * act(x[ci][p]). Each lane loads ONE float4 (4 consecutive pixels
+// of "its" channel lane&15, pixel quad lane>>4) per 16-channel tile; MFMA #j of a 16-pixel group
+// contracts element j of every lane's float4, i.e. pixels {4k + j : k = lane>>4} — A and B use
+// the same pixel<->(lane, j) bijection, so no cross-lane movement is needed.
+struct PwWgArgs {
+  const float* x; const float* dy; float* dw; float* db;
+  int N, Cin, Cout, L, G16, in_act;
+  long total_groups;
+};
+
+template <int NCOT, int NCIT, int ACT>
+__global__ void __launch_bounds__(WG_THREADS) conv_wgrad_pw_kernel(const PwWgArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int ch = lane & 15, quad = lane >> 4;
+  const bool do_bias = a.db != nullptr && blockIdx.z == 0;
+
+  f32x4 acc[NCOT][NCIT];
+  f32x4 accb[NCOT];
+#pragma unroll
+  for (int i = 0; i < NCOT; ++i) {
+    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NCIT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const long wstride = (long)gridDim.x * (WG_THREADS / 64);
+  for (long grp = (long)blockIdx.x * (WG_THREADS / 64) + wave; grp < a.total_groups; grp += wstride) {
+    const int n = (int)(grp / a.G16);
+    const int p0 = (int)(grp - (long)n * a.G16) * 16 + quad * 4;
+    const bool pok = p0 < a.L;  // L % 4 == 0: the float4 is entirely in or out
+    float4 av[NCOT], bv[NCIT];
+#pragma unroll
+    for (int i = 0; i < NCOT; ++i) {
+      const int co = co0 + i * 16 + ch;
+      av[i] = (pok && co < a.Cout)
+                  ? *reinterpret_cast<const float4*>(a.dy + ((size_t)n * a.Cout + co) * a.L + p0)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < NCIT; ++j) {
+      const int ci = ci0 + j * 16 + ch;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pok && ci < a.Cin) {
+        v = *reinterpret_cast<const float4*>(a.x + ((size_t)n * a.Cin + ci) * a.L + p0);
+        if (ACT != PG_ACT_NONE) {
+          v.x = pg_apply_act(v.x, ACT); v.y = pg_apply_act(v.y, ACT);
+          v.z = pg_apply_act(v.z, ACT); v.w = pg_apply_act(v.w, ACT);
+        }
+      }
+      bv[j] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NCOT; ++i) {
+      const float ae[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int j = 0; j < NCIT; ++j) {
+          const float be = e == 0 ? bv[j].x : (e == 1 ? bv[j].y : (e == 2 ? bv[j].z : bv[j].w));
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], be, acc[i][j], 0, 0, 0);
+        }
+        if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], 1.0f, accb[i], 0, 0, 0);
+      }
+    }
+  }
+  // D[row = quad*4 + r][col = ch] -> dw[co][ci]
+#pragma unroll
+  for (int i = 0; i < NCOT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + i * 16 + quad * 4 + r;
+      if (co < a.Cout) {
+#pragma unroll
+        for (int j = 0; j < NCIT; ++j) {
+          const int ci = ci0 + j * 16 + ch;
+          if (ci < a.Cin) atomicAdd(&a.dw[(size_t)co * a.Cin + ci], acc[i][j][r]);
+        }
+        if (do_bias && ch == 0) atomicAdd(&a.db[co], accb[i][r]);
+      }
+    }
+  }
+}
+
+template <int NCOT, int NCIT>
+void launch_pw_wgrad_act(const PwWgArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.in_act) {
+    case PG_ACT_RELU: hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_RELU>), grid, dim3(WG_THREADS), 0, st, a); break;
+    case PG_ACT_ELU:  hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_ELU>),  grid, dim3(WG_THREADS), 0, st, a); break;
+    case PG_ACT_GELU: hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_GELU>), grid, dim3(WG_THREADS), 0, st, a); break;
+    default:          hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_NONE>), grid, dim3(WG_THREADS), 0, st, a); break;
+  }
+}
+
+template <int NCOT>
+void launch_pw_wgrad(const PwWgArgs& a, int ncit, dim3 grid, hipStream_t st) {
+  if (ncit <= 1) launch_pw_wgrad_act<NCOT, 1>(a, grid, st);
+  else if (ncit == 2) launch_pw_wgrad_act<NCOT, 2>(a, grid, st);
+  else launch_pw_wgrad_act<NCOT, 4>(a, grid, st);
+}
+
 inline int pad_stride(int s) {  // smallest s' >= s with s' % 32 == 2
   int r = s % 32;
   return r <= 2 ? s + (2 - r) : s + (34 - r);
@@ -172,6 +275,26 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   PG_REQUIRE(T >= 1 && T <= PG_MAX_TAPS, PG_ESHAPE, "pg_conv2d_wgrad: T=%d not in [1,%d]", T,
              PG_MAX_TAPS);
   PG_REQUIRE(in_act >= PG_ACT_NONE && in_act <= PG_ACT_GELU, PG_EINVAL, "pg_conv2d_wgrad: bad in_act");
+  if (T == 1 && KH == 1 && KW == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
+      ((OH * OW) % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {
+    PwWgArgs p;
+    p.x = x; p.dy = dy; p.dw = dw; p.db = db;
+    p.N = N; p.Cin = Cin; p.Cout = Cout; p.L = OH * OW; p.in_act = in_act;
+    p.G16 = (p.L + 15) / 16;
+    p.total_groups = (long)N * p.G16;
+    const int co_chunks = (Cout + 63) / 64, ci_chunks = (Cin + 63) / 64;
+    const int ncot = ((Cout < 64 ? Cout : 64) + 15) / 16, ncit = ((Cin < 64 ? Cin : 64) + 15) / 16;
+    long gx = (p.total_groups + 3) / 4;
+    const long cap = 256 / (co_chunks * ci_chunks) > 32 ? 256 / (co_chunks * ci_chunks) : 32;
+    if (gx > cap) gx = cap;
+    dim3 grid((unsigned)gx, (unsigned)co_chunks, (unsigned)ci_chunks);
+    hipStream_t st = (hipStream_t)stream;
+    if (ncot <= 1) launch_pw_wgrad<1>(p, ncit, grid, st);
+    else if (ncot == 2) launch_pw_wgrad<2>(p, ncit, grid, st);
+    else launch_pw_wgrad<4>(p, ncit, grid, st);
+    PG_LAUNCH_CHECK("pg_conv2d_wgrad(1x1)");
+    return 0;
+  }
   WgArgs a;
   a.x = x; a.dy = dy; a.dw = dw; a.db = db;
   a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW;
