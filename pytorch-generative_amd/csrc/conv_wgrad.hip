@@ -35,6 +35,8 @@ struct WgArgs {
   int N, Cin, IH, IW, Cout, OH, OW, KH, KW, T;
   int TR, tiles_per_img, total_tiles, SW, xh, min_dr, min_dc;
   int S_dy, S_x, npos, in_act;
+  int swp_shift, rpi;       // lanes per staged row = 1<<swp_shift, rows per wave iteration
+  float inv_TR, inv_xh;
   int tapoff[PG_MAX_TAPS];
   int tap_u[PG_MAX_TAPS];
   int tap_v[PG_MAX_TAPS];
@@ -78,26 +80,40 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
       const int n = tile / a.tiles_per_img;
       const int row0 = (tile - n * a.tiles_per_img) * a.TR;
       __syncthreads();
-      // ---- stage dy rows: (channel,row) per wave iteration, lanes over columns
-      for (int rr = wave; rr < nco * a.TR; rr += 4) {
-        const int ch = rr / a.TR;
-        const int r = rr - ch * a.TR;
-        const bool rok = row0 + r < a.OH;
-        const float* src = a.dy + (((size_t)n * a.Cout + co0 + ch) * a.OH + (rok ? row0 + r : 0)) * a.OW;
-        float* dst = dyl + ch * a.S_dy + r * a.SW;
-        for (int c = lane; c < a.SW; c += 64) dst[c] = (rok && c < a.OW) ? src[c] : 0.f;
-      }
-      // ---- stage x rows (halo, zero filled, prologue activation applied once)
-      for (int rr = wave; rr < nci * a.xh; rr += 4) {
-        const int ch = rr / a.xh;
-        const int xr = rr - ch * a.xh;
-        const int ir = row0 + xr + a.min_dr;
-        const bool rok = ir >= 0 && ir < a.IH;
-        const float* src = a.x + (((size_t)n * a.Cin + ci0 + ch) * a.IH + (rok ? ir : 0)) * a.IW;
-        float* dst = xl + ch * a.S_x + xr * a.SW;
-        for (int c = lane; c < a.SW; c += 64) {
-          const int ic = c + a.min_dc;
-          dst[c] = (rok && ic >= 0 && ic < a.IW) ? pg_apply_act(src[ic], a.in_act) : 0.f;
+      // ---- stage dy rows: `rpi` (channel,row) pairs per wave iteration, lanes over columns;
+      //      4 iterations unrolled so several independent global loads are in flight
+      {
+        const int sub = lane >> a.swp_shift, col = lane & ((1 << a.swp_shift) - 1);
+        const int rows = nco * a.TR;
+#pragma unroll 4
+        for (int rr0 = wave * a.rpi; rr0 < rows; rr0 += 4 * a.rpi) {
+          const int rr = rr0 + sub;
+          if (rr < rows) {
+            const int ch = (int)(((float)rr + 0.5f) * a.inv_TR);
+            const int r = rr - ch * a.TR;
+            const bool rok = row0 + r < a.OH;
+            const float* src = a.dy + (((size_t)n * a.Cout + co0 + ch) * a.OH + (rok ? row0 + r : 0)) * a.OW;
+            float* dst = dyl + ch * a.S_dy + r * a.SW;
+            for (int c = col; c < a.SW; c += (1 << a.swp_shift)) dst[c] = (rok && c < a.OW) ? src[c] : 0.f;
+          }
+        }
+        // ---- stage x rows (halo, zero filled, prologue activation applied once)
+        const int xrows = nci * a.xh;
+#pragma unroll 4
+        for (int rr0 = wave * a.rpi; rr0 < xrows; rr0 += 4 * a.rpi) {
+          const int rr = rr0 + sub;
+          if (rr < xrows) {
+            const int ch = (int)(((float)rr + 0.5f) * a.inv_xh);
+            const int xr = rr - ch * a.xh;
+            const int ir = row0 + xr + a.min_dr;
+            const bool rok = ir >= 0 && ir < a.IH;
+            const float* src = a.x + (((size_t)n * a.Cin + ci0 + ch) * a.IH + (rok ? ir : 0)) * a.IW;
+            float* dst = xl + ch * a.S_x + xr * a.SW;
+            for (int c = col; c < a.SW; c += (1 << a.swp_shift)) {
+              const int ic = c + a.min_dc;
+              dst[c] = (rok && ic >= 0 && ic < a.IW) ? pg_apply_act(src[ic], a.in_act) : 0.f;
+            }
+          }
         }
       }
       __syncthreads();
@@ -122,8 +138,27 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
         }
       }
     }
-    // ---- flush this tap chunk
-    if (cot < ncot_real) {
+    // ---- flush this tap chunk: K-split partners reduce through LDS, one set of atomics per
+    //      (co tile) instead of one per wave
+    __syncthreads();
+    if (ks > 1 && kpart > 0 && cot < ncot_real) {
+      float* dst = lds + ((size_t)((kpart - 1) * ncot + cot) * (2 * TC + 1)) * 256 + lane * 4;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < TC; ++t) *reinterpret_cast<f32x4*>(dst + (c * TC + t) * 256) = acc[c][t];
+      *reinterpret_cast<f32x4*>(dst + 2 * TC * 256) = accb;
+    }
+    __syncthreads();
+    if (kpart == 0 && cot < ncot_real) {
+      for (int kp = 1; kp < ks; ++kp) {
+        const float* src = lds + ((size_t)((kp - 1) * ncot + cot) * (2 * TC + 1)) * 256 + lane * 4;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int t = 0; t < TC; ++t) acc[c][t] += *reinterpret_cast<const f32x4*>(src + (c * TC + t) * 256);
+        accb += *reinterpret_cast<const f32x4*>(src + 2 * TC * 256);
+      }
       const int co_b = co0 + cot * 16 + (lane >> 4) * 4;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -151,6 +186,10 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
         }
       }
     }
+    __syncthreads();
+    // the reduction scratch overlapped the staging tiles: restore the never-rewritten zero margins
+    if (t0 + TC < a.T)
+      for (int i = tid; i < lds_floats; i += WG_THREADS) lds[i] = 0.f;
   }
 }
 
@@ -167,6 +206,11 @@ struct PwWgArgs {
 
 template <int NCOT, int NCIT, int ACT>
 __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_pw_kernel(const PwWgArgs a) {
+  // U pixel groups are loaded per iteration before any MFMA, so >= 2*U*(tiles) 16-byte loads are
+  // in flight per lane (the loop is HBM-latency bound otherwise).
+  constexpr int U = (NCOT + NCIT <= 3) ? 4 : 2;
+  constexpr int NT = NCOT * NCIT + NCOT;  // accumulator tiles per wave (dw tiles + bias tiles)
+  extern __shared__ float red[];           // [3 waves][NT][64 lanes][4]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
@@ -183,43 +227,78 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_pw_kernel(const PwWgArg
   }
 
   const long wstride = (long)gridDim.x * (WG_THREADS / 64);
-  for (long grp = (long)blockIdx.x * (WG_THREADS / 64) + wave; grp < a.total_groups; grp += wstride) {
-    const int n = (int)(grp / a.G16);
-    const int p0 = (int)(grp - (long)n * a.G16) * 16 + quad * 4;
-    const bool pok = p0 < a.L;  // L % 4 == 0: the float4 is entirely in or out
-    float4 av[NCOT], bv[NCIT];
+  // each wave takes U CONSECUTIVE 16-pixel groups per iteration: its U loads per channel cover one
+  // contiguous U*64 B span (whole cache lines), issued back to back
+  for (long g0 = ((long)blockIdx.x * (WG_THREADS / 64) + wave) * U; g0 < a.total_groups; g0 += U * wstride) {
+    float4 av[U][NCOT], bv[U][NCIT];
 #pragma unroll
-    for (int i = 0; i < NCOT; ++i) {
-      const int co = co0 + i * 16 + ch;
-      av[i] = (pok && co < a.Cout)
-                  ? *reinterpret_cast<const float4*>(a.dy + ((size_t)n * a.Cout + co) * a.L + p0)
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < U; ++u) {
+      const long grp = g0 + u;
+      const bool gok = grp < a.total_groups;
+      const long gc = gok ? grp : 0;
+      const int n = (int)(gc / a.G16);
+      const int p0 = (int)(gc - (long)n * a.G16) * 16 + quad * 4;
+      const bool pok = gok && p0 < a.L;  // L % 4 == 0: the float4 is entirely in or out
+#pragma unroll
+      for (int i = 0; i < NCOT; ++i) {
+        const int co = co0 + i * 16 + ch;
+        av[u][i] = (pok && co < a.Cout)
+                       ? *reinterpret_cast<const float4*>(a.dy + ((size_t)n * a.Cout + co) * a.L + p0)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < NCIT; ++j) {
+        const int ci = ci0 + j * 16 + ch;
+        bv[u][j] = (pok && ci < a.Cin)
+                       ? *reinterpret_cast<const float4*>(a.x + ((size_t)n * a.Cin + ci) * a.L + p0)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < NCIT; ++j) {
-      const int ci = ci0 + j * 16 + ch;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pok && ci < a.Cin) {
-        v = *reinterpret_cast<const float4*>(a.x + ((size_t)n * a.Cin + ci) * a.L + p0);
+    for (int u = 0; u < U; ++u) {
+      float be[NCIT][4];
+#pragma unroll
+      for (int j = 0; j < NCIT; ++j) {
+        be[j][0] = bv[u][j].x; be[j][1] = bv[u][j].y; be[j][2] = bv[u][j].z; be[j][3] = bv[u][j].w;
         if (ACT != PG_ACT_NONE) {
-          v.x = pg_apply_act(v.x, ACT); v.y = pg_apply_act(v.y, ACT);
-          v.z = pg_apply_act(v.z, ACT); v.w = pg_apply_act(v.w, ACT);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) be[j][e] = pg_apply_act(be[j][e], ACT);  // act(0) == 0
         }
       }
-      bv[j] = v;
+#pragma unroll
+      for (int i = 0; i < NCOT; ++i) {
+        const float ae[4] = {av[u][i].x, av[u][i].y, av[u][i].z, av[u][i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int j = 0; j < NCIT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], be[j][e], acc[i][j], 0, 0, 0);
+          if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], 1.0f, accb[i], 0, 0, 0);
+        }
+      }
     }
+  }
+  // cross-wave reduction in LDS, then ONE set of atomics per workgroup
+  if (wave > 0) {
+    float* dst = red + ((size_t)(wave - 1) * NT) * 256 + lane * 4;
 #pragma unroll
     for (int i = 0; i < NCOT; ++i) {
-      const float ae[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int j = 0; j < NCIT; ++j)
+        *reinterpret_cast<f32x4*>(dst + (i * NCIT + j) * 256) = acc[i][j];
+      *reinterpret_cast<f32x4*>(dst + (NCOT * NCIT + i) * 256) = accb[i];
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
 #pragma unroll
-        for (int j = 0; j < NCIT; ++j) {
-          const float be = e == 0 ? bv[j].x : (e == 1 ? bv[j].y : (e == 2 ? bv[j].z : bv[j].w));
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], be, acc[i][j], 0, 0, 0);
-        }
-        if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], 1.0f, accb[i], 0, 0, 0);
-      }
+  for (int w = 0; w < WG_THREADS / 64 - 1; ++w) {
+    const float* src = red + ((size_t)w * NT) * 256 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < NCOT; ++i) {
+#pragma unroll
+      for (int j = 0; j < NCIT; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(src + (i * NCIT + j) * 256);
+      accb[i] += *reinterpret_cast<const f32x4*>(src + (NCOT * NCIT + i) * 256);
     }
   }
   // D[row = quad*4 + r][col = ch] -> dw[co][ci]
@@ -242,11 +321,12 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_pw_kernel(const PwWgArg
 
 template <int NCOT, int NCIT>
 void launch_pw_wgrad_act(const PwWgArgs& a, dim3 grid, hipStream_t st) {
+  const size_t shm = (size_t)3 * (NCOT * NCIT + NCOT) * 256 * sizeof(float);
   switch (a.in_act) {
-    case PG_ACT_RELU: hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_RELU>), grid, dim3(WG_THREADS), 0, st, a); break;
-    case PG_ACT_ELU:  hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_ELU>),  grid, dim3(WG_THREADS), 0, st, a); break;
-    case PG_ACT_GELU: hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_GELU>), grid, dim3(WG_THREADS), 0, st, a); break;
-    default:          hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_NONE>), grid, dim3(WG_THREADS), 0, st, a); break;
+    case PG_ACT_RELU: hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_RELU>), grid, dim3(WG_THREADS), shm, st, a); break;
+    case PG_ACT_ELU:  hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_ELU>),  grid, dim3(WG_THREADS), shm, st, a); break;
+    case PG_ACT_GELU: hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_GELU>), grid, dim3(WG_THREADS), shm, st, a); break;
+    default:          hipLaunchKernelGGL((conv_wgrad_pw_kernel<NCOT, NCIT, PG_ACT_NONE>), grid, dim3(WG_THREADS), shm, st, a); break;
   }
 }
 
@@ -284,8 +364,8 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     p.total_groups = (long)N * p.G16;
     const int co_chunks = (Cout + 63) / 64, ci_chunks = (Cin + 63) / 64;
     const int ncot = ((Cout < 64 ? Cout : 64) + 15) / 16, ncit = ((Cin < 64 ? Cin : 64) + 15) / 16;
-    long gx = (p.total_groups + 3) / 4;
-    const long cap = 256 / (co_chunks * ci_chunks) > 32 ? 256 / (co_chunks * ci_chunks) : 32;
+    long gx = (p.total_groups + 15) / 16;
+    const long cap = 512 / (co_chunks * ci_chunks) > 64 ? 512 / (co_chunks * ci_chunks) : 64;
     if (gx > cap) gx = cap;
     dim3 grid((unsigned)gx, (unsigned)co_chunks, (unsigned)ci_chunks);
     hipStream_t st = (hipStream_t)stream;
@@ -332,12 +412,20 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     a.tap_u[t] = tap_u[t];
     a.tap_v[t] = tap_v[t];
   }
+  int shift = 0;
+  while ((1 << shift) < a.SW && shift < 6) ++shift;
+  a.swp_shift = shift;
+  a.rpi = 64 >> shift;
+  a.inv_TR = 1.0f / (float)a.TR;
+  a.inv_xh = 1.0f / (float)a.xh;
   const int co_chunks = (Cout + CO_CHUNK - 1) / CO_CHUNK;
   const int ci_chunks = (Cin + CI_CHUNK - 1) / CI_CHUNK;
-  int G = 1024 / (co_chunks * ci_chunks);
-  if (G < 1) G = 1;
+  int G = 512 / (co_chunks * ci_chunks);
+  if (G < 64) G = 64;
   if (G > a.total_tiles) G = a.total_tiles;
-  const size_t shmem = ((size_t)nco_alloc * a.S_dy + (size_t)nci * a.S_x) * sizeof(float);
+  size_t shmem = ((size_t)nco_alloc * a.S_dy + (size_t)nci * a.S_x) * sizeof(float);
+  const size_t red_bytes = (size_t)3 * (2 * TC + 1) * 256 * sizeof(float);  // cross-wave reduction scratch
+  if (shmem < red_bytes) shmem = red_bytes;
   PG_REQUIRE(shmem <= 160 * 1024, PG_ESHAPE, "pg_conv2d_wgrad: LDS %zu B over budget", shmem);
   dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
   hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(WG_THREADS), shmem, (hipStream_t)stream, a);

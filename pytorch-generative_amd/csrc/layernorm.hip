@@ -70,51 +70,98 @@ ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
 }
 
 // dx = rstd * (g - mean_c(g) - xhat * mean_c(g*xhat)),  g = dy*gamma
-// dgamma[c] += sum_p dy*xhat ; dbeta[c] += sum_p dy   (wave reduce -> LDS -> one atomic/block)
+// dgamma[c] += sum_p dy*xhat ; dbeta[c] += sum_p dy
+// One lane walks PPL pixels (stride = blockDim, so every access stays a coalesced row) keeping the
+// pixel's C values of x and dy in registers (CREG > 0) and its dgamma/dbeta partials across pixels;
+// one wave reduction + one atomic per channel per block at the end.
+constexpr int LN_PPL = 4;
+
+template <int CREG>
 __global__ void __launch_bounds__(LN_THREADS)
 ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
               const float* __restrict__ mean, const float* __restrict__ rstd,
               const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dgamma,
               float* __restrict__ dbeta, int N, int C, int L) {
   extern __shared__ float red[];  // [2][C][waves]
-  const int nw = LN_THREADS / 64;
+  constexpr int nw = LN_THREADS / 64;
+  constexpr int CR = CREG > 0 ? CREG : 1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long p = (long)blockIdx.x * LN_THREADS + threadIdx.x;
   const long total = (long)N * L;
-  const bool act = p < total;
-  const long pc = act ? p : total - 1;
-  const int n = (int)(pc / L);
-  const int l = (int)(pc - (long)n * L);
-  const size_t base = (size_t)n * C * L + l;
-  const float mu = mean[pc], rs = rstd[pc];
   const float invC = 1.f / (float)C;
+  float pg[CR], pb[CR];
+#pragma unroll
+  for (int c = 0; c < CR; ++c) pg[c] = pb[c] = 0.f;
 
-  float sg = 0.f, sgx = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float xh = (x[base + (size_t)c * L] - mu) * rs;
-    const float g = dy[base + (size_t)c * L] * gamma[c];
-    sg += g;
-    sgx = fmaf(g, xh, sgx);
-  }
-  const float mg = sg * invC, mgx = sgx * invC;
-  for (int c = 0; c < C; ++c) {
-    const float xh = (x[base + (size_t)c * L] - mu) * rs;
-    const float d = act ? dy[base + (size_t)c * L] : 0.f;
-    const float g = d * gamma[c];
-    if (act) dx[base + (size_t)c * L] = rs * (g - mg - xh * mgx);
-    const float wg = pg_wave_sum(d * xh);
-    const float wb = pg_wave_sum(d);
-    if (lane == 0) {
-      red[(0 * C + c) * nw + wave] = wg;
-      red[(1 * C + c) * nw + wave] = wb;
+  for (int it = 0; it < LN_PPL; ++it) {
+    const long p_raw = ((long)blockIdx.x * LN_PPL + it) * LN_THREADS + threadIdx.x;
+    const bool live = p_raw < total;
+    if (CREG > 0 && !live) break;      // register path: no cross-lane ops inside the pixel loop
+    const long p = live ? p_raw : total - 1;
+    const int n = (int)(p / L);
+    const int l = (int)(p - (long)n * L);
+    const size_t base = (size_t)n * C * L + l;
+    const float mu = mean[p], rs = rstd[p];
+    if (CREG > 0) {
+      float xh[CR], dv[CR];
+      float sg = 0.f, sgx = 0.f;
+#pragma unroll
+      for (int c = 0; c < CR; ++c) {
+        const bool ok = c < C;
+        xh[c] = ok ? (x[base + (size_t)c * L] - mu) * rs : 0.f;
+        dv[c] = ok ? dy[base + (size_t)c * L] : 0.f;
+        const float g = ok ? dv[c] * gamma[c] : 0.f;
+        sg += g;
+        sgx = fmaf(g, xh[c], sgx);
+      }
+      const float mg = sg * invC, mgx = sgx * invC;
+#pragma unroll
+      for (int c = 0; c < CR; ++c) {
+        if (c < C) {
+          dx[base + (size_t)c * L] = rs * (dv[c] * gamma[c] - mg - xh[c] * mgx);
+          pg[c] = fmaf(dv[c], xh[c], pg[c]);
+          pb[c] += dv[c];
+        }
+      }
+    } else {
+      float sg = 0.f, sgx = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float xh = (x[base + (size_t)c * L] - mu) * rs;
+        const float g = dy[base + (size_t)c * L] * gamma[c];
+        sg += g;
+        sgx = fmaf(g, xh, sgx);
+      }
+      const float mg = sg * invC, mgx = sgx * invC;
+      for (int c = 0; c < C; ++c) {
+        const float xh = (x[base + (size_t)c * L] - mu) * rs;
+        const float d = live ? dy[base + (size_t)c * L] : 0.f;
+        if (live) dx[base + (size_t)c * L] = rs * (d * gamma[c] - mg - xh * mgx);
+        // large C: reduce per channel straight away (no per-lane partial array)
+        const float wg = pg_wave_sum(d * xh), wb = pg_wave_sum(d);
+        if (lane == 0) {
+          atomicAdd(&dgamma[c], wg);
+          atomicAdd(&dbeta[c], wb);
+        }
+      }
     }
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += LN_THREADS) {
-    float s = 0.f;
-    for (int w = 0; w < nw; ++w) s += red[i * nw + w];
-    if (i < C) atomicAdd(&dgamma[i], s);
-    else atomicAdd(&dbeta[i - C], s);
+  if (CREG > 0) {
+#pragma unroll
+    for (int c = 0; c < CR; ++c) {
+      if (c < C) {
+        const float wg = pg_wave_sum(pg[c]), wb = pg_wave_sum(pb[c]);
+        if (lane == 0) {
+          red[(0 * C + c) * nw + wave] = wg;
+          red[(1 * C + c) * nw + wave] = wb;
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += LN_THREADS) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += red[i * nw + w];
+      if (i < C) atomicAdd(&dgamma[i], s);
+      else atomicAdd(&dbeta[i - C], s);
+    }
   }
 }
 
@@ -146,10 +193,18 @@ PG_EXPORT int pg_nchw_layernorm_bwd(const float* x, const float* gamma, const fl
   PG_REQUIRE(N > 0 && C > 0 && L > 0, PG_EINVAL, "pg_nchw_layernorm_bwd: bad dims");
   PG_REQUIRE(C <= 2048, PG_ESHAPE, "pg_nchw_layernorm_bwd: C=%d > 2048", C);
   const long total = (long)N * L;
-  dim3 grid((unsigned)((total + LN_THREADS - 1) / LN_THREADS));
+  const long per_block = (long)LN_THREADS * LN_PPL;
+  dim3 grid((unsigned)((total + per_block - 1) / per_block));
   const size_t shmem = (size_t)2 * C * (LN_THREADS / 64) * sizeof(float);
-  hipLaunchKernelGGL(ln_bwd_kernel, grid, dim3(LN_THREADS), shmem, (hipStream_t)stream, x, gamma,
-                     mean, rstd, dy, dx, dgamma, dbeta, N, C, L);
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 16)
+    hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, N, C, L);
+  else if (C <= 32)
+    hipLaunchKernelGGL(ln_bwd_kernel<32>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, N, C, L);
+  else if (C <= 64)
+    hipLaunchKernelGGL(ln_bwd_kernel<64>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, N, C, L);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<0>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx, dgamma, dbeta, N, C, L);
   PG_LAUNCH_CHECK("pg_nchw_layernorm_bwd");
   return 0;
 }

@@ -28,14 +28,15 @@ class TransformerBlock(nn.Module):
         )
         self._out = nn.Sequential(
             pg_nn.Conv2d(in_channels=n_channels, out_channels=4 * n_channels, kernel_size=1),
-            nn.GELU(),  # placeholder keeping the Sequential indices; computed by ops.gelu
+            nn.GELU(),  # placeholder keeping the Sequential indices; fused into _out[2]'s load
             pg_nn.Conv2d(in_channels=4 * n_channels, out_channels=n_channels, kernel_size=1),
         )
 
     def forward(self, x):
         x = self._attn(self._ln1(x), res=x)              # x + attn(ln1(x))
-        hidden = ops.gelu(self._out[0](self._ln2(x)))
-        return self._out[2](hidden, res=x)                # x + mlp(ln2(x))
+        hidden = self._out[0](self._ln2(x))
+        # exact GELU fused into the MLP-out kernel's input load, residual into its epilogue
+        return self._out[2](hidden, in_act="gelu", res=x)  # x + mlp(ln2(x))
 
 
 class ImageGPT(base.AutoregressiveModel):
