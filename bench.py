@@ -39,48 +39,73 @@ def synthetic_batch(batch, rank):
 
 
 def attention_kernel_roofline(batch, device, iters=10):
-    """Times the dominant kernel (the causal-attention backward: dQ and dK/dV launches of
-    pg_causal_attn_bwd) live with HIP events on the stream it is launched on, at the bench's
-    exact shapes and on random data. Algorithmic FLOPs per launch are defined in DESIGN.md:
-    pairs = N*heads*L*(L+1)/2 allowed (query,key) pairs;
-    dQ pass 2*(2dk+dv) = 24 flop/pair... see DESIGN.md §kernels."""
-    from pytorch_generative_amd import ops
+    """Times the three causal-attention kernels live with HIP events on the stream they are
+    launched on, through the C-ABI, at the bench's exact shapes and on random data. The dominant
+    kernel of the step is attn_bwd_dkv_kernel<4,4> (pg_causal_attn_bwd_dkv).
+    Algorithmic FLOPs (DESIGN.md §4): pairs = N*heads*L*(L+1)/2 allowed (query, key) pairs;
+      fwd   2*dk + 2*dv          (QK^T, PV)
+      dQ    2*dk + 2*dv + 2*dk   (QK^T recompute, dP = dO V^T, dQ = dS K)
+      dK/dV 2*dk + 2*dv + 2*dv + 2*dk (QK^T recompute, dP, dV = P^T dO, dK = dS^T Q)."""
+    from pytorch_generative_amd import _lib
 
+    lib = _lib.load()
     e = HEADS * DK
     g = torch.Generator().manual_seed(7)
-    q = torch.randn(batch, e, 28, 28, generator=g).to(device).requires_grad_(True)
-    kv = torch.randn(batch, 2 * e, 28, 28, generator=g).to(device).requires_grad_(True)
-    d_o = torch.randn(batch, e, 28, 28, generator=g).to(device)
+    mk = lambda c: torch.randn(batch, c, 28, 28, generator=g).to(device)  # noqa: E731
+    q, kv, d_o = mk(e), mk(2 * e), mk(e)
+    o, dq, dkv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(kv)
+    lse = torch.empty(batch, HEADS, L, device=device)
+    delta = torch.empty_like(lse)
     stream = torch.cuda.current_stream()
-    # forward
-    o = ops.causal_attention(q, kv, HEADS, e, e, False)
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * iters + 2)]
-    for i in range(iters):
-        ev[2 * i].record(stream)
-        o = ops.causal_attention(q, kv, HEADS, e, e, False)
-        ev[2 * i + 1].record(stream)
-    torch.cuda.synchronize()
-    fwd_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(iters)) / iters
-    bwd_ms = 0.0
-    for i in range(iters):
-        o = ops.causal_attention(q, kv, HEADS, e, e, False)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(stream)
-        o.backward(d_o)
-        b.record(stream)
+    st = stream.cuda_stream
+    kvs = 2 * e * L
+
+    def fwd():
+        _lib.check(lib.pg_causal_attn_fwd(q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * e * L,
+                                          o.data_ptr(), lse.data_ptr(), batch, HEADS, L, DK, DV,
+                                          e * L, kvs, kvs, e * L, 0, st), "fwd")
+
+    def bwd(fn):
+        _lib.check(fn(q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * e * L, o.data_ptr(),
+                      d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(),
+                      dkv.data_ptr(), dkv.data_ptr() + 4 * e * L, batch, HEADS, L, DK, DV, e * L,
+                      kvs, kvs, e * L, e * L, e * L, kvs, kvs, 0, st), "bwd")
+
+    def timed(fn):
+        fn()
         torch.cuda.synchronize()
-        bwd_ms += a.elapsed_time(b)
-        q.grad = kv.grad = None
-    bwd_ms /= iters
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(iters)]
+        for a, b in evs:
+            a.record(stream)
+            fn()
+            b.record(stream)
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / iters
+
+    t_fwd = timed(fwd)
+    t_dq = timed(lambda: bwd(lib.pg_causal_attn_bwd_dq))
+    t_dkv = timed(lambda: bwd(lib.pg_causal_attn_bwd_dkv))
     pairs = batch * HEADS * L * (L + 1) / 2
-    flop_fwd = pairs * (2 * DK + 2 * DV)                      # QK^T + PV
-    flop_bwd = pairs * ((2 * DK + 2 * DV + 2 * DK) + (2 * DK + 2 * DV + 2 * DV + 2 * DK))
-    return {
-        "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
-        "fwd_tflops": flop_fwd / fwd_ms / 1e9, "bwd_tflops": flop_bwd / bwd_ms / 1e9,
-        "flop_fwd": flop_fwd, "flop_bwd": flop_bwd,
-    }
+    fl = {"fwd": pairs * (2 * DK + 2 * DV), "dq": pairs * (4 * DK + 2 * DV),
+          "dkv": pairs * (4 * DK + 4 * DV)}
+    ms = {"fwd": t_fwd, "dq": t_dq, "dkv": t_dkv}
+    return {k: {"launch_ms": ms[k], "flop_per_launch": fl[k], "tflops": fl[k] / ms[k] / 1e9}
+            for k in ms}
+
+
+def measured_traffic(batch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (collected in
+    separate rocprofv3 --pmc passes, see profiles/README.md); None when no profile matches."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("per_gpu_batch") == batch:
+            return t.get("attn_bwd_dkv_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(batch=16, steps=2):
@@ -213,21 +238,24 @@ def main():
         if world == 1:
             r = attention_kernel_roofline(args.batch, device)
             out["roofline"] = {
-                "bound": "mfma",
-                "kernel": "pg_causal_attn_bwd (attn_bwd_dq_kernel<4,4> + attn_bwd_dkv_kernel<4,4>)",
-                "achieved": r["bwd_tflops"],
+                "bound": "mfma",  # fp32: matrix peak == vector peak == 157.3 TF on gfx950; this
+                                  # kernel is fp32 VALU/exp bound
+                "kernel": "attn_bwd_dkv_kernel<4,4> (pg_causal_attn_bwd_dkv)",
+                "achieved": r["dkv"]["tflops"],
                 "peak": FP32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": r["bwd_tflops"] / FP32_PEAK_TFLOPS,
-                "traffic": None,
-                "launch_ms": r["bwd_ms"],
-                "flop_per_launch": r["flop_bwd"],
-                "fwd_kernel": {"achieved": r["fwd_tflops"], "launch_ms": r["fwd_ms"],
-                               "frac": r["fwd_tflops"] / FP32_PEAK_TFLOPS},
+                "frac": r["dkv"]["tflops"] / FP32_PEAK_TFLOPS,
+                "traffic": measured_traffic(args.batch),
+                "launch_ms": r["dkv"]["launch_ms"],
+                "flop_per_launch": r["dkv"]["flop_per_launch"],
+                "other_kernels": {
+                    "attn_fwd_kernel<4,4>": r["fwd"],
+                    "attn_bwd_dq_kernel<4,4>": r["dq"],
+                },
+                # whole step against SURVEY.md §8(d)'s per-image algorithmic work (1.223 GF, 26.2 MB)
+                "step_tflops": value * 1.223e9 / 1e12,
+                "step_hbm_gbps_algorithmic": value * 26.2e6 / 1e9,
             }
-            # whole-step view against SURVEY §8(d)'s per-image algorithmic work (1.223 GF, 26.2 MB)
-            out["roofline"]["step_tflops"] = value * 1.223e9 / 1e12
-            out["roofline"]["step_hbm_gbps_algorithmic"] = value * 26.2e6 / 1e9
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -73,8 +73,10 @@ size_t pg_packed_weight_floats(int a, int T, int b);
 /* padded extent of b the conv kernel expects */
 int pg_conv_b_pad(int b);
 
-/* Weight + bias gradient (MFMA f32 16x16x4, atomically ACCUMULATED into dw/db — caller
- * zeroes them once per step). Replaces aten::convolution_backward's weight/bias outputs.
+/* Weight + bias gradient (MFMA f32 16x16x4). The result is ADDED to dw/db (the caller zeroes
+ * them once per step); per-workgroup partial sums go through `workspace` and a second,
+ * deterministic reduction kernel (no atomics). Replaces aten::convolution_backward's weight/bias
+ * outputs.
  * dw[co][ci][tap_u[t]][tap_v[t]] += sum_{n,r,c} dy[n,co,r,c] * act(x[n,ci,r+dr[t],c+dc[t]])
  * db[co] += sum dy  (db may be NULL).
  * NOTE the reference's weight.grad is non-zero at masked taps (mask is applied to
@@ -82,7 +84,9 @@ int pg_conv_b_pad(int b);
 int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int Cin,
                     int IH, int IW, int Cout, int OH, int OW, int KH, int KW, int T,
                     const int* tap_dr, const int* tap_dc, const int* tap_u, const int* tap_v,
-                    int in_act, void* stream);
+                    int in_act, float* workspace, size_t workspace_floats, void* stream);
+/* floats of scratch pg_conv2d_wgrad needs for a (Cout, Cin, T) problem */
+size_t pg_conv2d_wgrad_workspace_floats(int Cout, int Cin, int T);
 
 /* w *= mask in place: nn/convolution.py:42 `self.weight.data *= self.mask`. */
 int pg_mul_inplace(float* w, const float* mask, size_t n, void* stream);
@@ -117,6 +121,19 @@ int pg_causal_attn_bwd(const float* q, const float* k, const float* v, const flo
                        float* dv, int N, int heads, int L, int dk_dim, int dv_dim, long q_bs,
                        long k_bs, long v_bs, long o_bs, long do_bs, long dq_bs, long dk_bs,
                        long dv_bs, int strict, void* stream);
+
+/* The two launches of pg_causal_attn_bwd individually (same argument list): _dq writes dq and
+ * delta, _dkv reads delta and writes dk, dv. Used by bench.py to time the dominant kernel. */
+int pg_causal_attn_bwd_dq(const float* q, const float* k, const float* v, const float* o,
+                          const float* d_o, const float* lse2, float* delta, float* dq, float* dk,
+                          float* dv, int N, int heads, int L, int dk_dim, int dv_dim, long q_bs,
+                          long k_bs, long v_bs, long o_bs, long do_bs, long dq_bs, long dk_bs,
+                          long dv_bs, int strict, void* stream);
+int pg_causal_attn_bwd_dkv(const float* q, const float* k, const float* v, const float* o,
+                           const float* d_o, const float* lse2, float* delta, float* dq, float* dk,
+                           float* dv, int N, int heads, int L, int dk_dim, int dv_dim, long q_bs,
+                           long k_bs, long v_bs, long o_bs, long do_bs, long dq_bs, long dk_bs,
+                           long dv_bs, int strict, void* stream);
 
 /* (N,2,H,W) pixel-coordinate encoding, nn/attention.py:37-57 (torch.arange(-.5,.5,1/h)). */
 int pg_image_positional_encoding(float* out, int N, int H, int W, void* stream);

@@ -501,11 +501,11 @@ PG_EXPORT int pg_causal_attn_fwd(const float* q, const float* k, const float* v,
   return 0;
 }
 
-PG_EXPORT int pg_causal_attn_bwd(const float* q, const float* k, const float* v, const float* o,
-                                 const float* d_o, const float* lse2, float* delta, float* dq,
-                                 float* dk, float* dv, int N, int heads, int L, int dk_dim,
-                                 int dv_dim, long q_bs, long k_bs, long v_bs, long o_bs, long do_bs,
-                                 long dq_bs, long dk_bs, long dv_bs, int strict, void* stream) {
+namespace {
+int attn_bwd_impl(int which_mask, const float* q, const float* k, const float* v, const float* o,
+                  const float* d_o, const float* lse2, float* delta, float* dq, float* dk, float* dv,
+                  int N, int heads, int L, int dk_dim, int dv_dim, long q_bs, long k_bs, long v_bs,
+                  long o_bs, long do_bs, long dq_bs, long dk_bs, long dv_bs, int strict, void* stream) {
   PG_REQUIRE(q && k && v && o && d_o && lse2 && delta && dq && dk && dv, PG_EINVAL,
              "pg_causal_attn_bwd: null pointer");
   int rc = check_dims("pg_causal_attn_bwd", N, heads, L, dk_dim, dv_dim, strict);
@@ -518,11 +518,48 @@ PG_EXPORT int pg_causal_attn_bwd(const float* q, const float* k, const float* v,
   a.dq_bs = dq_bs; a.dk_bs = dk_bs; a.dv_bs = dv_bs;
   a.scale = 1.f / sqrtf((float)dk_dim);
   a.scale2 = a.scale * 1.44269504088896340736f;
-  rc = launch_attn(K_DQ, a, (hipStream_t)stream);
-  PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: unsupported head dims");
-  PG_LAUNCH_CHECK("pg_causal_attn_bwd(dq)");
-  rc = launch_attn(K_DKV, a, (hipStream_t)stream);
-  PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: unsupported head dims");
-  PG_LAUNCH_CHECK("pg_causal_attn_bwd(dkv)");
+  if (which_mask & 1) {
+    rc = launch_attn(K_DQ, a, (hipStream_t)stream);
+    PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: unsupported head dims");
+    PG_LAUNCH_CHECK("pg_causal_attn_bwd(dq)");
+  }
+  if (which_mask & 2) {
+    rc = launch_attn(K_DKV, a, (hipStream_t)stream);
+    PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: unsupported head dims");
+    PG_LAUNCH_CHECK("pg_causal_attn_bwd(dkv)");
+  }
   return 0;
+}
+}  // namespace
+
+#define PG_ATTN_BWD_ARGS                                                                          \
+  q, k, v, o, d_o, lse2, delta, dq, dk, dv, N, heads, L, dk_dim, dv_dim, q_bs, k_bs, v_bs, o_bs,  \
+      do_bs, dq_bs, dk_bs, dv_bs, strict, stream
+
+PG_EXPORT int pg_causal_attn_bwd(const float* q, const float* k, const float* v, const float* o,
+                                 const float* d_o, const float* lse2, float* delta, float* dq,
+                                 float* dk, float* dv, int N, int heads, int L, int dk_dim,
+                                 int dv_dim, long q_bs, long k_bs, long v_bs, long o_bs, long do_bs,
+                                 long dq_bs, long dk_bs, long dv_bs, int strict, void* stream) {
+  return attn_bwd_impl(3, PG_ATTN_BWD_ARGS);
+}
+
+// The two launches of pg_causal_attn_bwd individually (profiling / roofline measurement):
+// _dq writes dq and delta; _dkv reads delta and writes dk, dv.
+PG_EXPORT int pg_causal_attn_bwd_dq(const float* q, const float* k, const float* v, const float* o,
+                                    const float* d_o, const float* lse2, float* delta, float* dq,
+                                    float* dk, float* dv, int N, int heads, int L, int dk_dim,
+                                    int dv_dim, long q_bs, long k_bs, long v_bs, long o_bs,
+                                    long do_bs, long dq_bs, long dk_bs, long dv_bs, int strict,
+                                    void* stream) {
+  return attn_bwd_impl(1, PG_ATTN_BWD_ARGS);
+}
+
+PG_EXPORT int pg_causal_attn_bwd_dkv(const float* q, const float* k, const float* v, const float* o,
+                                     const float* d_o, const float* lse2, float* delta, float* dq,
+                                     float* dk, float* dv, int N, int heads, int L, int dk_dim,
+                                     int dv_dim, long q_bs, long k_bs, long v_bs, long o_bs,
+                                     long do_bs, long dq_bs, long dk_bs, long dv_bs, int strict,
+                                     void* stream) {
+  return attn_bwd_impl(2, PG_ATTN_BWD_ARGS);
 }

@@ -32,6 +32,8 @@ constexpr int LDS_BUDGET_FLOATS = 15000;  // ~60 KB -> 2 workgroups / CU
 
 struct WgArgs {
   const float* x; const float* dy; float* dw; float* db;
+  float* part;        // [gridDim.x][part_stride] per-block partial sums (no atomics: see below)
+  long part_stride;   // = Cout*Cin*T + Cout
   int N, Cin, IH, IW, Cout, OH, OW, KH, KW, T;
   int TR, tiles_per_img, total_tiles, SW, xh, min_dr, min_dc;
   int S_dy, S_x, npos, in_act;
@@ -160,6 +162,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
         accb += *reinterpret_cast<const f32x4*>(src + 2 * TC * 256);
       }
       const int co_b = co0 + cot * 16 + (lane >> 4) * 4;
+      float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         if (c < ncit) {
@@ -167,12 +170,11 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
 #pragma unroll
           for (int t = 0; t < TC; ++t) {
             if (t < tcount && ci < a.Cin) {
-              const int u = a.tap_u[t0 + t], v = a.tap_v[t0 + t];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int co = co_b + r;
                 if (co < a.Cout)
-                  atomicAdd(&a.dw[(((size_t)co * a.Cin + ci) * a.KH + u) * a.KW + v], acc[c][t][r]);
+                  prow[((size_t)co * a.Cin + ci) * a.T + (t0 + t)] = acc[c][t][r];
               }
             }
           }
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = co_b + r;
-          if (co < a.Cout) atomicAdd(&a.db[co], accb[r]);
+          if (co < a.Cout) prow[(size_t)a.Cout * a.Cin * a.T + co] = accb[r];
         }
       }
     }
@@ -200,6 +202,8 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
 // the same pixel<->(lane, j) bijection, so no cross-lane movement is needed.
 struct PwWgArgs {
   const float* x; const float* dy; float* dw; float* db;
+  float* part;        // [gridDim.x][Cout*Cin + Cout]
+  long part_stride;
   int N, Cin, Cout, L, G16, in_act;
   long total_groups;
 };
@@ -301,7 +305,8 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_pw_kernel(const PwWgArg
       accb[i] += *reinterpret_cast<const f32x4*>(src + (NCOT * NCIT + i) * 256);
     }
   }
-  // D[row = quad*4 + r][col = ch] -> dw[co][ci]
+  // D[row = quad*4 + r][col = ch] -> this block's row of the partial buffer
+  float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
 #pragma unroll
   for (int i = 0; i < NCOT; ++i) {
 #pragma unroll
@@ -311,9 +316,9 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_pw_kernel(const PwWgArg
 #pragma unroll
         for (int j = 0; j < NCIT; ++j) {
           const int ci = ci0 + j * 16 + ch;
-          if (ci < a.Cin) atomicAdd(&a.dw[(size_t)co * a.Cin + ci], acc[i][j][r]);
+          if (ci < a.Cin) prow[(size_t)co * a.Cin + ci] = acc[i][j][r];
         }
-        if (do_bias && ch == 0) atomicAdd(&a.db[co], accb[i][r]);
+        if (do_bias && ch == 0) prow[(size_t)a.Cout * a.Cin + co] = accb[i][r];
       }
     }
   }
@@ -337,6 +342,62 @@ void launch_pw_wgrad(const PwWgArgs& a, int ncit, dim3 grid, hipStream_t st) {
   else launch_pw_wgrad_act<NCOT, 4>(a, grid, st);
 }
 
+// ---- second stage: deterministic reduction of the per-block partials --------------------------
+// (A chain of G same-address fp32 atomics costs ~65-100 ns per link on MI355X — measured: the
+// atomic flush of 512-1024 workgroups dominated these kernels — so each workgroup stores its
+// partial tile instead and this kernel sums the G rows: coalesced, atomic-free, run-to-run
+// deterministic.)  slot s < Cout*Cin*T -> dw[co][ci][u_t][v_t]; then Cout bias slots.
+struct RedArgs {
+  const float* part; float* dw; float* db;
+  long part_stride; int G, Cout, Cin, KH, KW, T;
+  int tap_u[PG_MAX_TAPS];
+  int tap_v[PG_MAX_TAPS];
+};
+
+// block = 32 consecutive slots x 8 row groups: loads stay 128-byte coalesced, the G-row sum is
+// split 8 ways and finished through LDS.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedArgs a) {
+  __shared__ float red[8][33];
+  const int sl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const long s = (long)blockIdx.x * 32 + sl;
+  const long nw = (long)a.Cout * a.Cin * a.T;
+  const long total = nw + (a.db ? a.Cout : 0);
+  float acc0 = 0.f, acc1 = 0.f;
+  if (s < total) {
+    const float* p = a.part + s;
+    int g = rg;
+    for (; g + 8 < a.G; g += 16) {
+      acc0 += p[(size_t)g * a.part_stride];
+      acc1 += p[(size_t)(g + 8) * a.part_stride];
+    }
+    if (g < a.G) acc0 += p[(size_t)g * a.part_stride];
+  }
+  red[rg][sl] = acc0 + acc1;
+  __syncthreads();
+  if (rg != 0 || s >= total) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc += red[r][sl];
+  if (s < nw) {
+    const int t = (int)(s % a.T);
+    const long cc = s / a.T;  // co*Cin + ci
+    a.dw[(cc * a.KH + a.tap_u[t]) * a.KW + a.tap_v[t]] += acc;
+  } else {
+    a.db[s - nw] += acc;
+  }
+}
+
+int launch_reduce(const float* part, long stride, int G, float* dw, float* db, int Cout, int Cin,
+                  int KH, int KW, int T, const int* tap_u, const int* tap_v, hipStream_t st) {
+  RedArgs r;
+  r.part = part; r.dw = dw; r.db = db; r.part_stride = stride; r.G = G;
+  r.Cout = Cout; r.Cin = Cin; r.KH = KH; r.KW = KW; r.T = T;
+  for (int t = 0; t < T; ++t) { r.tap_u[t] = tap_u[t]; r.tap_v[t] = tap_v[t]; }
+  const long total = (long)Cout * Cin * T + (db ? Cout : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, r);
+  return 0;
+}
+
 inline int pad_stride(int s) {  // smallest s' >= s with s' % 32 == 2
   int r = s % 32;
   return r <= 2 ? s + (2 - r) : s + (34 - r);
@@ -344,35 +405,55 @@ inline int pad_stride(int s) {  // smallest s' >= s with s' % 32 == 2
 
 }  // namespace
 
+static long wgrad_max_rows(int Cout, int Cin) {
+  const long chunks = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
+  const long g = 512 / chunks;
+  return g > 64 ? g : 64;
+}
+
+PG_EXPORT size_t pg_conv2d_wgrad_workspace_floats(int Cout, int Cin, int T) {
+  return (size_t)wgrad_max_rows(Cout, Cin) * ((size_t)Cout * Cin * T + Cout);
+}
+
 PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int N,
                               int Cin, int IH, int IW, int Cout, int OH, int OW, int KH, int KW,
                               int T, const int* tap_dr, const int* tap_dc, const int* tap_u,
-                              const int* tap_v, int in_act, void* stream) {
-  PG_REQUIRE(x && dy && dw && tap_dr && tap_dc && tap_u && tap_v, PG_EINVAL,
+                              const int* tap_v, int in_act, float* workspace,
+                              size_t workspace_floats, void* stream) {
+  PG_REQUIRE(x && dy && dw && tap_dr && tap_dc && tap_u && tap_v && workspace, PG_EINVAL,
              "pg_conv2d_wgrad: null pointer");
   PG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, PG_EINVAL,
              "pg_conv2d_wgrad: non-positive dimension");
   PG_REQUIRE(T >= 1 && T <= PG_MAX_TAPS, PG_ESHAPE, "pg_conv2d_wgrad: T=%d not in [1,%d]", T,
              PG_MAX_TAPS);
   PG_REQUIRE(in_act >= PG_ACT_NONE && in_act <= PG_ACT_GELU, PG_EINVAL, "pg_conv2d_wgrad: bad in_act");
+  PG_REQUIRE(workspace_floats >= pg_conv2d_wgrad_workspace_floats(Cout, Cin, T), PG_EINVAL,
+             "pg_conv2d_wgrad: workspace of %zu floats < required %zu", workspace_floats,
+             pg_conv2d_wgrad_workspace_floats(Cout, Cin, T));
+  for (int t = 0; t < T; ++t)
+    PG_REQUIRE(tap_u[t] >= 0 && tap_u[t] < KH && tap_v[t] >= 0 && tap_v[t] < KW, PG_EINVAL,
+               "pg_conv2d_wgrad: tap %d outside the %dx%d filter", t, KH, KW);
+  hipStream_t st = (hipStream_t)stream;
+  const long stride = (long)Cout * Cin * T + Cout;
+  const long max_rows = wgrad_max_rows(Cout, Cin);
   if (T == 1 && KH == 1 && KW == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
       ((OH * OW) % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {
     PwWgArgs p;
-    p.x = x; p.dy = dy; p.dw = dw; p.db = db;
+    p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.part = workspace; p.part_stride = stride;
     p.N = N; p.Cin = Cin; p.Cout = Cout; p.L = OH * OW; p.in_act = in_act;
     p.G16 = (p.L + 15) / 16;
     p.total_groups = (long)N * p.G16;
     const int co_chunks = (Cout + 63) / 64, ci_chunks = (Cin + 63) / 64;
     const int ncot = ((Cout < 64 ? Cout : 64) + 15) / 16, ncit = ((Cin < 64 ? Cin : 64) + 15) / 16;
     long gx = (p.total_groups + 15) / 16;
-    const long cap = 512 / (co_chunks * ci_chunks) > 64 ? 512 / (co_chunks * ci_chunks) : 64;
-    if (gx > cap) gx = cap;
+    if (gx > max_rows) gx = max_rows;
     dim3 grid((unsigned)gx, (unsigned)co_chunks, (unsigned)ci_chunks);
-    hipStream_t st = (hipStream_t)stream;
     if (ncot <= 1) launch_pw_wgrad<1>(p, ncit, grid, st);
     else if (ncot == 2) launch_pw_wgrad<2>(p, ncit, grid, st);
     else launch_pw_wgrad<4>(p, ncit, grid, st);
     PG_LAUNCH_CHECK("pg_conv2d_wgrad(1x1)");
+    launch_reduce(workspace, stride, (int)gx, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
+    PG_LAUNCH_CHECK("pg_conv2d_wgrad(reduce)");
     return 0;
   }
   WgArgs a;
@@ -380,9 +461,8 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW;
   a.KH = KH; a.KW = KW; a.T = T; a.in_act = in_act;
   int min_dr = tap_dr[0], max_dr = tap_dr[0], min_dc = tap_dc[0], max_dc = tap_dc[0];
+  a.part = workspace; a.part_stride = stride;
   for (int t = 0; t < T; ++t) {
-    PG_REQUIRE(tap_u[t] >= 0 && tap_u[t] < KH && tap_v[t] >= 0 && tap_v[t] < KW, PG_EINVAL,
-               "pg_conv2d_wgrad: tap %d outside the %dx%d filter", t, KH, KW);
     min_dr = tap_dr[t] < min_dr ? tap_dr[t] : min_dr;
     max_dr = tap_dr[t] > max_dr ? tap_dr[t] : max_dr;
     min_dc = tap_dc[t] < min_dc ? tap_dc[t] : min_dc;
@@ -423,12 +503,15 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   int G = 512 / (co_chunks * ci_chunks);
   if (G < 64) G = 64;
   if (G > a.total_tiles) G = a.total_tiles;
+  if (G > max_rows) G = (int)max_rows;
   size_t shmem = ((size_t)nco_alloc * a.S_dy + (size_t)nci * a.S_x) * sizeof(float);
   const size_t red_bytes = (size_t)3 * (2 * TC + 1) * 256 * sizeof(float);  // cross-wave reduction scratch
   if (shmem < red_bytes) shmem = red_bytes;
   PG_REQUIRE(shmem <= 160 * 1024, PG_ESHAPE, "pg_conv2d_wgrad: LDS %zu B over budget", shmem);
   dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
-  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(WG_THREADS), shmem, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(WG_THREADS), shmem, st, a);
   PG_LAUNCH_CHECK("pg_conv2d_wgrad");
+  launch_reduce(workspace, stride, G, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
+  PG_LAUNCH_CHECK("pg_conv2d_wgrad(reduce)");
   return 0;
 }

@@ -35,8 +35,9 @@ SIGNATURES = {
     "pg_conv2d_wgrad": (
         c_i,
         [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_ip,
-         c_ip, c_i, c_s],
+         c_ip, c_i, c_f, c_z, c_s],
     ),
+    "pg_conv2d_wgrad_workspace_floats": (c_z, [c_i, c_i, c_i]),
     "pg_mul_inplace": (c_i, [c_f, c_f, c_z, c_s]),
     "pg_nchw_layernorm_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_flt, c_s]),
     "pg_nchw_layernorm_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_s]),
@@ -45,6 +46,16 @@ SIGNATURES = {
         [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_i, c_s],
     ),
     "pg_causal_attn_bwd": (
+        c_i,
+        [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l,
+         c_l, c_l, c_l, c_l, c_l, c_i, c_s],
+    ),
+    "pg_causal_attn_bwd_dq": (
+        c_i,
+        [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l,
+         c_l, c_l, c_l, c_l, c_l, c_i, c_s],
+    ),
+    "pg_causal_attn_bwd_dkv": (
         c_i,
         [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l,
          c_l, c_l, c_l, c_l, c_l, c_i, c_s],

@@ -173,11 +173,13 @@ class _ConvTaps(torch.autograd.Function):
                     gb_t = gb
             else:
                 gb_t = None
+            ws_n = lib.pg_conv2d_wgrad_workspace_floats(cout, cin, len(spec.wg_taps))
+            ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
             _lib.check(
                 lib.pg_conv2d_wgrad(
                     x.data_ptr(), dy.data_ptr(), gw_t.data_ptr(), _p(gb_t), n, cin, ih, iw, cout,
                     oh, ow, spec.kh, spec.kw, len(spec.wg_taps), spec.w_dr, spec.w_dc, spec.w_u,
-                    spec.w_v, ctx.in_act, _stream(),
+                    spec.w_v, ctx.in_act, ws.data_ptr(), ws_n, _stream(),
                 ),
                 "pg_conv2d_wgrad",
             )
