@@ -45,6 +45,9 @@ template <int DK, int DV> struct Cfg {
   static constexpr int RS = DK + DV;        // floats per staged key row (fwd / dQ)
   static constexpr int RS2 = DK + DV + 4;   // floats per staged query row (dK/dV): q|dO|lse|delta|pad
   static constexpr int CH = (RS <= 8) ? 8 : ((RS <= 16) ? 4 : 2);
+  // dK/dV keeps 2x(dk + dv) accumulators per lane on top of the staged rows: a smaller chunk
+  // keeps it under 96 VGPRs (5 waves/SIMD instead of 3 — measured: the kernel was occupancy bound)
+  static constexpr int CH2 = (CH > 2) ? CH / 2 : 2;
   static constexpr int KT = (RS <= 16) ? 256 : ((RS <= 48) ? 128 : 64);  // rows per LDS tile
 };
 
@@ -304,13 +307,14 @@ __device__ __forceinline__ void dkv_chunk(const float* __restrict__ rows, int lg
                                           const float (&kv)[QPL][DK], const float (&vv)[QPL][DV],
                                           float (&dkv)[QPL][DK], float (&dvv)[QPL][DV],
                                           const int (&my_first)[QPL]) {
-  constexpr int CH = Cfg<DK, DV>::CH, RS2 = Cfg<DK, DV>::RS2;
-  float qq[CH][DK], gg[CH][DV], ld[CH][4];
+  constexpr int CH = Cfg<DK, DV>::CH2, RS2 = Cfg<DK, DV>::RS2;
+  float qq[CH][DK], gg[CH][DV];
+  float2 ld[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     read_row<DK>(qq[c], rows + c * RS2);
     read_row<DV>(gg[c], rows + c * RS2 + DK);
-    read_row<4>(ld[c], rows + c * RS2 + DK + DV);
+    ld[c] = *reinterpret_cast<const float2*>(rows + c * RS2 + DK + DV);
   }
 #pragma unroll
   for (int u = 0; u < QPL; ++u) {
@@ -322,9 +326,9 @@ __device__ __forceinline__ void dkv_chunk(const float* __restrict__ rows, int lg
       float dp = vv[u][0] * gg[c][0];
 #pragma unroll
       for (int j = 1; j < DV; ++j) dp = fmaf(vv[u][j], gg[c][j], dp);
-      float p = fast_exp2(t - ld[c][0]);
+      float p = fast_exp2(t - ld[c].x);
       if (MASKED) p = ((lglob + c) >= my_first[u] && (lglob + c) < L) ? p : 0.f;
-      const float ds = p * (dp - ld[c][1]);
+      const float ds = p * (dp - ld[c].y);
 #pragma unroll
       for (int j = 0; j < DV; ++j) dvv[u][j] = fmaf(p, gg[c][j], dvv[u][j]);
 #pragma unroll
@@ -375,9 +379,9 @@ __global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(const AttnArgs a) {
     }
   }
   // wave-uniform query ranges: band [w_lo, w_full) needs predicates, [w_full, L) is unmasked
-  const int w_lo = ((m0w + a.strict) / C::CH) * C::CH;
-  const int w_full = ((min(m0w + 64 * QPL - 1, L - 1) + a.strict + C::CH - 1) / C::CH) * C::CH;
-  const int L_full_end = (L / C::CH) * C::CH;
+  const int w_lo = ((m0w + a.strict) / C::CH2) * C::CH2;
+  const int w_full = ((min(m0w + 64 * QPL - 1, L - 1) + a.strict + C::CH2 - 1) / C::CH2) * C::CH2;
+  const int L_full_end = (L / C::CH2) * C::CH2;
   const int blk_lo = ((b0 + a.strict) / C::KT) * C::KT;  // first tile the block needs
 
   for (int t0 = blk_lo; t0 < L; t0 += C::KT) {
@@ -409,12 +413,12 @@ __global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(const AttnArgs a) {
     int lq = max(t0, w_lo);
     // leading band
     const int band_end = min(t_end, w_full);
-    for (; lq < band_end; lq += C::CH)
+    for (; lq < band_end; lq += C::CH2)
       dkv_chunk<DK, DV, true>(tile + (lq - t0) * C::RS2, lq, L, kv, vv, dkv, dvv, my_first);
     const int full_end = min(t_end, L_full_end);
-    for (; lq < full_end; lq += C::CH)
+    for (; lq < full_end; lq += C::CH2)
       dkv_chunk<DK, DV, false>(tile + (lq - t0) * C::RS2, lq, L, kv, vv, dkv, dvv, my_first);
-    for (; lq < t_end; lq += C::CH)  // ragged tail (zero / +BIG filled rows beyond L)
+    for (; lq < t_end; lq += C::CH2)  // ragged tail (zero / +BIG filled rows beyond L)
       dkv_chunk<DK, DV, true>(tile + (lq - t0) * C::RS2, lq, L, kv, vv, dkv, dvv, my_first);
   }
 
