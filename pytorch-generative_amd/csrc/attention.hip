@@ -36,7 +36,10 @@ struct AttnArgs {
   int N, heads, L, dk_dim, dv_dim, strict;
   long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;
   float scale, scale2;  // 1/sqrt(dk), log2(e)/sqrt(dk)
-  int nwaves;           // waves per block; a block owns 64*QPL*nwaves consecutive rows
+  int blocks_per_wg;    // 64-row blocks per workgroup (<= 16); waves = ceil(blocks_per_wg / 2)
+  int kt, kt2;          // rows per LDS tile (fwd/dQ resp. dK/dV), multiples of 64, sized so that a
+                        // whole (n, head) fits when LDS allows: barriers between tiles would
+                        // re-serialise the balanced pairing
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -48,16 +51,15 @@ template <int DK, int DV> struct Cfg {
   // dK/dV keeps 2x(dk + dv) accumulators per lane on top of the staged rows: a smaller chunk
   // keeps it under 96 VGPRs (5 waves/SIMD instead of 3 — measured: the kernel was occupancy bound)
   static constexpr int CH2 = (CH > 2) ? CH / 2 : 2;
-  static constexpr int KT = (RS <= 16) ? 256 : ((RS <= 48) ? 128 : 64);  // rows per LDS tile
 };
 
 // Stage KT rows [m0, m0+KT) of two channel-major sources (a: DA chans, b: DB chans) into the
 // row-interleaved LDS tile. Global reads are coalesced along the row index; padded channels and
 // rows >= L are zero filled.
-template <int DA, int DB, int RS, int KT>
+template <int DA, int DB, int RS>
 __device__ __forceinline__ void stage_rows(float* __restrict__ tile, const float* __restrict__ a,
                                            int da, const float* __restrict__ b, int db, int L,
-                                           int m0, int tid, int nthreads) {
+                                           int m0, int KT, int tid, int nthreads) {
   for (int idx = tid; idx < (DA + DB) * KT; idx += nthreads) {
     const int c = idx / KT;
     const int m = idx - c * KT;
@@ -84,8 +86,28 @@ __device__ __forceinline__ void read_row(float (&dst)[D], const float* __restric
   }
 }
 
+// Row ownership and load balance: the 64-row blocks of a workgroup are handed out in PAIRS —
+// wave w owns block bB = first + w and block bA = first + nb - 1 - w (slot A streams the whole
+// range the wave needs, slot B only part of it) — so every wave of the workgroup streams the same
+// number of rows of the causal triangle (measured: 1.35x over consecutive blocks). A lane holds
+// one row of each block: slot 0 = A, slot 1 = B.
+struct WavePlan {
+  int bA, bB;    // 64-row block indices (bB < bA; bB == -1: the wave owns a single block)
+  bool on;
+};
+
+__device__ __forceinline__ WavePlan plan_wave(int first, int nb, int wave) {
+  WavePlan p;
+  const int lo = first + wave, hi = first + nb - 1 - wave;
+  p.on = lo <= hi;
+  p.bA = hi;
+  p.bB = lo < hi ? lo : -1;
+  return p;
+}
+
 // ------------------------------------------------------------------------------ forward
-template <int DK, int DV, bool MASKED>
+// slot A = the later query block (more keys), slot B = the earlier one.
+template <int DK, int DV, bool ACTB, bool MASKA, bool MASKB>
 __device__ __forceinline__ void fwd_chunk(const float* __restrict__ rows, int mglob,
                                           const float (&qv)[QPL][DK], float (&acc)[QPL][DV],
                                           float (&mrun)[QPL], float (&lsum)[QPL],
@@ -98,7 +120,8 @@ __device__ __forceinline__ void fwd_chunk(const float* __restrict__ rows, int mg
     read_row<DV>(vv[c], rows + c * RS + DK);
   }
 #pragma unroll
-  for (int u = 0; u < QPL; ++u) {
+  for (int u = 0; u < (ACTB ? 2 : 1); ++u) {
+    const bool masked = u == 0 ? MASKA : MASKB;
     float s[CH];
     float cmax = NEG_BIG;
 #pragma unroll
@@ -106,7 +129,7 @@ __device__ __forceinline__ void fwd_chunk(const float* __restrict__ rows, int mg
       float t = qv[u][0] * kk[c][0];
 #pragma unroll
       for (int i = 1; i < DK; ++i) t = fmaf(qv[u][i], kk[c][i], t);
-      if (MASKED) t = (mglob + c) <= my_last[u] ? t : NEG_BIG;
+      if (masked) t = (mglob + c) <= my_last[u] ? t : NEG_BIG;
       s[c] = t;
       cmax = fmaxf(cmax, t);
     }
@@ -118,13 +141,34 @@ __device__ __forceinline__ void fwd_chunk(const float* __restrict__ rows, int mg
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       float p = fast_exp2(s[c] - mnew);
-      if (MASKED) p = (mglob + c) <= my_last[u] ? p : 0.f;
+      if (masked) p = (mglob + c) <= my_last[u] ? p : 0.f;
       lsum[u] += p;
 #pragma unroll
       for (int j = 0; j < DV; ++j) acc[u][j] = fmaf(p, vv[c][j], acc[u][j]);
     }
     mrun[u] = mnew;
   }
+}
+
+// key-range plan of a wave for the query-owning kernels (fwd, dQ); all bounds multiples of CH
+// except endA.
+struct KeyRegions { int fullB, endB, fullA, endA; };
+
+template <int CH>
+__device__ __forceinline__ KeyRegions key_regions(const WavePlan& w, int L, int strict) {
+  KeyRegions r;
+  if (!w.on) { r.fullB = r.endB = r.fullA = r.endA = 0; return r; }
+  const int fa = 64 * w.bA - strict + 1;
+  r.fullA = fa < 0 ? 0 : (fa / CH) * CH;                     // keys < fullA: allowed for all of A
+  r.endA = min(64 * w.bA + 63, L - 1) - strict + 1;           // keys < endA: needed by some lane of A
+  if (w.bB >= 0) {
+    const int fb = 64 * w.bB - strict + 1;
+    r.fullB = fb < 0 ? 0 : (fb / CH) * CH;
+    r.endB = ((64 * w.bB + 63 - strict + 1 + CH - 1) / CH) * CH;  // rounded up (<= fullA)
+  } else {
+    r.fullB = r.endB = 0;
+  }
+  return r;
 }
 
 template <int DK, int DV>
@@ -136,11 +180,11 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int L = a.L;
-  const int rows_per_block = 64 * QPL * a.nwaves;
-  const int qb = gridDim.x - 1 - blockIdx.x;  // heaviest blocks first
-  const int b0 = qb * rows_per_block;
-  const int l0 = b0 + wave * 64 * QPL;        // first row of this wave
-  const bool wave_on = l0 < L;
+  const int NB = (L + 63) >> 6;
+  const int wg = gridDim.x - 1 - blockIdx.x;  // heaviest workgroups first
+  const int first = wg * a.blocks_per_wg;
+  const int nb = min(a.blocks_per_wg, NB - first);
+  const WavePlan w = plan_wave(first, nb, wave);
 
   const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * a.dk_dim * L;
   const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * a.dk_dim * L;
@@ -150,33 +194,35 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs a) {
   float qv[QPL][DK], acc[QPL][DV], mrun[QPL], lsum[QPL];
 #pragma unroll
   for (int u = 0; u < QPL; ++u) {
-    lq[u] = l0 + u * 64 + lane;
+    const int blk = u == 0 ? w.bA : w.bB;
+    const bool slot_on = w.on && blk >= 0;
+    lq[u] = slot_on ? 64 * blk + lane : L;    // L = "no row"
     const int lc = min(lq[u], L - 1);
     my_last[u] = lc - a.strict;
     mrun[u] = NEG_BIG;
     lsum[u] = 0.f;
 #pragma unroll
-    for (int i = 0; i < DK; ++i) qv[u][i] = (wave_on && i < a.dk_dim) ? qp[(size_t)i * L + lc] * a.scale2 : 0.f;
+    for (int i = 0; i < DK; ++i) qv[u][i] = (slot_on && i < a.dk_dim) ? qp[(size_t)i * L + lc] * a.scale2 : 0.f;
 #pragma unroll
     for (int j = 0; j < DV; ++j) acc[u][j] = 0.f;
   }
-  // wave-uniform key ranges
-  const int wl_max = min(l0 + 64 * QPL - 1, L - 1);
-  const int m_end = wave_on ? wl_max - a.strict + 1 : 0;           // keys needed by some lane
-  const int m_full = wave_on ? max(0, l0 - a.strict + 1) : 0;      // keys allowed for every lane
-  const int blk_end = min(b0 + rows_per_block - 1, L - 1) - a.strict + 1;  // keys the block needs
+  const KeyRegions r = key_regions<C::CH>(w, L, a.strict);
+  const int blk_end = min(64 * (first + nb - 1) + 63, L - 1) - a.strict + 1;  // keys the workgroup needs
 
-  for (int m0 = 0; m0 < blk_end; m0 += C::KT) {
+  for (int m0 = 0; m0 < blk_end; m0 += a.kt) {
     __syncthreads();
-    stage_rows<DK, DV, C::RS, C::KT>(tile, kp, a.dk_dim, vp, a.dv_dim, L, m0, threadIdx.x, blockDim.x);
+    stage_rows<DK, DV, C::RS>(tile, kp, a.dk_dim, vp, a.dv_dim, L, m0, a.kt, threadIdx.x, blockDim.x);
     __syncthreads();
-    const int t_end = min(m0 + C::KT, m_end);
+    const int t_hi = m0 + a.kt;
     int m = m0;
-    const int t_full = min(t_end, (m_full / C::CH) * C::CH);
-    for (; m < t_full; m += C::CH)
-      fwd_chunk<DK, DV, false>(tile + (m - m0) * C::RS, m, qv, acc, mrun, lsum, my_last);
-    for (; m < t_end; m += C::CH)  // diagonal band (rows >= L in the tile are zero filled)
-      fwd_chunk<DK, DV, true>(tile + (m - m0) * C::RS, m, qv, acc, mrun, lsum, my_last);
+    for (const int e = min(t_hi, r.fullB); m < e; m += C::CH)
+      fwd_chunk<DK, DV, true, false, false>(tile + (m - m0) * C::RS, m, qv, acc, mrun, lsum, my_last);
+    for (const int e = min(t_hi, r.endB); m < e; m += C::CH)
+      fwd_chunk<DK, DV, true, false, true>(tile + (m - m0) * C::RS, m, qv, acc, mrun, lsum, my_last);
+    for (const int e = min(t_hi, r.fullA); m < e; m += C::CH)
+      fwd_chunk<DK, DV, false, false, false>(tile + (m - m0) * C::RS, m, qv, acc, mrun, lsum, my_last);
+    for (const int e = min(t_hi, r.endA); m < e; m += C::CH)  // A's diagonal band
+      fwd_chunk<DK, DV, false, true, false>(tile + (m - m0) * C::RS, m, qv, acc, mrun, lsum, my_last);
   }
 
 #pragma unroll
@@ -194,7 +240,7 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs a) {
 }
 
 // --------------------------------------------------------------------------- backward: dQ
-template <int DK, int DV, bool MASKED>
+template <int DK, int DV, bool ACTB, bool MASKA, bool MASKB>
 __device__ __forceinline__ void dq_chunk(const float* __restrict__ rows, int mglob,
                                          const float (&qv)[QPL][DK], const float (&gv)[QPL][DV],
                                          float (&dqv)[QPL][DK], const float (&lse)[QPL],
@@ -207,7 +253,8 @@ __device__ __forceinline__ void dq_chunk(const float* __restrict__ rows, int mgl
     read_row<DV>(vv[c], rows + c * RS + DK);
   }
 #pragma unroll
-  for (int u = 0; u < QPL; ++u) {
+  for (int u = 0; u < (ACTB ? 2 : 1); ++u) {
+    const bool masked = u == 0 ? MASKA : MASKB;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       float t = qv[u][0] * kk[c][0];
@@ -217,7 +264,7 @@ __device__ __forceinline__ void dq_chunk(const float* __restrict__ rows, int mgl
 #pragma unroll
       for (int j = 1; j < DV; ++j) dp = fmaf(gv[u][j], vv[c][j], dp);
       float p = fast_exp2(t - lse[u]);
-      if (MASKED) p = (mglob + c) <= my_last[u] ? p : 0.f;
+      if (masked) p = (mglob + c) <= my_last[u] ? p : 0.f;
       const float ds = p * (dp - delta[u]);
 #pragma unroll
       for (int i = 0; i < DK; ++i) dqv[u][i] = fmaf(ds, kk[c][i], dqv[u][i]);
@@ -225,7 +272,7 @@ __device__ __forceinline__ void dq_chunk(const float* __restrict__ rows, int mgl
   }
 }
 
-// lane = QPL queries. Also writes delta[l] = sum_j do[l,j]*o[l,j] for the dK/dV pass.
+// lane = one query of block A and one of block B. Also writes delta[l] = sum_j dO[l,j]*O[l,j].
 template <int DK, int DV>
 __global__ void __launch_bounds__(512) attn_bwd_dq_kernel(const AttnArgs a) {
   using C = Cfg<DK, DV>;
@@ -235,11 +282,11 @@ __global__ void __launch_bounds__(512) attn_bwd_dq_kernel(const AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int L = a.L;
-  const int rows_per_block = 64 * QPL * a.nwaves;
-  const int qb = gridDim.x - 1 - blockIdx.x;
-  const int b0 = qb * rows_per_block;
-  const int l0 = b0 + wave * 64 * QPL;
-  const bool wave_on = l0 < L;
+  const int NB = (L + 63) >> 6;
+  const int wg = gridDim.x - 1 - blockIdx.x;
+  const int first = wg * a.blocks_per_wg;
+  const int nb = min(a.blocks_per_wg, NB - first);
+  const WavePlan w = plan_wave(first, nb, wave);
 
   const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * a.dk_dim * L;
   const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * a.dk_dim * L;
@@ -252,42 +299,45 @@ __global__ void __launch_bounds__(512) attn_bwd_dq_kernel(const AttnArgs a) {
   float qv[QPL][DK], dqv[QPL][DK], gv[QPL][DV], lse[QPL], delta[QPL];
 #pragma unroll
   for (int u = 0; u < QPL; ++u) {
-    lq[u] = l0 + u * 64 + lane;
+    const int blk = u == 0 ? w.bA : w.bB;
+    const bool slot_on = w.on && blk >= 0;
+    lq[u] = slot_on ? 64 * blk + lane : L;
     const int lc = min(lq[u], L - 1);
     my_last[u] = lc - a.strict;
 #pragma unroll
     for (int i = 0; i < DK; ++i) {
-      qv[u][i] = (wave_on && i < a.dk_dim) ? qp[(size_t)i * L + lc] * a.scale2 : 0.f;
+      qv[u][i] = (slot_on && i < a.dk_dim) ? qp[(size_t)i * L + lc] * a.scale2 : 0.f;
       dqv[u][i] = 0.f;
     }
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < DV; ++j) {
-      const bool ok = wave_on && j < a.dv_dim;
+      const bool ok = slot_on && j < a.dv_dim;
       gv[u][j] = ok ? gp[(size_t)j * L + lc] : 0.f;
       const float ov = ok ? op[(size_t)j * L + lc] : 0.f;
       d = fmaf(gv[u][j], ov, d);
     }
     delta[u] = d;
-    lse[u] = wave_on ? a.lse2_in[row + lc] : POS_BIG;
+    lse[u] = slot_on ? a.lse2_in[row + lc] : POS_BIG;
     if (lq[u] < L) a.delta[row + lq[u]] = d;
   }
-  const int wl_max = min(l0 + 64 * QPL - 1, L - 1);
-  const int m_end = wave_on ? wl_max - a.strict + 1 : 0;
-  const int m_full = wave_on ? max(0, l0 - a.strict + 1) : 0;
-  const int blk_end = min(b0 + rows_per_block - 1, L - 1) - a.strict + 1;
+  const KeyRegions r = key_regions<C::CH>(w, L, a.strict);
+  const int blk_end = min(64 * (first + nb - 1) + 63, L - 1) - a.strict + 1;
 
-  for (int m0 = 0; m0 < blk_end; m0 += C::KT) {
+  for (int m0 = 0; m0 < blk_end; m0 += a.kt) {
     __syncthreads();
-    stage_rows<DK, DV, C::RS, C::KT>(tile, kp, a.dk_dim, vp, a.dv_dim, L, m0, threadIdx.x, blockDim.x);
+    stage_rows<DK, DV, C::RS>(tile, kp, a.dk_dim, vp, a.dv_dim, L, m0, a.kt, threadIdx.x, blockDim.x);
     __syncthreads();
-    const int t_end = min(m0 + C::KT, m_end);
+    const int t_hi = m0 + a.kt;
     int m = m0;
-    const int t_full = min(t_end, (m_full / C::CH) * C::CH);
-    for (; m < t_full; m += C::CH)
-      dq_chunk<DK, DV, false>(tile + (m - m0) * C::RS, m, qv, gv, dqv, lse, delta, my_last);
-    for (; m < t_end; m += C::CH)
-      dq_chunk<DK, DV, true>(tile + (m - m0) * C::RS, m, qv, gv, dqv, lse, delta, my_last);
+    for (const int e = min(t_hi, r.fullB); m < e; m += C::CH)
+      dq_chunk<DK, DV, true, false, false>(tile + (m - m0) * C::RS, m, qv, gv, dqv, lse, delta, my_last);
+    for (const int e = min(t_hi, r.endB); m < e; m += C::CH)
+      dq_chunk<DK, DV, true, false, true>(tile + (m - m0) * C::RS, m, qv, gv, dqv, lse, delta, my_last);
+    for (const int e = min(t_hi, r.fullA); m < e; m += C::CH)
+      dq_chunk<DK, DV, false, false, false>(tile + (m - m0) * C::RS, m, qv, gv, dqv, lse, delta, my_last);
+    for (const int e = min(t_hi, r.endA); m < e; m += C::CH)
+      dq_chunk<DK, DV, false, true, false>(tile + (m - m0) * C::RS, m, qv, gv, dqv, lse, delta, my_last);
   }
 #pragma unroll
   for (int u = 0; u < QPL; ++u) {
@@ -301,9 +351,11 @@ __global__ void __launch_bounds__(512) attn_bwd_dq_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------ backward: dK, dV
-// staged query row: [q(DK) | dO(DV) | lse2 | delta | pad pad]
-template <int DK, int DV, bool MASKED>
-__device__ __forceinline__ void dkv_chunk(const float* __restrict__ rows, int lglob, int L,
+// staged query row: [q(DK) | dO(DV) | lse2 | delta | pad pad]; rows >= L are neutral
+// (q = dO = 0, lse = +BIG -> p = 0). slot A = the EARLIER key block (more queries), slot B = the
+// later one.
+template <int DK, int DV, bool ACTB, bool MASKA, bool MASKB>
+__device__ __forceinline__ void dkv_chunk(const float* __restrict__ rows, int lglob,
                                           const float (&kv)[QPL][DK], const float (&vv)[QPL][DV],
                                           float (&dkv)[QPL][DK], float (&dvv)[QPL][DV],
                                           const int (&my_first)[QPL]) {
@@ -317,7 +369,8 @@ __device__ __forceinline__ void dkv_chunk(const float* __restrict__ rows, int lg
     ld[c] = *reinterpret_cast<const float2*>(rows + c * RS2 + DK + DV);
   }
 #pragma unroll
-  for (int u = 0; u < QPL; ++u) {
+  for (int u = 0; u < (ACTB ? 2 : 1); ++u) {
+    const bool masked = u == 0 ? MASKA : MASKB;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       float t = kv[u][0] * qq[c][0];
@@ -327,7 +380,7 @@ __device__ __forceinline__ void dkv_chunk(const float* __restrict__ rows, int lg
 #pragma unroll
       for (int j = 1; j < DV; ++j) dp = fmaf(vv[u][j], gg[c][j], dp);
       float p = fast_exp2(t - ld[c].x);
-      if (MASKED) p = ((lglob + c) >= my_first[u] && (lglob + c) < L) ? p : 0.f;
+      if (masked) p = (lglob + c) >= my_first[u] ? p : 0.f;
       const float ds = p * (dp - ld[c].y);
 #pragma unroll
       for (int j = 0; j < DV; ++j) dvv[u][j] = fmaf(p, gg[c][j], dvv[u][j]);
@@ -337,20 +390,22 @@ __device__ __forceinline__ void dkv_chunk(const float* __restrict__ rows, int lg
   }
 }
 
-// lane = QPL keys; streams the queries l >= key + strict through LDS tiles.
 template <int DK, int DV>
 __global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(const AttnArgs a) {
   using C = Cfg<DK, DV>;
+  constexpr int CH = C::CH2;
   extern __shared__ float4 lds4[];
   float* tile = reinterpret_cast<float*>(lds4);
   const int h = blockIdx.y, n = blockIdx.z;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int L = a.L;
-  const int rows_per_block = 64 * QPL * a.nwaves;
-  const int b0 = blockIdx.x * rows_per_block;  // smallest keys (most queries) first
-  const int m0w = b0 + wave * 64 * QPL;
-  const bool wave_on = m0w < L;
+  const int NB = (L + 63) >> 6;
+  const int first = blockIdx.x * a.blocks_per_wg;  // smallest keys (most queries) first
+  const int nb = min(a.blocks_per_wg, NB - first);
+  WavePlan w = plan_wave(first, nb, wave);
+  // here the block that streams the whole range is the EARLIER one: swap roles
+  if (w.on && w.bB >= 0) { const int t = w.bA; w.bA = w.bB; w.bB = t; }
 
   const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * a.dk_dim * L;
   const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * a.dk_dim * L;
@@ -364,32 +419,41 @@ __global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(const AttnArgs a) {
   float kv[QPL][DK], dkv[QPL][DK], vv[QPL][DV], dvv[QPL][DV];
 #pragma unroll
   for (int u = 0; u < QPL; ++u) {
-    mk[u] = m0w + u * 64 + lane;
+    const int blk = u == 0 ? w.bA : w.bB;
+    const bool slot_on = w.on && blk >= 0;
+    mk[u] = slot_on ? 64 * blk + lane : L;
     const int mc = min(mk[u], L - 1);
     my_first[u] = mc + a.strict;
 #pragma unroll
     for (int i = 0; i < DK; ++i) {
-      kv[u][i] = (wave_on && i < a.dk_dim) ? kp[(size_t)i * L + mc] * a.scale2 : 0.f;
+      kv[u][i] = (slot_on && i < a.dk_dim) ? kp[(size_t)i * L + mc] * a.scale2 : 0.f;
       dkv[u][i] = 0.f;
     }
 #pragma unroll
     for (int j = 0; j < DV; ++j) {
-      vv[u][j] = (wave_on && j < a.dv_dim) ? vp[(size_t)j * L + mc] : 0.f;
+      vv[u][j] = (slot_on && j < a.dv_dim) ? vp[(size_t)j * L + mc] : 0.f;
       dvv[u][j] = 0.f;
     }
   }
-  // wave-uniform query ranges: band [w_lo, w_full) needs predicates, [w_full, L) is unmasked
-  const int w_lo = ((m0w + a.strict) / C::CH2) * C::CH2;
-  const int w_full = ((min(m0w + 64 * QPL - 1, L - 1) + a.strict + C::CH2 - 1) / C::CH2) * C::CH2;
-  const int L_full_end = (L / C::CH2) * C::CH2;
-  const int blk_lo = ((b0 + a.strict) / C::KT) * C::KT;  // first tile the block needs
+  // wave-uniform query regions (multiples of CH):
+  //   [startA, fullA) A masked | [fullA, startB) A | [startB, fullB) A + B masked | [fullB, Lr) A + B
+  const int Lr = ((L + CH - 1) / CH) * CH;
+  int startA = Lr, fullA = Lr, startB = Lr, fullB = Lr;
+  if (w.on) {
+    startA = ((64 * w.bA + a.strict) / CH) * CH;
+    fullA = min(Lr, ((min(64 * w.bA + 63, L - 1) + a.strict + CH - 1) / CH) * CH);
+    if (w.bB >= 0) {
+      startB = ((64 * w.bB + a.strict) / CH) * CH;
+      fullB = min(Lr, ((min(64 * w.bB + 63, L - 1) + a.strict + CH - 1) / CH) * CH);
+    }
+  }
+  const int blk_lo = ((64 * first + a.strict) / 64) * 64;  // first row the workgroup needs
 
-  for (int t0 = blk_lo; t0 < L; t0 += C::KT) {
+  for (int t0 = blk_lo; t0 < L; t0 += a.kt2) {
     __syncthreads();
-    // q | dO
-    for (int idx = threadIdx.x; idx < (DK + DV) * C::KT; idx += blockDim.x) {
-      const int c = idx / C::KT;
-      const int m = idx - c * C::KT;
+    for (int idx = threadIdx.x; idx < (DK + DV) * a.kt2; idx += blockDim.x) {
+      const int c = idx / a.kt2;
+      const int m = idx - c * a.kt2;
       const int gl = t0 + m;
       float val = 0.f;
       if (gl < L) {
@@ -401,25 +465,22 @@ __global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(const AttnArgs a) {
       }
       tile[m * C::RS2 + c] = val;
     }
-    // lse2 | delta (rows >= L get lse = +BIG -> p = 0)
-    for (int m = threadIdx.x; m < C::KT; m += blockDim.x) {
+    for (int m = threadIdx.x; m < a.kt2; m += blockDim.x) {
       const int gl = t0 + m;
       tile[m * C::RS2 + DK + DV] = gl < L ? lsep[gl] : POS_BIG;
       tile[m * C::RS2 + DK + DV + 1] = gl < L ? dlp[gl] : 0.f;
     }
     __syncthreads();
-    if (!wave_on) continue;
-    const int t_end = min(t0 + C::KT, L);
-    int lq = max(t0, w_lo);
-    // leading band
-    const int band_end = min(t_end, w_full);
-    for (; lq < band_end; lq += C::CH2)
-      dkv_chunk<DK, DV, true>(tile + (lq - t0) * C::RS2, lq, L, kv, vv, dkv, dvv, my_first);
-    const int full_end = min(t_end, L_full_end);
-    for (; lq < full_end; lq += C::CH2)
-      dkv_chunk<DK, DV, false>(tile + (lq - t0) * C::RS2, lq, L, kv, vv, dkv, dvv, my_first);
-    for (; lq < t_end; lq += C::CH2)  // ragged tail (zero / +BIG filled rows beyond L)
-      dkv_chunk<DK, DV, true>(tile + (lq - t0) * C::RS2, lq, L, kv, vv, dkv, dvv, my_first);
+    const int t_hi = min(t0 + a.kt2, Lr);
+    int lq = max(t0, startA);
+    for (const int e = min(t_hi, fullA); lq < e; lq += CH)
+      dkv_chunk<DK, DV, false, true, false>(tile + (lq - t0) * C::RS2, lq, kv, vv, dkv, dvv, my_first);
+    for (const int e = min(t_hi, startB); lq < e; lq += CH)
+      dkv_chunk<DK, DV, false, false, false>(tile + (lq - t0) * C::RS2, lq, kv, vv, dkv, dvv, my_first);
+    for (const int e = min(t_hi, fullB); lq < e; lq += CH)
+      dkv_chunk<DK, DV, true, false, true>(tile + (lq - t0) * C::RS2, lq, kv, vv, dkv, dvv, my_first);
+    for (; lq < t_hi; lq += CH)
+      dkv_chunk<DK, DV, true, false, false>(tile + (lq - t0) * C::RS2, lq, kv, vv, dkv, dvv, my_first);
   }
 
 #pragma unroll
@@ -442,12 +503,19 @@ enum { K_FWD = 0, K_DQ = 1, K_DKV = 2 };
 template <int DK, int DV>
 void launch_one(int which, const AttnArgs& a, dim3 grid, dim3 block, hipStream_t st) {
   using C = Cfg<DK, DV>;
+  // tile rows: everything the workgroup streams if it fits ~64 KB of LDS, else 64-row multiples
+  AttnArgs b = a;
+  const int rows = ((b.L + 63) / 64) * 64;
+  const int budget = 16384;  // floats
+  int kt = (budget / C::RS / 64) * 64, kt2 = (budget / C::RS2 / 64) * 64;
+  b.kt = kt < 64 ? 64 : (kt > rows ? rows : kt);
+  b.kt2 = kt2 < 64 ? 64 : (kt2 > rows ? rows : kt2);
   if (which == K_FWD)
-    hipLaunchKernelGGL((attn_fwd_kernel<DK, DV>), grid, block, C::KT * C::RS * sizeof(float), st, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<DK, DV>), grid, block, (size_t)b.kt * C::RS * sizeof(float), st, b);
   else if (which == K_DQ)
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DK, DV>), grid, block, C::KT * C::RS * sizeof(float), st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DK, DV>), grid, block, (size_t)b.kt * C::RS * sizeof(float), st, b);
   else
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DK, DV>), grid, block, C::KT * C::RS2 * sizeof(float), st, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DK, DV>), grid, block, (size_t)b.kt2 * C::RS2 * sizeof(float), st, b);
 }
 
 template <int DK>
@@ -462,13 +530,13 @@ int launch_dv(int which, const AttnArgs& a, dim3 grid, dim3 block, hipStream_t s
 }
 
 int launch_attn(int which, AttnArgs& a, hipStream_t st) {
-  // one block owns 128*nwaves consecutive rows; small L -> one block per (n, head)
-  const int rows_per_wave = 64 * QPL;
-  int nwaves = (a.L + rows_per_wave - 1) / rows_per_wave;
-  if (nwaves > 8) nwaves = 8;
-  a.nwaves = nwaves;
-  const int rows_per_block = rows_per_wave * nwaves;
-  dim3 grid((unsigned)((a.L + rows_per_block - 1) / rows_per_block), (unsigned)a.heads, (unsigned)a.N);
+  // a workgroup owns up to 16 consecutive 64-row blocks, handed to its waves in balanced pairs;
+  // small L -> one workgroup per (n, head)
+  const int NB = (a.L + 63) / 64;
+  const int bpw = NB < 16 ? NB : 16;
+  a.blocks_per_wg = bpw;
+  const int nwaves = (bpw + 1) / 2;
+  dim3 grid((unsigned)((NB + bpw - 1) / bpw), (unsigned)a.heads, (unsigned)a.N);
   dim3 block((unsigned)(64 * nwaves));
   const int dk = a.dk_dim;
   if (dk <= 4) return launch_dv<4>(which, a, grid, block, st);

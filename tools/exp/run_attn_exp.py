@@ -9,7 +9,7 @@ q = torch.randn(N, 16, L, device=dev); k = torch.randn(N, 16, L, device=dev); v 
 o = torch.empty_like(q)
 vp = ctypes.c_void_p
 lib.exp_attn_fwd.argtypes = [ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
-names = ["v1 CH8", "v1 CH4", "v1 CH4 prefetch", "v2 CH4", "v2 CH4 prefetch", "v2 CH8", "v1 CH2 prefetch", "v3 LDS qpl2", "v3 LDS qpl1", "v3 LDS qpl4"]
+names = ["v1 CH8", "v1 CH4", "v1 CH4 prefetch", "v2 CH4", "v2 CH4 prefetch", "v2 CH8", "v1 CH2 prefetch", "v3 LDS qpl2", "v3 LDS qpl1", "v3 LDS qpl4", "v4 MFMA QT8", "v4 MFMA QT4", "v5 balanced pairs"]
 st = torch.cuda.current_stream().cuda_stream
 ref = None
 for var, name in enumerate(names):
