@@ -56,10 +56,13 @@ const char* pg_last_error(void);
  * (zero outside the input extent). `wpk` is the packed weight made by pg_pack_conv_weight.
  * The same kernel is the data-gradient: call it with the transposed pack and negated taps.
  * `res` (optional, may be NULL) is added to the result (fused residual).
+ * `dact_src`/`dact` (optional): the result is multiplied by act'(dact_src) — the data gradient of
+ * a convolution whose forward fused `in_act` (dact_src = that convolution's raw input).
  * ------------------------------------------------------------------------------------- */
 int pg_conv2d_taps(const float* in, const float* wpk, const float* bias, const float* res,
                    float* out, int N, int Cin, int IH, int IW, int Cout, int OH, int OW,
-                   int T, const int* tap_dr, const int* tap_dc, int in_act, void* stream);
+                   int T, const int* tap_dr, const int* tap_dc, int in_act,
+                   const float* dact_src, int dact, void* stream);
 
 /* packed-weight helper: wpk[a][t][b] (b padded to b_pad, zero filled),
  *   transpose==0: = w[b][a][tap_u[t]][tap_v[t]]   (forward:   a=Cin,  b=Cout)
@@ -98,10 +101,13 @@ int pg_mul_inplace(float* w, const float* mask, size_t n, void* stream);
 int pg_nchw_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                           float* mean, float* rstd, int N, int C, int L, float eps,
                           void* stream);
-/* dgamma/dbeta are ACCUMULATED (atomics). */
+/* dgamma/dbeta are ADDED to (per-block partial rows through `workspace`, then a deterministic
+ * reduce kernel; no atomics). */
 int pg_nchw_layernorm_bwd(const float* x, const float* gamma, const float* mean,
                           const float* rstd, const float* dy, float* dx, float* dgamma,
-                          float* dbeta, int N, int C, int L, void* stream);
+                          float* dbeta, int N, int C, int L, float* workspace,
+                          size_t workspace_floats, void* stream);
+size_t pg_nchw_layernorm_bwd_workspace_floats(int N, int C, int L);
 
 /* ---------------------------------------------------------------------------------------
  * Fused causal attention core.  nn/attention.py:147-160:

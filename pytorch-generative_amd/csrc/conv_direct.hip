@@ -26,12 +26,13 @@ struct TapArgs {
   const float* wpk;
   const float* bias;
   const float* res;
+  const float* dact_src;  // optional: out *= act'(dact_src) (data-gradient of a fused input activation)
   float* out;
   int N, Cin, IH, IW, Cout, OH, OW, T;
   int b_pad;
   int TR, Wg, tiles_per_img;
   int tile_h, tile_w, min_dr, min_dc, ch_stride, CIB;
-  int in_act;
+  int in_act, dact;
   int vec;  // OW%4==0 and 16B-aligned out/res: float4 epilogue
   int tapoff[PG_MAX_TAPS];
 };
@@ -113,6 +114,11 @@ __global__ void __launch_bounds__(256) conv_taps_kernel(const TapArgs a) {
         const float4 rv = *reinterpret_cast<const float4*>(a.res + o);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
       }
+      if (a.dact_src) {
+        const float4 sv = *reinterpret_cast<const float4*>(a.dact_src + o);
+        v.x *= pg_act_grad(sv.x, a.dact); v.y *= pg_act_grad(sv.y, a.dact);
+        v.z *= pg_act_grad(sv.z, a.dact); v.w *= pg_act_grad(sv.w, a.dact);
+      }
       *reinterpret_cast<float4*>(a.out + o) = v;
     } else {
 #pragma unroll
@@ -120,6 +126,7 @@ __global__ void __launch_bounds__(256) conv_taps_kernel(const TapArgs a) {
         if (c0 + i < a.OW) {
           float v = acc[i][j] + b;
           if (a.res) v += a.res[o + i];
+          if (a.dact_src) v *= pg_act_grad(a.dact_src[o + i], a.dact);
           a.out[o + i] = v;
         }
       }
@@ -133,12 +140,13 @@ struct PwArgs {
   const float* wpk;
   const float* bias;
   const float* res;
+  const float* dact_src;
   float* out;
   int N, Cin, Cout, L, G;  // G = ceil(L/4) lane groups per image
-  int b_pad, in_act;
+  int b_pad, in_act, dact;
 };
 
-template <bool VEC, int ACT>
+template <bool VEC, int ACT, int DACT>
 __global__ void __launch_bounds__(256) conv_pw_kernel(const PwArgs a) {
   const long g = (long)blockIdx.x * 256 + threadIdx.x;
   const long total = (long)a.N * a.G;
@@ -156,7 +164,7 @@ __global__ void __launch_bounds__(256) conv_pw_kernel(const PwArgs a) {
 
   const float* xp = a.in + (size_t)n * a.Cin * a.L + p0;
   const float* wp = a.wpk + co0;
-#pragma unroll 2
+#pragma unroll 8
   for (int ci = 0; ci < a.Cin; ++ci) {
     float x0, x1 = 0.f, x2 = 0.f, x3 = 0.f;
     if (VEC) {
@@ -196,6 +204,11 @@ __global__ void __launch_bounds__(256) conv_pw_kernel(const PwArgs a) {
         const float4 rv = *reinterpret_cast<const float4*>(a.res + o);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
       }
+      if (DACT != PG_ACT_NONE) {
+        const float4 sv = *reinterpret_cast<const float4*>(a.dact_src + o);
+        v.x *= pg_act_grad(sv.x, DACT); v.y *= pg_act_grad(sv.y, DACT);
+        v.z *= pg_act_grad(sv.z, DACT); v.w *= pg_act_grad(sv.w, DACT);
+      }
       *reinterpret_cast<float4*>(a.out + o) = v;
     } else {
 #pragma unroll
@@ -203,6 +216,7 @@ __global__ void __launch_bounds__(256) conv_pw_kernel(const PwArgs a) {
         if (p0 + i < a.L) {
           float v = acc[i][j] + b;
           if (a.res) v += a.res[o + i];
+          if (DACT != PG_ACT_NONE) v *= pg_act_grad(a.dact_src[o + i], DACT);
           a.out[o + i] = v;
         }
       }
@@ -212,13 +226,25 @@ __global__ void __launch_bounds__(256) conv_pw_kernel(const PwArgs a) {
 
 template <bool VEC>
 int launch_pw(const PwArgs& a, dim3 grid, hipStream_t st) {
-  switch (a.in_act) {
-    case PG_ACT_NONE: hipLaunchKernelGGL((conv_pw_kernel<VEC, PG_ACT_NONE>), grid, dim3(256), 0, st, a); break;
-    case PG_ACT_RELU: hipLaunchKernelGGL((conv_pw_kernel<VEC, PG_ACT_RELU>), grid, dim3(256), 0, st, a); break;
-    case PG_ACT_ELU:  hipLaunchKernelGGL((conv_pw_kernel<VEC, PG_ACT_ELU>),  grid, dim3(256), 0, st, a); break;
-    case PG_ACT_GELU: hipLaunchKernelGGL((conv_pw_kernel<VEC, PG_ACT_GELU>), grid, dim3(256), 0, st, a); break;
-    default: return PG_EINVAL;
+#define PG_PW(ACT, DACT) hipLaunchKernelGGL((conv_pw_kernel<VEC, ACT, DACT>), grid, dim3(256), 0, st, a)
+  if (a.dact == PG_ACT_NONE) {
+    switch (a.in_act) {
+      case PG_ACT_NONE: PG_PW(PG_ACT_NONE, PG_ACT_NONE); break;
+      case PG_ACT_RELU: PG_PW(PG_ACT_RELU, PG_ACT_NONE); break;
+      case PG_ACT_ELU:  PG_PW(PG_ACT_ELU, PG_ACT_NONE); break;
+      case PG_ACT_GELU: PG_PW(PG_ACT_GELU, PG_ACT_NONE); break;
+      default: return PG_EINVAL;
+    }
+  } else {
+    if (a.in_act != PG_ACT_NONE) return PG_EINVAL;  // the fused act' epilogue is a dgrad feature
+    switch (a.dact) {
+      case PG_ACT_RELU: PG_PW(PG_ACT_NONE, PG_ACT_RELU); break;
+      case PG_ACT_ELU:  PG_PW(PG_ACT_NONE, PG_ACT_ELU); break;
+      case PG_ACT_GELU: PG_PW(PG_ACT_NONE, PG_ACT_GELU); break;
+      default: return PG_EINVAL;
+    }
   }
+#undef PG_PW
   return 0;
 }
 
@@ -287,7 +313,8 @@ PG_EXPORT int pg_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin,
 PG_EXPORT int pg_conv2d_taps(const float* in, const float* wpk, const float* bias,
                              const float* res, float* out, int N, int Cin, int IH, int IW,
                              int Cout, int OH, int OW, int T, const int* tap_dr,
-                             const int* tap_dc, int in_act, void* stream) {
+                             const int* tap_dc, int in_act, const float* dact_src, int dact,
+                             void* stream) {
   PG_REQUIRE(in && wpk && out && tap_dr && tap_dc, PG_EINVAL, "pg_conv2d_taps: null pointer");
   PG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, PG_EINVAL,
              "pg_conv2d_taps: non-positive dimension");
@@ -295,29 +322,33 @@ PG_EXPORT int pg_conv2d_taps(const float* in, const float* wpk, const float* bia
              PG_MAX_TAPS);
   PG_REQUIRE(in_act >= PG_ACT_NONE && in_act <= PG_ACT_GELU, PG_EINVAL,
              "pg_conv2d_taps: bad in_act %d", in_act);
+  PG_REQUIRE(dact >= PG_ACT_NONE && dact <= PG_ACT_GELU && ((dact == PG_ACT_NONE) == (dact_src == nullptr)),
+             PG_EINVAL, "pg_conv2d_taps: dact_src / dact mismatch");
   hipStream_t st = (hipStream_t)stream;
   const int b_pad = pg_conv_b_pad(Cout);
 
   if (T == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW) {
     PwArgs a;
-    a.in = in; a.wpk = wpk; a.bias = bias; a.res = res; a.out = out;
+    a.in = in; a.wpk = wpk; a.bias = bias; a.res = res; a.out = out; a.dact_src = dact_src;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.L = OH * OW; a.G = (a.L + PX - 1) / PX;
-    a.b_pad = b_pad; a.in_act = in_act;
+    a.b_pad = b_pad; a.in_act = in_act; a.dact = dact;
     const long groups = (long)N * a.G;
     dim3 grid((unsigned)((groups + 255) / 256), (unsigned)(b_pad / COB));
     const bool vec = (a.L % 4 == 0) && (((uintptr_t)in & 15) == 0) &&
-                     (((uintptr_t)out & 15) == 0) && (!res || ((uintptr_t)res & 15) == 0);
+                     (((uintptr_t)out & 15) == 0) && (!res || ((uintptr_t)res & 15) == 0) &&
+                     (!dact_src || ((uintptr_t)dact_src & 15) == 0);
     int rc = vec ? launch_pw<true>(a, grid, st) : launch_pw<false>(a, grid, st);
-    if (rc) { pg_set_error("pg_conv2d_taps: bad act"); return rc; }
+    if (rc) { pg_set_error("pg_conv2d_taps: unsupported in_act/dact combination"); return rc; }
     PG_LAUNCH_CHECK("pg_conv2d_taps(1x1)");
     return 0;
   }
 
   TapArgs a;
-  a.in = in; a.wpk = wpk; a.bias = bias; a.res = res; a.out = out;
+  a.in = in; a.wpk = wpk; a.bias = bias; a.res = res; a.out = out; a.dact_src = dact_src;
   a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW; a.T = T;
-  a.b_pad = b_pad; a.in_act = in_act;
-  a.vec = ((OW % 4) == 0) && (((uintptr_t)out & 15) == 0) && (!res || ((uintptr_t)res & 15) == 0);
+  a.b_pad = b_pad; a.in_act = in_act; a.dact = dact;
+  a.vec = ((OW % 4) == 0) && (((uintptr_t)out & 15) == 0) && (!res || ((uintptr_t)res & 15) == 0) &&
+          (!dact_src || ((uintptr_t)dact_src & 15) == 0);
   int min_dr = tap_dr[0], max_dr = tap_dr[0], min_dc = tap_dc[0], max_dc = tap_dc[0];
   for (int t = 1; t < T; ++t) {
     min_dr = tap_dr[t] < min_dr ? tap_dr[t] : min_dr;

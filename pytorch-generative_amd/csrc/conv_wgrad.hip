@@ -354,21 +354,21 @@ struct RedArgs {
   int tap_v[PG_MAX_TAPS];
 };
 
-// block = 32 consecutive slots x 8 row groups: loads stay 128-byte coalesced, the G-row sum is
-// split 8 ways and finished through LDS.
+// block = 8 consecutive slots x 32 row groups: the G-row sum is split 32 ways (short dependent
+// chains: this kernel is pure latency) and finished through LDS.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedArgs a) {
-  __shared__ float red[8][33];
-  const int sl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const long s = (long)blockIdx.x * 32 + sl;
+  __shared__ float red[32][9];
+  const int sl = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const long s = (long)blockIdx.x * 8 + sl;
   const long nw = (long)a.Cout * a.Cin * a.T;
   const long total = nw + (a.db ? a.Cout : 0);
   float acc0 = 0.f, acc1 = 0.f;
   if (s < total) {
     const float* p = a.part + s;
     int g = rg;
-    for (; g + 8 < a.G; g += 16) {
+    for (; g + 32 < a.G; g += 64) {
       acc0 += p[(size_t)g * a.part_stride];
-      acc1 += p[(size_t)(g + 8) * a.part_stride];
+      acc1 += p[(size_t)(g + 32) * a.part_stride];
     }
     if (g < a.G) acc0 += p[(size_t)g * a.part_stride];
   }
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedArgs a) {
   if (rg != 0 || s >= total) return;
   float acc = 0.f;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) acc += red[r][sl];
+  for (int r = 0; r < 32; ++r) acc += red[r][sl];
   if (s < nw) {
     const int t = (int)(s % a.T);
     const long cc = s / a.T;  // co*Cin + ci
@@ -394,7 +394,7 @@ int launch_reduce(const float* part, long stride, int G, float* dw, float* db, i
   r.Cout = Cout; r.Cin = Cin; r.KH = KH; r.KW = KW; r.T = T;
   for (int t = 0; t < T; ++t) { r.tap_u[t] = tap_u[t]; r.tap_v[t] = tap_v[t]; }
   const long total = (long)Cout * Cin * T + (db ? Cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 7) / 8)), dim3(256), 0, st, r);
   return 0;
 }
 

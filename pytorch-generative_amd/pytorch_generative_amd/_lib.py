@@ -27,7 +27,8 @@ SIGNATURES = {
     "pg_last_error": (ctypes.c_char_p, []),
     "pg_conv2d_taps": (
         c_i,
-        [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_s],
+        [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_f, c_i,
+         c_s],
     ),
     "pg_pack_conv_weight": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_i, c_s]),
     "pg_packed_weight_floats": (c_z, [c_i, c_i, c_i]),
@@ -40,7 +41,9 @@ SIGNATURES = {
     "pg_conv2d_wgrad_workspace_floats": (c_z, [c_i, c_i, c_i]),
     "pg_mul_inplace": (c_i, [c_f, c_f, c_z, c_s]),
     "pg_nchw_layernorm_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_flt, c_s]),
-    "pg_nchw_layernorm_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_s]),
+    "pg_nchw_layernorm_bwd": (
+        c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_z, c_s]),
+    "pg_nchw_layernorm_bwd_workspace_floats": (c_z, [c_i, c_i, c_i]),
     "pg_causal_attn_fwd": (
         c_i,
         [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_i, c_s],

@@ -122,7 +122,8 @@ class _ConvTaps(torch.autograd.Function):
         _lib.check(
             lib.pg_conv2d_taps(
                 x.data_ptr(), wpk.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih, iw,
-                cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, _stream(),
+                cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, 0, ACT_NONE,
+                _stream(),
             ),
             "pg_conv2d_taps",
         )
@@ -143,14 +144,19 @@ class _ConvTaps(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpk_t = _pack(lib, weight, spec, transpose=True)
             dx = torch.empty_like(x)
+            # ReLU's derivative is applied in the dgrad kernel's epilogue; for ELU/GELU (exp/erf:
+            # ~40 instructions per element) the fused epilogue measured SLOWER than a separate
+            # streaming pass (107 us vs 25 + 47 us on the ImageGPT MLP), so they stay separate.
+            fuse = ctx.in_act == ACT_RELU
             _lib.check(
                 lib.pg_conv2d_taps(
                     dy.data_ptr(), wpk_t.data_ptr(), 0, 0, dx.data_ptr(), n, cout, oh, ow, cin, ih,
-                    iw, len(spec.fwd_taps), spec.f_ndr, spec.f_ndc, ACT_NONE, _stream(),
+                    iw, len(spec.fwd_taps), spec.f_ndr, spec.f_ndc, ACT_NONE,
+                    x.data_ptr() if fuse else 0, ctx.in_act if fuse else ACT_NONE, _stream(),
                 ),
                 "pg_conv2d_taps(dgrad)",
             )
-            if ctx.in_act != ACT_NONE:
+            if ctx.in_act != ACT_NONE and not fuse:
                 _lib.check(
                     lib.pg_act_bwd(x.data_ptr(), dx.data_ptr(), dx.data_ptr(), dx.numel(),
                                    ctx.in_act, _stream()),
@@ -237,10 +243,12 @@ class _NCHWLayerNorm(torch.autograd.Function):
         if gb is None:
             db = torch.zeros(c, device=x.device, dtype=torch.float32)
             gb = db
+        ws_n = lib.pg_nchw_layernorm_bwd_workspace_floats(n, c, h * w)
+        ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
         _lib.check(
             lib.pg_nchw_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                       rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), gg.data_ptr(),
-                                      gb.data_ptr(), n, c, h * w, _stream()),
+                                      gb.data_ptr(), n, c, h * w, ws.data_ptr(), ws_n, _stream()),
             "pg_nchw_layernorm_bwd",
         )
         return dx, dg, db, None, None, None

@@ -32,7 +32,7 @@ def test_argument_errors_without_gpu(lib):
     from pytorch_generative_amd import _lib
 
     ia = _lib.int_array
-    rc = lib.pg_conv2d_taps(0, 0, 0, 0, 0, 1, 1, 4, 4, 1, 4, 4, 1, ia([0]), ia([0]), 0, 0)
+    rc = lib.pg_conv2d_taps(0, 0, 0, 0, 0, 1, 1, 4, 4, 1, 4, 4, 1, ia([0]), ia([0]), 0, 0, 0, 0)
     assert rc == -1
     with pytest.raises(ValueError, match="null pointer"):
         _lib.check(rc, "pg_conv2d_taps")
