@@ -154,11 +154,18 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # debugging hooks (1-GPU dev box): PG_FORCE_DEVICE pins every rank to one GPU and
+    # PG_DIST_BACKEND=gloo replaces RCCL so the multi-process code path can be exercised there
+    local_rank = int(os.environ.get("PG_FORCE_DEVICE", local_rank))
+    backend = os.environ.get("PG_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     import pytorch_generative_amd as pg
     from pytorch_generative_amd import graph, ops, optim, parallel
@@ -174,18 +181,31 @@ def main():
     x = synthetic_batch(args.batch, rank).to(device)
     loss_fn = lambda xx, preds: ops.bce_with_logits_sum_mean(preds, xx)  # noqa: E731
 
-    if args.no_graph:
-        def step():
-            opt.zero_grad()
-            loss = loss_fn(x, model(x))
-            loss.backward()
-            if reducer is not None:
-                reducer.all_reduce()
-            opt.step()
-            return loss.detach()
-    else:
-        gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
-        step = lambda: gstep()  # noqa: E731
+    def eager_step():
+        opt.zero_grad()
+        loss = loss_fn(x, model(x))
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        opt.step()
+        return loss.detach()
+
+    launch = "eager"
+    step = eager_step
+    if not args.no_graph:
+        try:
+            gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
+            step = lambda: gstep()  # noqa: E731
+            launch = "hipGraph replay"
+        except Exception as e:  # keep the bench alive (e.g. capture refused next to a live RCCL comm)
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); "
+                  "falling back to eager launches", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+    if world > 1:  # every rank must take the same path (graphs imply a different collective order)
+        flag = torch.tensor([1 if launch == "eager" else 0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) == 1 and launch != "eager":
+            step, launch = eager_step, "eager"
 
     for _ in range(args.warmup):
         loss = step()
@@ -230,7 +250,7 @@ def main():
                 "per_gpu_batch": args.batch,
                 "global_batch": global_batch,
                 "parallelism": f"dp{world}",
-                "launch": "eager" if args.no_graph else "hipGraph replay",
+                "launch": launch,
             },
             "loss_nats_per_image": loss_val,
             "bits_per_dim": loss_val / (784 * 0.6931471805599453),

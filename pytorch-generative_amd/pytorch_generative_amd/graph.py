@@ -41,15 +41,17 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
+        # thread_local: RCCL's watchdog thread may touch the HIP runtime while we capture
+        mode = dict(capture_error_mode="thread_local")
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
+        with torch.cuda.graph(self.graph_a, **mode):
             self.static_loss = self._fwd_bwd()
             if not self.split:
                 self.opt.step()
         self.graph_b = None
         if self.split:
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b):
+            with torch.cuda.graph(self.graph_b, **mode):
                 self.opt.step()
 
     def _fwd_bwd(self):
