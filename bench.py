@@ -29,13 +29,29 @@ import torch.distributed as dist  # noqa: E402
 MODEL_KW = dict(in_channels=1, out_channels=1, in_size=28, n_transformer_blocks=8,
                 n_attention_heads=4, n_embedding_channels=16)
 LR, LR_DECAY = 5e-3, 0.999977  # reference reproduce(): image_gpt.py:155-156
+# secondary workloads (same step definition; selected with --model, reported under the same
+# contract but NOT the default bench line): BASELINE.json configs[0], [2], [3]
+OTHER_MODELS = {
+    "pixel_snail": ("PixelSNAIL", dict(in_channels=3, out_channels=3, n_channels=64,
+                                       n_pixel_snail_blocks=8, n_residual_blocks=2,
+                                       attention_key_channels=4, attention_value_channels=32),
+                    (3, 32, 32), 1e-3, 0.999977, 7.97e9, 110.5e6),
+    "gated_pixel_cnn": ("GatedPixelCNN", dict(in_channels=3, out_channels=3, n_gated=10,
+                                              gated_channels=128, head_channels=32),
+                        (3, 32, 32), 1e-3, 0.9999, 21.23e9, 266e6),
+    "pixel_cnn": ("PixelCNN", dict(in_channels=1, out_channels=1, n_residual=15,
+                                   residual_channels=32, head_channels=32),
+                  (1, 28, 28), 1e-3, 0.999977, 0.964e9, 31.6e6),
+}
 HEADS, DK, DV, L = 4, 4, 4, 784
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix == vector peak (no TF32 on gfx950)
 
 
-def synthetic_batch(batch, rank):
+def synthetic_batch(batch, rank, chw=(1, 28, 28)):
     g = torch.Generator().manual_seed(1234 + rank)
-    return torch.bernoulli(torch.full((batch, 1, 28, 28), 0.1307), generator=g)
+    if chw[0] == 1:   # dynamically binarised MNIST-shaped (datasets.py:16-17)
+        return torch.bernoulli(torch.full((batch, *chw), 0.1307), generator=g)
+    return torch.randint(0, 256, (batch, *chw), generator=g).float() / 255  # CIFAR-shaped
 
 
 def attention_kernel_roofline(batch, device, iters=10):
@@ -142,6 +158,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--model", default="image_gpt", choices=["image_gpt", *OTHER_MODELS])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     args = ap.parse_args()
@@ -171,14 +188,20 @@ def main():
     from pytorch_generative_amd import graph, ops, optim, parallel
 
     torch.manual_seed(0)  # identical initial weights on every rank (then broadcast anyway)
-    model = pg.models.ImageGPT(**MODEL_KW).to(device)
+    chw, gflop_img, bytes_img = (1, 28, 28), 1.223e9, 26.2e6  # SURVEY.md §8(d), per image
+    if args.model == "image_gpt":
+        model = pg.models.ImageGPT(**MODEL_KW).to(device)
+        lr, lr_decay = LR, LR_DECAY
+    else:
+        ctor, kw, chw, lr, lr_decay, gflop_img, bytes_img = OTHER_MODELS[args.model]
+        model = getattr(pg.models, ctor)(**kw).to(device)
     model.train()
-    opt = optim.FlatAdam(model.parameters(), lr=LR, lr_decay=LR_DECAY)
+    opt = optim.FlatAdam(model.parameters(), lr=lr, lr_decay=lr_decay)
     reducer = None
     if world > 1:
         reducer = parallel.FlatGradAllReduce(opt)
         reducer.broadcast_parameters(src=0)
-    x = synthetic_batch(args.batch, rank).to(device)
+    x = synthetic_batch(args.batch, rank, chw).to(device)
     loss_fn = lambda xx, preds: ops.bce_with_logits_sum_mean(preds, xx)  # noqa: E731
 
     def eager_step():
@@ -255,7 +278,16 @@ def main():
             "loss_nats_per_image": loss_val,
             "bits_per_dim": loss_val / (784 * 0.6931471805599453),
         }
-        if world == 1:
+        if args.model != "image_gpt":
+            ctor, kw = OTHER_MODELS[args.model][:2]
+            out["metric"] = f"training images/sec ({ctor}, {chw[1]}x{chw[2]}x{chw[0]})"
+            out["config"]["workload"] = (f"{ctor}({kw}) on {chw[1]}x{chw[2]}x{chw[0]} synthetic; same step "
+                                         "definition as the default ImageGPT line (secondary workload)")
+            out["bits_per_dim"] = loss_val / (chw[0] * chw[1] * chw[2] * 0.6931471805599453)
+            out["roofline"] = {"step_tflops": value * gflop_img / 1e12,
+                               "step_hbm_gbps_algorithmic": value * bytes_img / 1e9,
+                               "note": "whole-step view against SURVEY.md §8(d) per-image work"}
+        elif world == 1:
             r = attention_kernel_roofline(args.batch, device)
             out["roofline"] = {
                 "bound": "mfma",  # fp32: matrix peak == vector peak == 157.3 TF on gfx950; this

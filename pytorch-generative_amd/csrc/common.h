@@ -66,3 +66,53 @@ __device__ __forceinline__ float pg_wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+
+// Stage `rows` = nch * tile_h rows of `tile_w` columns from channel planes in global memory into an
+// LDS tile laid out [ch][tile_h][tile_w] (channel stride ch_stride), zero filling everything outside
+// the plane and applying the (compile-time) activation once. Row r of channel c maps to input row
+// in_row0 + r and tile column t to input column t + min_dc.
+// The loop is pure latency, so it is written with NO branches at all — clamped unconditional loads,
+// a select, and an unconditional store whose address is redirected to a `dump` word for lanes that
+// have nothing to write (hipcc otherwise sinks each load into its predicated store: load, wait,
+// store, one at a time) — and unrolled 8x: 8 independent loads per lane are in flight before the
+// first wait. `rpi` rows are packed per wave iteration (lanes = 1 << swp_shift columns).
+template <int ACT>
+__device__ __forceinline__ void pg_stage_rows(float* __restrict__ lds, int dump, int ch_stride,
+                                              int tile_h, int tile_w, float inv_tile_h,
+                                              const float* __restrict__ src, size_t plane_stride,
+                                              int IH, int IW, int nch, int in_row0, int min_dc,
+                                              int swp_shift, int rpi, int wave, int nwaves, int lane) {
+  const int sub = lane >> swp_shift, col = lane & ((1 << swp_shift) - 1);
+  const int rows = nch * tile_h;
+  const int step = nwaves * rpi;
+  const int iters = (rows + step - 1) / step;
+  const int wcols = 1 << swp_shift;
+  for (int tc0 = 0; tc0 < tile_w; tc0 += wcols) {  // one pass unless the tile is wider than 64
+    const int tc = tc0 + col;
+    const int ic = tc + min_dc;
+    const int icc = ic < 0 ? 0 : (ic >= IW ? IW - 1 : ic);
+    const bool cok = ic >= 0 && ic < IW;
+    const bool cwr = tc < tile_w;
+    for (int it0 = 0; it0 < iters; it0 += 8) {
+      float v[8];
+      int didx[8];
+      bool ok[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {  // phase 1: eight independent loads
+        const int rr = (it0 + k) * step + wave * rpi + sub;
+        const bool rvalid = rr < rows;
+        const int rrc = rvalid ? rr : rows - 1;
+        const int ch = (int)(((float)rrc + 0.5f) * inv_tile_h);
+        const int tr = rrc - ch * tile_h;
+        const int ir = in_row0 + tr;
+        const int irc = ir < 0 ? 0 : (ir >= IH ? IH - 1 : ir);
+        v[k] = src[(size_t)ch * plane_stride + (size_t)irc * IW + icc];
+        ok[k] = cok && ir >= 0 && ir < IH;
+        didx[k] = (rvalid && cwr) ? ch * ch_stride + tr * tile_w + tc : dump;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)  // phase 2: eight LDS stores
+        lds[didx[k]] = ok[k] ? pg_apply_act(v[k], ACT) : 0.f;
+    }
+  }
+}

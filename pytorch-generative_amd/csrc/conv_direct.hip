@@ -33,10 +33,13 @@ struct TapArgs {
   int TR, Wg, tiles_per_img;
   int tile_h, tile_w, min_dr, min_dc, ch_stride, CIB;
   int in_act, dact;
+  int swp_shift, rpi;  // staging: lanes per tile row = 1 << swp_shift, rows per wave iteration
+  float inv_tile_h;
   int vec;  // OW%4==0 and 16B-aligned out/res: float4 epilogue
   int tapoff[PG_MAX_TAPS];
 };
 
+template <int ACT>
 __global__ void __launch_bounds__(256) conv_taps_kernel(const TapArgs a) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x;
@@ -63,25 +66,14 @@ __global__ void __launch_bounds__(256) conv_taps_kernel(const TapArgs a) {
   for (int ci0 = 0; ci0 < a.Cin; ci0 += a.CIB) {
     const int cib = min(a.CIB, a.Cin - ci0);
     __syncthreads();
-    // stage: one (channel,row) per wave iteration, lanes over columns
-    for (int rr = wave; rr < cib * a.tile_h; rr += nwaves) {
-      const int ci = rr / a.tile_h;
-      const int tr = rr - ci * a.tile_h;
-      const int ir = row0 + tr + a.min_dr;
-      const bool rok = (ir >= 0) && (ir < a.IH);
-      const float* src = in_n + ((size_t)(ci0 + ci) * a.IH + (rok ? ir : 0)) * a.IW;
-      float* dst = lds + ci * a.ch_stride + tr * a.tile_w;
-      for (int tc = lane; tc < a.tile_w; tc += 64) {
-        const int ic = tc + a.min_dc;
-        float v = 0.f;
-        if (rok && ic >= 0 && ic < a.IW) v = pg_apply_act(src[ic], a.in_act);
-        dst[tc] = v;
-      }
-    }
+    pg_stage_rows<ACT>(lds, a.CIB * a.ch_stride, a.ch_stride, a.tile_h, a.tile_w, a.inv_tile_h,
+                       in_n + (size_t)ci0 * a.IH * a.IW, (size_t)a.IH * a.IW, a.IH, a.IW, cib,
+                       row0 + a.min_dr, a.min_dc, a.swp_shift, a.rpi, wave, nwaves, lane);
     __syncthreads();
     for (int ci = 0; ci < cib; ++ci) {
       const float* xl = lds + ci * a.ch_stride + lane_base;
       const float* wrow = a.wpk + ((size_t)(ci0 + ci) * a.T) * a.b_pad + co0;
+#pragma unroll 4
       for (int t = 0; t < a.T; ++t) {
         const float* wp = wrow + (size_t)t * a.b_pad;  // wave-uniform -> scalar loads
         const int off = a.tapoff[t];
@@ -366,6 +358,13 @@ PG_EXPORT int pg_conv2d_taps(const float* in, const float* wpk, const float* bia
   a.tile_w = a.Wg * PX + (max_dc - min_dc);
   a.min_dr = min_dr; a.min_dc = min_dc;
   a.ch_stride = a.tile_h * a.tile_w;
+  {
+    int shift = 0;
+    while ((1 << shift) < a.tile_w && shift < 6) ++shift;
+    a.swp_shift = shift;
+    a.rpi = 64 >> shift;
+    a.inv_tile_h = 1.0f / (float)a.tile_h;
+  }
   int CIB = (48 * 1024 / 4) / a.ch_stride;
   PG_REQUIRE(CIB >= 1, PG_ESHAPE, "pg_conv2d_taps: tile %dx%d does not fit LDS", a.tile_h,
              a.tile_w);
@@ -374,8 +373,13 @@ PG_EXPORT int pg_conv2d_taps(const float* in, const float* wpk, const float* bia
   for (int t = 0; t < T; ++t) a.tapoff[t] = (tap_dr[t] - min_dr) * a.tile_w + (tap_dc[t] - min_dc);
   int threads = ((TR * a.Wg + 63) / 64) * 64;
   dim3 grid((unsigned)(N * a.tiles_per_img), (unsigned)(b_pad / COB));
-  const size_t shmem = (size_t)CIB * a.ch_stride * sizeof(float);
-  hipLaunchKernelGGL(conv_taps_kernel, grid, dim3(threads), shmem, st, a);
+  const size_t shmem = ((size_t)CIB * a.ch_stride + 4) * sizeof(float);  // + dump word
+  switch (in_act) {
+    case PG_ACT_RELU: hipLaunchKernelGGL(conv_taps_kernel<PG_ACT_RELU>, grid, dim3(threads), shmem, st, a); break;
+    case PG_ACT_ELU:  hipLaunchKernelGGL(conv_taps_kernel<PG_ACT_ELU>, grid, dim3(threads), shmem, st, a); break;
+    case PG_ACT_GELU: hipLaunchKernelGGL(conv_taps_kernel<PG_ACT_GELU>, grid, dim3(threads), shmem, st, a); break;
+    default:          hipLaunchKernelGGL(conv_taps_kernel<PG_ACT_NONE>, grid, dim3(threads), shmem, st, a); break;
+  }
   PG_LAUNCH_CHECK("pg_conv2d_taps");
   return 0;
 }

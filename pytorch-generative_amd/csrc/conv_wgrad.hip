@@ -28,7 +28,7 @@ constexpr int WG_THREADS = 256;
 constexpr int CO_CHUNK = 64;  // dy channels staged per block
 constexpr int CI_CHUNK = 32;  // x channels staged per block (2 MFMA column tiles)
 constexpr int TC = 9;         // taps accumulated concurrently (3x3 full = one pass)
-constexpr int LDS_BUDGET_FLOATS = 15000;  // ~60 KB -> 2 workgroups / CU
+constexpr int LDS_BUDGET_FLOATS = 36000;  // ~144 KB: one workgroup per CU, big tiles (staging is latency bound)
 
 struct WgArgs {
   const float* x; const float* dy; float* dw; float* db;
@@ -38,12 +38,14 @@ struct WgArgs {
   int TR, tiles_per_img, total_tiles, SW, xh, min_dr, min_dc;
   int S_dy, S_x, npos, in_act;
   int swp_shift, rpi;       // lanes per staged row = 1<<swp_shift, rows per wave iteration
+  int dump;                 // LDS float index of the dump word (past every tile / scratch area)
   float inv_TR, inv_xh;
   int tapoff[PG_MAX_TAPS];
   int tap_u[PG_MAX_TAPS];
   int tap_v[PG_MAX_TAPS];
 };
 
+template <int ACT>
 __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x;
@@ -82,42 +84,14 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
       const int n = tile / a.tiles_per_img;
       const int row0 = (tile - n * a.tiles_per_img) * a.TR;
       __syncthreads();
-      // ---- stage dy rows: `rpi` (channel,row) pairs per wave iteration, lanes over columns;
-      //      4 iterations unrolled so several independent global loads are in flight
-      {
-        const int sub = lane >> a.swp_shift, col = lane & ((1 << a.swp_shift) - 1);
-        const int rows = nco * a.TR;
-#pragma unroll 4
-        for (int rr0 = wave * a.rpi; rr0 < rows; rr0 += 4 * a.rpi) {
-          const int rr = rr0 + sub;
-          if (rr < rows) {
-            const int ch = (int)(((float)rr + 0.5f) * a.inv_TR);
-            const int r = rr - ch * a.TR;
-            const bool rok = row0 + r < a.OH;
-            const float* src = a.dy + (((size_t)n * a.Cout + co0 + ch) * a.OH + (rok ? row0 + r : 0)) * a.OW;
-            float* dst = dyl + ch * a.S_dy + r * a.SW;
-            for (int c = col; c < a.SW; c += (1 << a.swp_shift)) dst[c] = (rok && c < a.OW) ? src[c] : 0.f;
-          }
-        }
-        // ---- stage x rows (halo, zero filled, prologue activation applied once)
-        const int xrows = nci * a.xh;
-#pragma unroll 4
-        for (int rr0 = wave * a.rpi; rr0 < xrows; rr0 += 4 * a.rpi) {
-          const int rr = rr0 + sub;
-          if (rr < xrows) {
-            const int ch = (int)(((float)rr + 0.5f) * a.inv_xh);
-            const int xr = rr - ch * a.xh;
-            const int ir = row0 + xr + a.min_dr;
-            const bool rok = ir >= 0 && ir < a.IH;
-            const float* src = a.x + (((size_t)n * a.Cin + ci0 + ch) * a.IH + (rok ? ir : 0)) * a.IW;
-            float* dst = xl + ch * a.S_x + xr * a.SW;
-            for (int c = col; c < a.SW; c += (1 << a.swp_shift)) {
-              const int ic = c + a.min_dc;
-              dst[c] = (rok && ic >= 0 && ic < a.IW) ? pg_apply_act(src[ic], a.in_act) : 0.f;
-            }
-          }
-        }
-      }
+      // ---- stage the dy rows and the x rows (+halo, zero filled, prologue activation applied once)
+      pg_stage_rows<PG_ACT_NONE>(dyl, a.dump - (int)(dyl - lds), a.S_dy, a.TR, a.SW, a.inv_TR,
+                                 a.dy + ((size_t)n * a.Cout + co0) * a.OH * a.OW,
+                                 (size_t)a.OH * a.OW, a.OH, a.OW, nco, row0, 0, a.swp_shift, a.rpi,
+                                 wave, 4, lane);
+      pg_stage_rows<ACT>(xl, a.dump - (int)(xl - lds), a.S_x, a.xh, a.SW, a.inv_xh,
+                         a.x + ((size_t)n * a.Cin + ci0) * a.IH * a.IW, (size_t)a.IH * a.IW, a.IH,
+                         a.IW, nci, row0 + a.min_dr, a.min_dc, a.swp_shift, a.rpi, wave, 4, lane);
       __syncthreads();
       // ---- MFMA over the tile's positions
       if (cot < ncot_real) {
@@ -507,9 +481,16 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   size_t shmem = ((size_t)nco_alloc * a.S_dy + (size_t)nci * a.S_x) * sizeof(float);
   const size_t red_bytes = (size_t)3 * (2 * TC + 1) * 256 * sizeof(float);  // cross-wave reduction scratch
   if (shmem < red_bytes) shmem = red_bytes;
+  a.dump = (int)(shmem / sizeof(float));
+  shmem += 16;
   PG_REQUIRE(shmem <= 160 * 1024, PG_ESHAPE, "pg_conv2d_wgrad: LDS %zu B over budget", shmem);
   dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
-  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(WG_THREADS), shmem, st, a);
+  switch (in_act) {
+    case PG_ACT_RELU: hipLaunchKernelGGL(conv_wgrad_kernel<PG_ACT_RELU>, grid, dim3(WG_THREADS), shmem, st, a); break;
+    case PG_ACT_ELU:  hipLaunchKernelGGL(conv_wgrad_kernel<PG_ACT_ELU>, grid, dim3(WG_THREADS), shmem, st, a); break;
+    case PG_ACT_GELU: hipLaunchKernelGGL(conv_wgrad_kernel<PG_ACT_GELU>, grid, dim3(WG_THREADS), shmem, st, a); break;
+    default:          hipLaunchKernelGGL(conv_wgrad_kernel<PG_ACT_NONE>, grid, dim3(WG_THREADS), shmem, st, a); break;
+  }
   PG_LAUNCH_CHECK("pg_conv2d_wgrad");
   launch_reduce(workspace, stride, G, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
   PG_LAUNCH_CHECK("pg_conv2d_wgrad(reduce)");
