@@ -116,3 +116,53 @@ __device__ __forceinline__ void pg_stage_rows(float* __restrict__ lds, int dump,
     }
   }
 }
+
+// float4 variant of pg_stage_rows for planes whose rows are 16-byte aligned (IW % 4 == 0, aligned
+// base): a lane loads 4 consecutive input columns with one global_load_dwordx4. Only in-range
+// elements are written, so the caller zero-fills the tile ONCE (halo columns / out-of-range rows
+// are never written afterwards and stay zero). `qshift`: lanes per row = 1 << qshift >= IW/4.
+template <int ACT>
+__device__ __forceinline__ void pg_stage_rows_vec4(float* __restrict__ lds, int dump, int ch_stride,
+                                                   int tile_h, int tile_w, float inv_tile_h,
+                                                   const float* __restrict__ src,
+                                                   size_t plane_stride, int IH, int IW, int nch,
+                                                   int in_row0, int min_dc, int qshift, int wave,
+                                                   int nwaves, int lane) {
+  const int rpi = 64 >> qshift;
+  const int sub = lane >> qshift, q = lane & ((1 << qshift) - 1);
+  const int rows = nch * tile_h;
+  const int step = nwaves * rpi;
+  const int iters = (rows + step - 1) / step;
+  const bool qok = 4 * q < IW;
+  const int qc = qok ? q : 0;
+  const int tcol = 4 * q - min_dc;  // tile column of the quad's first element
+  for (int it0 = 0; it0 < iters; it0 += 8) {
+    float4 v[8];
+    int didx[8];
+    bool vok[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int rr = (it0 + k) * step + wave * rpi + sub;
+      const bool rvalid = rr < rows;
+      const int rrc = rvalid ? rr : rows - 1;
+      const int ch = (int)(((float)rrc + 0.5f) * inv_tile_h);
+      const int tr = rrc - ch * tile_h;
+      const int ir = in_row0 + tr;
+      vok[k] = rvalid && qok && ir >= 0 && ir < IH;
+      const int irc = ir < 0 ? 0 : (ir >= IH ? IH - 1 : ir);
+      v[k] = *reinterpret_cast<const float4*>(src + (size_t)ch * plane_stride + (size_t)irc * IW + 4 * qc);
+      didx[k] = ch * ch_stride + tr * tile_w + tcol;  // may be -1..-3 for the first quad: per-element check below
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = vok[k];
+      const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // a quad may straddle the tile's column range when no tap reaches its outer columns
+        const bool oki = ok && (tcol + i) >= 0 && (tcol + i) < tile_w;
+        lds[oki ? didx[k] + i : dump] = pg_apply_act(e[i], ACT);
+      }
+    }
+  }
+}

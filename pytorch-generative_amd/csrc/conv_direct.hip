@@ -34,19 +34,26 @@ struct TapArgs {
   int tile_h, tile_w, min_dr, min_dc, ch_stride, CIB;
   int in_act, dact;
   int swp_shift, rpi;  // staging: lanes per tile row = 1 << swp_shift, rows per wave iteration
+  int stage_vec, qshift;  // float4 staging (IW % 4 == 0, aligned): lanes per row = 1 << qshift
+  int pix_threads, CT;    // threads per cout-tile group, cout tiles per block
   float inv_tile_h;
   int vec;  // OW%4==0 and 16B-aligned out/res: float4 epilogue
   int tapoff[PG_MAX_TAPS];
 };
 
 template <int ACT>
-__global__ void __launch_bounds__(256) conv_taps_kernel(const TapArgs a) {
+__global__ void __launch_bounds__(512) conv_taps_kernel(const TapArgs a) {
   extern __shared__ float lds[];
-  const int tid = threadIdx.x;
+  // blockDim = pix_threads * CT: thread group g = tid / pix_threads works on cout tile
+  // blockIdx.y*CT + g of the SAME staged input tile (staging is amortised over CT cout tiles)
+  const int tid_all = threadIdx.x;
+  const int grp = tid_all / a.pix_threads;
+  const int tid = tid_all - grp * a.pix_threads;
   const int n = blockIdx.x / a.tiles_per_img;
   const int tile = blockIdx.x - n * a.tiles_per_img;
   const int row0 = tile * a.TR;
-  const int co0 = blockIdx.y * COB;
+  const int co0 = (blockIdx.y * a.CT + grp) * COB;
+  const int co0c = co0 < a.b_pad ? co0 : a.b_pad - COB;  // odd tile count: idle group re-reads a valid tile
 
   const int lr = tid / a.Wg;
   const int cg = tid - lr * a.Wg;
@@ -60,19 +67,27 @@ __global__ void __launch_bounds__(256) conv_taps_kernel(const TapArgs a) {
 #pragma unroll
     for (int j = 0; j < COB; ++j) acc[i][j] = 0.f;
 
-  const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = tid_all >> 6, lane = tid_all & 63, nwaves = blockDim.x >> 6;
   const float* in_n = a.in + (size_t)n * a.Cin * a.IH * a.IW;
+  if (a.stage_vec) {  // vec4 staging only writes in-range elements: zero the tile once
+    for (int i = tid_all; i < a.CIB * a.ch_stride; i += blockDim.x) lds[i] = 0.f;
+  }
 
   for (int ci0 = 0; ci0 < a.Cin; ci0 += a.CIB) {
     const int cib = min(a.CIB, a.Cin - ci0);
     __syncthreads();
-    pg_stage_rows<ACT>(lds, a.CIB * a.ch_stride, a.ch_stride, a.tile_h, a.tile_w, a.inv_tile_h,
-                       in_n + (size_t)ci0 * a.IH * a.IW, (size_t)a.IH * a.IW, a.IH, a.IW, cib,
-                       row0 + a.min_dr, a.min_dc, a.swp_shift, a.rpi, wave, nwaves, lane);
+    if (a.stage_vec)
+      pg_stage_rows_vec4<ACT>(lds, a.CIB * a.ch_stride, a.ch_stride, a.tile_h, a.tile_w, a.inv_tile_h,
+                              in_n + (size_t)ci0 * a.IH * a.IW, (size_t)a.IH * a.IW, a.IH, a.IW, cib,
+                              row0 + a.min_dr, a.min_dc, a.qshift, wave, nwaves, lane);
+    else
+      pg_stage_rows<ACT>(lds, a.CIB * a.ch_stride, a.ch_stride, a.tile_h, a.tile_w, a.inv_tile_h,
+                         in_n + (size_t)ci0 * a.IH * a.IW, (size_t)a.IH * a.IW, a.IH, a.IW, cib,
+                         row0 + a.min_dr, a.min_dc, a.swp_shift, a.rpi, wave, nwaves, lane);
     __syncthreads();
     for (int ci = 0; ci < cib; ++ci) {
       const float* xl = lds + ci * a.ch_stride + lane_base;
-      const float* wrow = a.wpk + ((size_t)(ci0 + ci) * a.T) * a.b_pad + co0;
+      const float* wrow = a.wpk + ((size_t)(ci0 + ci) * a.T) * a.b_pad + co0c;
 #pragma unroll 4
       for (int t = 0; t < a.T; ++t) {
         const float* wp = wrow + (size_t)t * a.b_pad;  // wave-uniform -> scalar loads
@@ -90,7 +105,7 @@ __global__ void __launch_bounds__(256) conv_taps_kernel(const TapArgs a) {
     }
   }
 
-  if (!active) return;
+  if (!active || co0 >= a.Cout) return;
   const int r = row0 + lr;
   const int c0 = cg * PX;
   const bool vec = a.vec != 0;
@@ -372,7 +387,17 @@ PG_EXPORT int pg_conv2d_taps(const float* in, const float* wpk, const float* bia
   a.CIB = CIB;
   for (int t = 0; t < T; ++t) a.tapoff[t] = (tap_dr[t] - min_dr) * a.tile_w + (tap_dc[t] - min_dc);
   int threads = ((TR * a.Wg + 63) / 64) * 64;
-  dim3 grid((unsigned)(N * a.tiles_per_img), (unsigned)(b_pad / COB));
+  a.pix_threads = threads;
+  a.CT = (b_pad / COB >= 2 && threads <= 256) ? 2 : 1;  // two cout tiles share one staged tile
+  a.stage_vec = ((IW % 4) == 0) && (((uintptr_t)in & 15) == 0) && (IW / 4 <= 64);
+  {
+    int qs = 0;
+    while ((1 << qs) < IW / 4 && qs < 6) ++qs;
+    a.qshift = qs;
+  }
+  const int ytiles = b_pad / COB;
+  dim3 grid((unsigned)(N * a.tiles_per_img), (unsigned)((ytiles + a.CT - 1) / a.CT));
+  threads *= a.CT;
   const size_t shmem = ((size_t)CIB * a.ch_stride + 4) * sizeof(float);  // + dump word
   switch (in_act) {
     case PG_ACT_RELU: hipLaunchKernelGGL(conv_taps_kernel<PG_ACT_RELU>, grid, dim3(threads), shmem, st, a); break;
