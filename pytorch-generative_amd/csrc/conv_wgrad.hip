@@ -27,7 +27,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WG_THREADS = 256;
 constexpr int CO_CHUNK = 64;  // dy channels staged per block
 constexpr int CI_CHUNK = 32;  // x channels staged per block (2 MFMA column tiles)
-constexpr int TC = 9;         // taps accumulated concurrently (3x3 full = one pass)
 constexpr int LDS_BUDGET_FLOATS = 36000;  // ~144 KB: one workgroup per CU, big tiles (staging is latency bound)
 
 struct WgArgs {
@@ -39,13 +38,14 @@ struct WgArgs {
   int S_dy, S_x, npos, in_act;
   int swp_shift, rpi;       // lanes per staged row = 1<<swp_shift, rows per wave iteration
   int dump;                 // LDS float index of the dump word (past every tile / scratch area)
+  int vec_dy, vec_x, qshift_dy, qshift_x;  // float4 staging when rows are 16-byte aligned
   float inv_TR, inv_xh;
   int tapoff[PG_MAX_TAPS];
   int tap_u[PG_MAX_TAPS];
   int tap_v[PG_MAX_TAPS];
 };
 
-template <int ACT>
+template <int NT, int NCIT>
 __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x;
@@ -71,46 +71,72 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
   const int b_base = (lane & 15) * a.S_x + (lane >> 4);
   const bool do_bias = (a.db != nullptr) && (blockIdx.z == 0);
 
-  for (int t0 = 0; t0 < a.T; t0 += TC) {
-    const int tcount = min(TC, a.T - t0);
-    f32x4 acc[2][TC];
+  // NT taps are accumulated per pass over the tiles; a last partial pass re-uses tap 0's offset
+  // for its surplus slots (their results are simply not flushed).
+  for (int t0 = 0; t0 < a.T; t0 += NT) {
+    const int tcount = min(NT, a.T - t0);
+    f32x4 acc[NCIT][NT];
     f32x4 accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NCIT; ++c)
 #pragma unroll
-      for (int t = 0; t < TC; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
       const int n = tile / a.tiles_per_img;
       const int row0 = (tile - n * a.tiles_per_img) * a.TR;
       __syncthreads();
       // ---- stage the dy rows and the x rows (+halo, zero filled, prologue activation applied once)
-      pg_stage_rows<PG_ACT_NONE>(dyl, a.dump - (int)(dyl - lds), a.S_dy, a.TR, a.SW, a.inv_TR,
-                                 a.dy + ((size_t)n * a.Cout + co0) * a.OH * a.OW,
-                                 (size_t)a.OH * a.OW, a.OH, a.OW, nco, row0, 0, a.swp_shift, a.rpi,
-                                 wave, 4, lane);
-      pg_stage_rows<ACT>(xl, a.dump - (int)(xl - lds), a.S_x, a.xh, a.SW, a.inv_xh,
-                         a.x + ((size_t)n * a.Cin + ci0) * a.IH * a.IW, (size_t)a.IH * a.IW, a.IH,
-                         a.IW, nci, row0 + a.min_dr, a.min_dc, a.swp_shift, a.rpi, wave, 4, lane);
+      if (a.vec_dy)
+        pg_stage_rows_vec4<PG_ACT_NONE>(dyl, a.dump - (int)(dyl - lds), a.S_dy, a.TR, a.SW, a.inv_TR,
+                                        a.dy + ((size_t)n * a.Cout + co0) * a.OH * a.OW,
+                                        (size_t)a.OH * a.OW, a.OH, a.OW, nco, row0, 0, a.qshift_dy,
+                                        wave, 4, lane);
+      else
+        pg_stage_rows<PG_ACT_NONE>(dyl, a.dump - (int)(dyl - lds), a.S_dy, a.TR, a.SW, a.inv_TR,
+                                   a.dy + ((size_t)n * a.Cout + co0) * a.OH * a.OW,
+                                   (size_t)a.OH * a.OW, a.OH, a.OW, nco, row0, 0, a.swp_shift, a.rpi,
+                                   wave, 4, lane);
+#define PG_STAGE_X(ACT)                                                                            \
+  if (a.vec_x)                                                                                      \
+    pg_stage_rows_vec4<ACT>(xl, a.dump - (int)(xl - lds), a.S_x, a.xh, a.SW, a.inv_xh,              \
+                            a.x + ((size_t)n * a.Cin + ci0) * a.IH * a.IW, (size_t)a.IH * a.IW,     \
+                            a.IH, a.IW, nci, row0 + a.min_dr, a.min_dc, a.qshift_x, wave, 4, lane);  \
+  else                                                                                              \
+    pg_stage_rows<ACT>(xl, a.dump - (int)(xl - lds), a.S_x, a.xh, a.SW, a.inv_xh,                   \
+                       a.x + ((size_t)n * a.Cin + ci0) * a.IH * a.IW, (size_t)a.IH * a.IW, a.IH,    \
+                       a.IW, nci, row0 + a.min_dr, a.min_dc, a.swp_shift, a.rpi, wave, 4, lane)
+      switch (a.in_act) {  // wave-uniform
+        case PG_ACT_RELU: PG_STAGE_X(PG_ACT_RELU); break;
+        case PG_ACT_ELU:  PG_STAGE_X(PG_ACT_ELU); break;
+        case PG_ACT_GELU: PG_STAGE_X(PG_ACT_GELU); break;
+        default:          PG_STAGE_X(PG_ACT_NONE); break;
+      }
+#undef PG_STAGE_X
       __syncthreads();
       // ---- MFMA over the tile's positions
       if (cot < ncot_real) {
+        // tap offsets hoisted out of the K loop (a kernarg s_load per tap per step shares
+        // lgkmcnt with the ds_reads), and the step body is branch-free: 1 + NT*NCIT ds_reads are
+        // issued back to back, then the MFMAs.
+        int toff[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) toff[t] = a.tapoff[t0 + (t < tcount ? t : 0)];
+        const bool bias_pass = do_bias && t0 == 0;
 #pragma unroll 2
         for (int p0 = kpart * 4; p0 < a.npos; p0 += 4 * ks) {
           const float av = dyl[a_base + p0];
-          if (do_bias && t0 == 0) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.0f, accb, 0, 0, 0);
+          float bv[NCIT][NT];
 #pragma unroll
-          for (int t = 0; t < TC; ++t) {
-            if (t < tcount) {
-              const int off = a.tapoff[t0 + t] + p0;
-              const float b0 = xl[b_base + off];
-              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0][t], 0, 0, 0);
-              if (ncit > 1) {
-                const float b1 = xl[b_base + 16 * a.S_x + off];
-                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1][t], 0, 0, 0);
-              }
-            }
-          }
+          for (int c = 0; c < NCIT; ++c)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bv[c][t] = xl[b_base + c * 16 * a.S_x + toff[t] + p0];
+#pragma unroll
+          for (int c = 0; c < NCIT; ++c)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[c][t], acc[c][t], 0, 0, 0);
+          if (bias_pass) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.0f, accb, 0, 0, 0);
         }
       }
     }
@@ -118,31 +144,31 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
     //      (co tile) instead of one per wave
     __syncthreads();
     if (ks > 1 && kpart > 0 && cot < ncot_real) {
-      float* dst = lds + ((size_t)((kpart - 1) * ncot + cot) * (2 * TC + 1)) * 256 + lane * 4;
+      float* dst = lds + ((size_t)((kpart - 1) * ncot + cot) * (NCIT * NT + 1)) * 256 + lane * 4;
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < NCIT; ++c)
 #pragma unroll
-        for (int t = 0; t < TC; ++t) *reinterpret_cast<f32x4*>(dst + (c * TC + t) * 256) = acc[c][t];
-      *reinterpret_cast<f32x4*>(dst + 2 * TC * 256) = accb;
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(dst + (c * NT + t) * 256) = acc[c][t];
+      *reinterpret_cast<f32x4*>(dst + NCIT * NT * 256) = accb;
     }
     __syncthreads();
     if (kpart == 0 && cot < ncot_real) {
       for (int kp = 1; kp < ks; ++kp) {
-        const float* src = lds + ((size_t)((kp - 1) * ncot + cot) * (2 * TC + 1)) * 256 + lane * 4;
+        const float* src = lds + ((size_t)((kp - 1) * ncot + cot) * (NCIT * NT + 1)) * 256 + lane * 4;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < NCIT; ++c)
 #pragma unroll
-          for (int t = 0; t < TC; ++t) acc[c][t] += *reinterpret_cast<const f32x4*>(src + (c * TC + t) * 256);
-        accb += *reinterpret_cast<const f32x4*>(src + 2 * TC * 256);
+          for (int t = 0; t < NT; ++t) acc[c][t] += *reinterpret_cast<const f32x4*>(src + (c * NT + t) * 256);
+        accb += *reinterpret_cast<const f32x4*>(src + NCIT * NT * 256);
       }
       const int co_b = co0 + cot * 16 + (lane >> 4) * 4;
       float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < NCIT; ++c) {
         if (c < ncit) {
           const int ci = ci0 + c * 16 + (lane & 15);
 #pragma unroll
-          for (int t = 0; t < TC; ++t) {
+          for (int t = 0; t < NT; ++t) {
             if (t < tcount && ci < a.Cin) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
@@ -164,7 +190,7 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
     }
     __syncthreads();
     // the reduction scratch overlapped the staging tiles: restore the never-rewritten zero margins
-    if (t0 + TC < a.T)
+    if (t0 + NT < a.T)
       for (int i = tid; i < lds_floats; i += WG_THREADS) lds[i] = 0.f;
   }
 }
@@ -472,6 +498,11 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   a.rpi = 64 >> shift;
   a.inv_TR = 1.0f / (float)a.TR;
   a.inv_xh = 1.0f / (float)a.xh;
+  a.vec_dy = (OW % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (OW / 4 <= 64);
+  a.vec_x = (IW % 4 == 0) && (((uintptr_t)x & 15) == 0) && (IW / 4 <= 64);
+  a.qshift_dy = a.qshift_x = 0;
+  while ((1 << a.qshift_dy) < OW / 4 && a.qshift_dy < 6) ++a.qshift_dy;
+  while ((1 << a.qshift_x) < IW / 4 && a.qshift_x < 6) ++a.qshift_x;
   const int co_chunks = (Cout + CO_CHUNK - 1) / CO_CHUNK;
   const int ci_chunks = (Cin + CI_CHUNK - 1) / CI_CHUNK;
   int G = 512 / (co_chunks * ci_chunks);
@@ -479,18 +510,23 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   if (G > a.total_tiles) G = a.total_tiles;
   if (G > max_rows) G = (int)max_rows;
   size_t shmem = ((size_t)nco_alloc * a.S_dy + (size_t)nci * a.S_x) * sizeof(float);
-  const size_t red_bytes = (size_t)3 * (2 * TC + 1) * 256 * sizeof(float);  // cross-wave reduction scratch
+  const int ncit_h = (nci + 15) / 16;
+  const int NTsel = T >= 9 ? 9 : (T >= 4 ? 4 : T);  // taps per pass: 1, 2, 3, 4 or 9
+  const size_t red_bytes = (size_t)3 * (ncit_h * NTsel + 1) * 256 * sizeof(float);  // cross-wave reduction scratch
   if (shmem < red_bytes) shmem = red_bytes;
   a.dump = (int)(shmem / sizeof(float));
   shmem += 16;
   PG_REQUIRE(shmem <= 160 * 1024, PG_ESHAPE, "pg_conv2d_wgrad: LDS %zu B over budget", shmem);
   dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
-  switch (in_act) {
-    case PG_ACT_RELU: hipLaunchKernelGGL(conv_wgrad_kernel<PG_ACT_RELU>, grid, dim3(WG_THREADS), shmem, st, a); break;
-    case PG_ACT_ELU:  hipLaunchKernelGGL(conv_wgrad_kernel<PG_ACT_ELU>, grid, dim3(WG_THREADS), shmem, st, a); break;
-    case PG_ACT_GELU: hipLaunchKernelGGL(conv_wgrad_kernel<PG_ACT_GELU>, grid, dim3(WG_THREADS), shmem, st, a); break;
-    default:          hipLaunchKernelGGL(conv_wgrad_kernel<PG_ACT_NONE>, grid, dim3(WG_THREADS), shmem, st, a); break;
+#define PG_WG(NT, NC) hipLaunchKernelGGL((conv_wgrad_kernel<NT, NC>), grid, dim3(WG_THREADS), shmem, st, a)
+  if (ncit_h <= 1) {
+    switch (NTsel) { case 1: PG_WG(1, 1); break; case 2: PG_WG(2, 1); break; case 3: PG_WG(3, 1); break;
+                     case 4: PG_WG(4, 1); break; default: PG_WG(9, 1); break; }
+  } else {
+    switch (NTsel) { case 1: PG_WG(1, 2); break; case 2: PG_WG(2, 2); break; case 3: PG_WG(3, 2); break;
+                     case 4: PG_WG(4, 2); break; default: PG_WG(9, 2); break; }
   }
+#undef PG_WG
   PG_LAUNCH_CHECK("pg_conv2d_wgrad");
   launch_reduce(workspace, stride, G, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
   PG_LAUNCH_CHECK("pg_conv2d_wgrad(reduce)");
