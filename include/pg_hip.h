@@ -170,6 +170,32 @@ int pg_bce_logits_bwd(const float* z, const float* x, const float* gscale, float
                       size_t per, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * VAE pieces (models/vae/vd_vae.py:224,256; models/vae/vaes.py:17-33; vae.py:91-93,149-159).
+ * ------------------------------------------------------------------------------------- */
+/* 2x2 average pool, stride 2: x (planes, 2*OH, 2*OW) -> y (planes, OH, OW); planes = N*C */
+int pg_avgpool2_fwd(const float* x, float* y, int planes, int OH, int OW, void* stream);
+int pg_avgpool2_bwd(const float* dy, float* dx, int planes, int OH, int OW, void* stream);
+/* nearest-neighbour x2 upsample: x (planes, IH, IW) -> y (planes, 2*IH, 2*IW) */
+int pg_upsample2_fwd(const float* x, float* y, int planes, int IH, int IW, void* stream);
+int pg_upsample2_bwd(const float* dy, float* dx, int planes, int IH, int IW, void* stream);
+/* Fused Gaussian head. q, p: (N, >=2C, L) conv outputs holding [mean | log_std] in channels
+ * [0,C) / [C,2C), read in place through batch strides q_bs / p_bs (floats). eps, z: (N, C, L).
+ *   mode 0: z = mu_q + exp(s_q) eps ; kl[n] += sum KL(q || N(0,1))       (vae.py:91-93)
+ *   mode 1: z = mu_q + exp(s_q) eps ; kl[n] += sum KL(q || p)            (vd_vae.py:177-186)
+ *   mode 2: z = mu_p + exp(s_p) eps (sampling from the prior, no KL)     (vd_vae.py:166-168)
+ * kl (N floats) is accumulated: the caller zeroes it. */
+int pg_gauss_head_fwd(const float* q, const float* p, const float* eps, float* z, float* kl, int N,
+                      int C, int L, long q_bs, long p_bs, int mode, void* stream);
+/* dq / dp receive the gradient of the [mean | log_std] channels (written, not accumulated);
+ * dz: (N,C,L) or NULL, dkl: (N) or NULL. */
+int pg_gauss_head_bwd(const float* q, const float* p, const float* eps, const float* dz,
+                      const float* dkl, float* dq, float* dp, int N, int C, int L, long q_bs,
+                      long p_bs, int mode, void* stream);
+/* out[0] += mean(v[0..n)) ; out[i] = g[0]*scale (its backward) */
+int pg_vec_mean_accum(const float* v, int n, float* out, void* stream);
+int pg_fill_scaled(const float* g, float scale, float* out, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser step as timed by the reference (trainer.py:183-191): global grad L2 norm
  * (clip_grad_norm_) + torch.optim.Adam over ONE flat parameter/grad buffer.
  * state (device, 8 floats): [0]=step count, [1]=lr, [2]=sum of squares (scratch),

@@ -123,6 +123,73 @@ def pixel_snail(p, x):
     return _conv(_conv(h, p, "_output.0"), p, "_output.1")
 
 
+# -------------------------------------------------------------------------------- VD-VAE
+def _bottleneck(p, pre, x, residual):
+    """BottleneckBlock.forward, vd_vae.py:102-104 (kernel size / padding read off the weights)."""
+    h = x
+    for idx in ("1", "3", "5", "7"):
+        w = p[f"{pre}_net.{idx}.weight"]
+        h = F.conv2d(F.gelu(h), w, p[f"{pre}_net.{idx}.bias"], padding=w.shape[-1] // 2)
+    return x + h if residual else h
+
+
+def _count(p, prefix):
+    return 1 + max(int(k[len(prefix):].split(".")[0]) for k in p if k.startswith(prefix))
+
+
+def vd_vae(p, x, eps_list):
+    """VeryDeepVAE.forward, vd_vae.py:375-405 (+ TopDownBlock.forward :147-189, EncoderStack
+    :226-229, DecoderStack :270-284). `eps_list` supplies the noise of every TopDownBlock in
+    call order (top-down). Returns (logits, kl_div per sample)."""
+    n = x.shape[0]
+    n_stacks = _count(p, "_encoder.")
+    latent = p["_decoder.0._topdowns.0._latents.weight"].shape[1]
+    h = F.conv2d(x, p["_input.weight"], p["_input.bias"], padding=1)
+    mixins = []
+    for i in range(n_stacks):
+        for j in range(_count(p, f"_encoder.{i}._residuals.")):
+            h = _bottleneck(p, f"_encoder.{i}._residuals.{j}.", h, True)
+        mixins.append(h)
+        if i < n_stacks - 1:
+            h = F.avg_pool2d(h, kernel_size=2, stride=2)
+    h = torch.zeros_like(p[f"_biases.{n_stacks - 1}"]).repeat(n, 1, 1, 1)
+    kl = torch.zeros(n)
+    eps_iter = iter(eps_list)
+    for i in range(n_stacks):
+        mixin, bias = mixins[n_stacks - 1 - i], p[f"_biases.{n_stacks - 1 - i}"]
+        h = h + bias.repeat(n, 1, 1, 1)
+        if i > 0:
+            h = F.interpolate(h, scale_factor=2, mode="nearest")
+        for j in range(_count(p, f"_decoder.{i}._topdowns.")):
+            pre = f"_decoder.{i}._topdowns.{j}."
+            prior = _bottleneck(p, pre + "_prior.", h, False)
+            p_mean, p_log_std, p_h = prior[:, :latent], prior[:, latent:2 * latent], prior[:, 2 * latent:]
+            post = _bottleneck(p, pre + "_posterior.", torch.cat((h, mixin), dim=1), False)
+            q_mean, q_log_std = post[:, :latent], post[:, latent:]
+            z = ops.sample_from_gaussian(q_mean, q_log_std, next(eps_iter))
+            kl = kl + ops.gaussian_kl_div(q_mean, q_log_std, p_mean, p_log_std).sum(dim=(1, 2, 3))
+            lat = F.conv2d(z, p[pre + "_latents.weight"], p[pre + "_latents.bias"])
+            h = _bottleneck(p, pre + "_out.", h + p_h + lat, True)
+    return F.conv2d(h, p["_output.weight"], p["_output.bias"]), kl
+
+
+def vd_vae_noise_shapes(p, n, input_resolution):
+    """Shapes of the eps tensors vd_vae() consumes, in call order."""
+    n_stacks = _count(p, "_encoder.")
+    latent = p["_decoder.0._topdowns.0._latents.weight"].shape[1]
+    shapes = []
+    for i in range(n_stacks):
+        res = input_resolution // 2 ** (n_stacks - 1 - i)
+        shapes += [(n, latent, res, res)] * _count(p, f"_decoder.{i}._topdowns.")
+    return shapes
+
+
+def elbo_terms(logits, x, kl):
+    """loss_fn of the VAE reproduce()s, vae.py:149-159: (recon.mean(), kl.mean(), elbo.mean())."""
+    recon = F.binary_cross_entropy_with_logits(logits, x, reduction="none").sum(dim=(1, 2, 3))
+    return recon.mean(), kl.mean(), (recon + kl).mean()
+
+
 FORWARDS = {
     "image_gpt": image_gpt,
     "pixel_cnn": pixel_cnn,

@@ -86,3 +86,20 @@ def bce_sum_mean(logits, x):
     n = x.shape[0]
     loss = F.binary_cross_entropy_with_logits(logits.reshape(n, -1), x.reshape(n, -1), reduction="none")
     return loss.sum(dim=1).mean()
+
+
+def unit_gaussian_kl_div(mean, log_std):
+    """models/vae/vaes.py:17-19."""
+    return -0.5 * (1 + 2 * log_std - log_std.exp().pow(2) - mean**2)
+
+
+def gaussian_kl_div(p_mean, p_log_std, q_mean, q_log_std):
+    """models/vae/vaes.py:23-27 — KL(p || q); note q_var = 2 * var(q) folded in."""
+    mean_delta, log_std_delta = (p_mean - q_mean) ** 2, q_log_std - p_log_std
+    p_var, q_var = p_log_std.exp().pow(2), 2 * q_log_std.exp().pow(2)
+    return -0.5 + log_std_delta + (p_var + mean_delta) / q_var
+
+
+def sample_from_gaussian(mu, log_sig, eps):
+    """models/vae/vaes.py:31-33 with the noise made explicit."""
+    return mu + log_sig.exp() * eps

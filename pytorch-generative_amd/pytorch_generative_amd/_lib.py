@@ -73,6 +73,14 @@ SIGNATURES = {
     "pg_add_bcast_bwd": (c_i, [c_f, c_f, c_i, c_z, c_s]),
     "pg_bce_logits_fwd": (c_i, [c_f, c_f, c_f, c_i, c_z, c_s]),
     "pg_bce_logits_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_z, c_s]),
+    "pg_avgpool2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
+    "pg_avgpool2_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
+    "pg_upsample2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
+    "pg_upsample2_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
+    "pg_gauss_head_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_l, c_l, c_i, c_s]),
+    "pg_gauss_head_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_l, c_l, c_i, c_s]),
+    "pg_vec_mean_accum": (c_i, [c_f, c_i, c_f, c_s]),
+    "pg_fill_scaled": (c_i, [c_f, c_flt, c_f, c_i, c_s]),
     "pg_sumsq_accum": (c_i, [c_f, c_z, c_f, c_s]),
     "pg_adam_prepare": (c_i, [c_f, c_s]),
     "pg_adam_step": (c_i, [c_f, c_f, c_f, c_f, c_z, c_f, c_flt, c_flt, c_flt, c_s]),

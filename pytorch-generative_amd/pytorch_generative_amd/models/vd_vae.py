@@ -1,0 +1,192 @@
+"""Very Deep VAE on the MI355X operator path (reference models/vae/vd_vae.py:48-412).
+
+Same constructor, parameter names (= state_dict keys) and forward graph, including the
+reference's quirks: the decoder's `_out` bottlenecks get the kernel size left over from the
+ENCODER loop (the decoder loop assigns a misspelt variable, vd_vae.py:354 vs :361), `_prior` /
+`_posterior` always use 3x3 bottlenecks, and last-conv weights are pre-scaled by
+1/sqrt(total blocks) (:337,:365-366). GELUs are fused into the following convolution's input
+load, residual adds into its epilogue; the Gaussian heads (split, KL, reparameterised sample) are
+one fused kernel reading the conv output in place.
+"""
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+from torch import nn
+
+from pytorch_generative_amd import nn as pg_nn
+from pytorch_generative_amd import ops
+from pytorch_generative_amd.models import vaes
+
+
+@dataclass
+class StackConfig:
+    """Encoder / decoder block counts of one resolution level."""
+
+    n_encoder_blocks: int
+    n_decoder_blocks: int
+
+
+DEFAULT_MODEL = [StackConfig(n_encoder_blocks=1, n_decoder_blocks=1) for _ in range(6)]
+
+
+class BottleneckBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, bottleneck_channels, bottleneck_kernel_size=3,
+                 is_residual=True):
+        super().__init__()
+        self._is_residual = is_residual
+        padding = 1 if bottleneck_kernel_size == 3 else 0  # like the reference: k in {1, 3}
+        self._net = nn.Sequential(
+            nn.GELU(),
+            pg_nn.Conv2d(in_channels, bottleneck_channels, kernel_size=1),
+            nn.GELU(),
+            pg_nn.Conv2d(bottleneck_channels, bottleneck_channels,
+                         kernel_size=bottleneck_kernel_size, padding=padding),
+            nn.GELU(),
+            pg_nn.Conv2d(bottleneck_channels, bottleneck_channels,
+                         kernel_size=bottleneck_kernel_size, padding=padding),
+            nn.GELU(),
+            pg_nn.Conv2d(bottleneck_channels, out_channels, kernel_size=1),
+        )
+
+    def forward(self, x):
+        h = self._net[1](x, in_act="gelu")
+        h = self._net[3](h, in_act="gelu")
+        h = self._net[5](h, in_act="gelu")
+        return self._net[7](h, in_act="gelu", res=x if self._is_residual else None)
+
+
+class TopDownBlock(nn.Module):
+    def __init__(self, n_channels, latent_channels, bottleneck_channels, bottleneck_kernel_size):
+        super().__init__()
+        self._n_channels = n_channels
+        self._latent_channels = latent_channels
+        self._prior = BottleneckBlock(n_channels, 2 * latent_channels + n_channels,
+                                      bottleneck_channels, is_residual=False)
+        self._posterior = BottleneckBlock(2 * n_channels, 2 * latent_channels,
+                                          bottleneck_channels, is_residual=False)
+        self._latents = pg_nn.Conv2d(latent_channels, n_channels, kernel_size=1)
+        self._out = BottleneckBlock(n_channels, n_channels, bottleneck_channels,
+                                    bottleneck_kernel_size=bottleneck_kernel_size, is_residual=True)
+
+    def forward(self, x, mixin=None):
+        c = self._latent_channels
+        n, _, h, w = x.shape
+        prior = self._prior(x)  # [p_mean | p_log_std | p_h]
+        eps = vaes.draw_noise((n, c, h, w), x.device)
+        if mixin is None:  # generation: sample from the prior
+            z, kl_div = ops.gaussian_head_prior(prior, eps, c), None
+        else:              # training: sample from the approximate posterior
+            post = self._posterior(torch.cat((x, mixin), dim=1))
+            z, kl_div = ops.gaussian_head_pair(post, prior, eps, c)
+        x_ph = ops.add(x, prior[:, 2 * c:].contiguous())
+        return self._out(self._latents(z, res=x_ph)), kl_div
+
+
+class EncoderStack(nn.Module):
+    def __init__(self, n_residual_blocks, pool, n_channels, bottleneck_channels,
+                 bottleneck_kernel_size):
+        super().__init__()
+        self._residuals = nn.Sequential(*[
+            BottleneckBlock(n_channels, n_channels, bottleneck_channels,
+                            bottleneck_kernel_size=bottleneck_kernel_size, is_residual=True)
+            for _ in range(n_residual_blocks)
+        ])
+        self._pool = nn.AvgPool2d(kernel_size=2, stride=2) if pool else None  # parameterless marker
+
+    def forward(self, x):
+        features = self._residuals(x)
+        x = ops.avg_pool2(features) if self._pool is not None else features
+        return x, features
+
+
+class DecoderStack(nn.Module):
+    def __init__(self, n_topdown_blocks, unpool, n_channels, latent_channels, bottleneck_channels,
+                 bottleneck_kernel_size):
+        super().__init__()
+        self._unpool = nn.Upsample(scale_factor=2, mode="nearest") if unpool else None  # marker
+        self._topdowns = nn.ModuleList([
+            TopDownBlock(n_channels, latent_channels, bottleneck_channels, bottleneck_kernel_size)
+            for _ in range(n_topdown_blocks)
+        ])
+
+    def forward(self, x, mixin=None):
+        if self._unpool is not None:
+            x = ops.upsample2_nearest(x)
+        kl_divs = []
+        for topdown in self._topdowns:
+            x, kl_div = topdown(x, mixin)
+            kl_divs.append(kl_div)
+        return x, kl_divs
+
+
+class VeryDeepVAE(vaes.VariationalAutoEncoder):
+    def __init__(self, in_channels=1, out_channels=1, input_resolution=32,
+                 stack_configs=DEFAULT_MODEL, latent_channels=4, hidden_channels=16,
+                 bottleneck_channels=8, sample_fn=None):
+        super().__init__(sample_fn)
+        stack_configs = [c if isinstance(c, StackConfig) else StackConfig(*c) for c in stack_configs]
+        self._hidden_channels = hidden_channels
+
+        self._input = pg_nn.Conv2d(in_channels, hidden_channels, kernel_size=3, padding=1)
+        self._encoder = nn.ModuleList()
+        resolutions = [input_resolution // 2**i for i in range(len(stack_configs))]
+        encoder_blocks = [conf.n_encoder_blocks for conf in stack_configs]
+        total_encoder_blocks = sum(encoder_blocks)
+        bottleneck_kernel_size = 3
+        for i, (res, n_blocks) in enumerate(zip(resolutions, encoder_blocks)):
+            bottleneck_kernel_size = 3 if res >= 3 else 1
+            stack = EncoderStack(n_blocks, i < len(stack_configs) - 1, hidden_channels,
+                                 bottleneck_channels, bottleneck_kernel_size)
+            for block in stack._residuals:
+                block._net[-1].weight.data /= np.sqrt(total_encoder_blocks)
+            self._encoder.append(stack)
+
+        self._biases = nn.ParameterList([
+            nn.Parameter(torch.zeros(1, hidden_channels, size, size))
+            for size in resolutions[1:] + [resolutions[-1]]
+        ])
+
+        self._decoder = nn.ModuleList()
+        decoder_blocks = [conf.n_decoder_blocks for conf in stack_configs]
+        total_decoder_blocks = sum(decoder_blocks)
+        for i, (res, n_blocks) in enumerate(zip(reversed(resolutions), reversed(decoder_blocks))):
+            # NB (reference quirk, vd_vae.py:354-361): the decoder stacks receive the kernel size
+            # the ENCODER loop ended with, not one derived from their own resolution.
+            stack = DecoderStack(n_blocks, i > 0, hidden_channels, latent_channels,
+                                 bottleneck_channels, bottleneck_kernel_size)
+            for block in stack._topdowns:
+                block._out._net[-1].weight.data /= np.sqrt(total_decoder_blocks)
+                block._latents.weight.data /= np.sqrt(total_decoder_blocks)
+            self._decoder.append(stack)
+        self._output = pg_nn.Conv2d(hidden_channels, out_channels, kernel_size=1)
+
+    def _top(self, n):
+        b = self._biases[-1]
+        return torch.zeros((n,) + tuple(b.shape[1:]), device=b.device, dtype=torch.float32)
+
+    def forward(self, x):
+        """Returns (logits, kl_div) with kl_div the per-sample sum over all latents (not normalised)."""
+        n = x.shape[0]
+        x = self._input(x)
+        mixins = []
+        for stack in self._encoder:
+            x, mixin = stack(x)
+            mixins.append(mixin)
+
+        x = self._top(n)
+        kl_divs = []
+        for stack, mixin, bias in zip(self._decoder, reversed(mixins), reversed(list(self._biases))):
+            x = ops.add_broadcast_batch(x, bias)
+            x, divs = stack(x, mixin)
+            kl_divs.extend(divs)
+        kl_div = torch.stack(kl_divs).sum(dim=0)
+        return self._output(x), kl_div
+
+    def _sample(self, n_samples):
+        x = self._top(n_samples)
+        for stack, bias in zip(self._decoder, reversed(list(self._biases))):
+            x = ops.add_broadcast_batch(x, bias)
+            x, _ = stack(x)
+        return self._output(x)

@@ -496,3 +496,177 @@ def bce_with_logits_sum_mean(logits, targets):
     """F.binary_cross_entropy_with_logits(reduction='none').sum(pixels).mean(batch)
     (reference image_gpt.py:158-162 and every other AR reproduce())."""
     return _BCEWithLogitsSumMean.apply(logits, targets)
+
+
+# --------------------------------------------------------------------------------------------
+# VAE pieces
+# --------------------------------------------------------------------------------------------
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _chk(x, "avgpool2.x")
+        n, c, h, w = x.shape
+        if h % 2 or w % 2:
+            raise ValueError("avg_pool2: H and W must be even")
+        y = torch.empty((n, c, h // 2, w // 2), device=x.device, dtype=torch.float32)
+        _lib.check(lib.pg_avgpool2_fwd(x.data_ptr(), y.data_ptr(), n * c, h // 2, w // 2, _stream()),
+                   "pg_avgpool2_fwd")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = _chk(dy, "avgpool2.dy")
+        n, c, oh, ow = dy.shape
+        dx = torch.empty((n, c, 2 * oh, 2 * ow), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.pg_avgpool2_bwd(dy.data_ptr(), dx.data_ptr(), n * c, oh, ow, _stream()),
+                   "pg_avgpool2_bwd")
+        return dx
+
+
+def avg_pool2(x):
+    """nn.AvgPool2d(kernel_size=2, stride=2)"""
+    return _AvgPool2.apply(x)
+
+
+class _Upsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _chk(x, "upsample2.x")
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
+        _lib.check(lib.pg_upsample2_fwd(x.data_ptr(), y.data_ptr(), n * c, h, w, _stream()),
+                   "pg_upsample2_fwd")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = _chk(dy, "upsample2.dy")
+        n, c, h2, w2 = dy.shape
+        dx = torch.empty((n, c, h2 // 2, w2 // 2), device=dy.device, dtype=torch.float32)
+        _lib.check(lib.pg_upsample2_bwd(dy.data_ptr(), dx.data_ptr(), n * c, h2 // 2, w2 // 2, _stream()),
+                   "pg_upsample2_bwd")
+        return dx
+
+
+def upsample2_nearest(x):
+    """nn.Upsample(scale_factor=2, mode="nearest")"""
+    return _Upsample2.apply(x)
+
+
+class _GaussHead(torch.autograd.Function):
+    """mode 0: (q, eps) -> z, kl vs N(0,1); mode 1: (q, p, eps) -> z, kl(q||p); mode 2: (p, eps) -> z."""
+
+    @staticmethod
+    def forward(ctx, q, p, eps, latent, mode):
+        lib = _lib.load()
+        ref = q if q is not None else p
+        n, _, h, w = ref.shape
+        L = h * w
+        if q is not None:
+            q = _chk(q, "gauss.q")
+            if q.shape[1] < 2 * latent:
+                raise ValueError("gauss head: q needs 2*latent channels")
+        if p is not None:
+            p = _chk(p, "gauss.p")
+            if p.shape[1] < 2 * latent:
+                raise ValueError("gauss head: p needs 2*latent channels")
+        eps = _chk(eps, "gauss.eps")
+        if tuple(eps.shape) != (n, latent, h, w):
+            raise ValueError(f"gauss head: eps shape {tuple(eps.shape)} != {(n, latent, h, w)}")
+        z = torch.empty((n, latent, h, w), device=ref.device, dtype=torch.float32)
+        kl = torch.zeros(n, device=ref.device, dtype=torch.float32)
+        _lib.check(
+            lib.pg_gauss_head_fwd(_p(q), _p(p), eps.data_ptr(), z.data_ptr(), kl.data_ptr(), n, latent,
+                                  L, 0 if q is None else q.shape[1] * L,
+                                  0 if p is None else p.shape[1] * L, mode, _stream()),
+            "pg_gauss_head_fwd",
+        )
+        ctx.save_for_backward(*[t for t in (q, p, eps) if t is not None])
+        ctx.cfg = (q is not None, p is not None, latent, mode)
+        ctx.mark_non_differentiable(kl) if mode == 2 else None
+        return z, kl
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        lib = _lib.load()
+        has_q, has_p, latent, mode = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        q = saved.pop(0) if has_q else None
+        p = saved.pop(0) if has_p else None
+        eps = saved.pop(0)
+        ref = q if q is not None else p
+        n, _, h, w = ref.shape
+        L = h * w
+        dz = _chk(dz, "gauss.dz") if dz is not None else None
+        dkl = _chk(dkl, "gauss.dkl") if (dkl is not None and mode != 2) else None
+        dq = dp = None
+        if q is not None:
+            dq = torch.empty_like(q) if q.shape[1] == 2 * latent else torch.zeros_like(q)
+        if p is not None:
+            dp = torch.empty_like(p) if p.shape[1] == 2 * latent else torch.zeros_like(p)
+        _lib.check(
+            lib.pg_gauss_head_bwd(_p(q), _p(p), eps.data_ptr(), _p(dz), _p(dkl), _p(dq), _p(dp), n,
+                                  latent, L, 0 if q is None else q.shape[1] * L,
+                                  0 if p is None else p.shape[1] * L, mode, _stream()),
+            "pg_gauss_head_bwd",
+        )
+        return dq, dp, None, None, None
+
+
+def gaussian_head_unit(h, eps, latent_channels):
+    """h = [mean | log_std]: returns (z = mean + exp(log_std) * eps, KL(q || N(0, 1)) summed per sample)."""
+    return _GaussHead.apply(h, None, eps, latent_channels, 0)
+
+
+def gaussian_head_pair(q, p, eps, latent_channels):
+    """Returns (z ~ q, KL(q || p) per sample); q, p hold [mean | log_std | ...] along channels."""
+    return _GaussHead.apply(q, p, eps, latent_channels, 1)
+
+
+def gaussian_head_prior(p, eps, latent_channels):
+    """z = mean_p + exp(log_std_p) * eps."""
+    return _GaussHead.apply(None, p, eps, latent_channels, 2)[0]
+
+
+class _ElboMean(torch.autograd.Function):
+    """loss = mean_n(recon_n) + mean_n(kl_n) with recon_n the per-sample BCE-with-logits sum."""
+
+    @staticmethod
+    def forward(ctx, logits, x, kl):
+        lib = _lib.load()
+        logits, x, kl = _chk(logits, "elbo.logits"), _chk(x, "elbo.x"), _chk(kl, "elbo.kl")
+        n = logits.shape[0]
+        recon = torch.zeros(1, device=logits.device, dtype=torch.float32)
+        klm = torch.zeros(1, device=logits.device, dtype=torch.float32)
+        _lib.check(lib.pg_bce_logits_fwd(logits.data_ptr(), x.data_ptr(), recon.data_ptr(), n,
+                                         logits.numel() // n, _stream()), "pg_bce_logits_fwd")
+        _lib.check(lib.pg_vec_mean_accum(kl.data_ptr(), n, klm.data_ptr(), _stream()),
+                   "pg_vec_mean_accum")
+        ctx.save_for_backward(logits, x)
+        ctx.n = n
+        return recon.view(()), klm.view(())
+
+    @staticmethod
+    def backward(ctx, g_recon, g_kl):
+        lib = _lib.load()
+        logits, x = ctx.saved_tensors
+        n = ctx.n
+        dz = torch.empty_like(logits)
+        g_recon = _chk(g_recon.reshape(1), "elbo.g")
+        _lib.check(lib.pg_bce_logits_bwd(logits.data_ptr(), x.data_ptr(), g_recon.data_ptr(),
+                                         dz.data_ptr(), n, logits.numel() // n, _stream()),
+                   "pg_bce_logits_bwd")
+        dkl = torch.empty(n, device=logits.device, dtype=torch.float32)
+        g_kl = _chk(g_kl.reshape(1), "elbo.gk")
+        _lib.check(lib.pg_fill_scaled(g_kl.data_ptr(), 1.0 / n, dkl.data_ptr(), n, _stream()),
+                   "pg_fill_scaled")
+        return dz, None, dkl
+
+
+def elbo_terms(logits, x, kl):
+    """Returns (recon_loss.mean(), kl_div.mean()) of the reference VAE loss_fn (vae.py:149-159)."""
+    return _ElboMean.apply(logits, x, kl)

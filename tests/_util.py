@@ -9,7 +9,14 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    return sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.pt")))
+    """Autoregressive-model fixtures (the VAE fixtures, `vae_*.pt`, carry noise and KL terms)."""
+    names = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.pt")))
+    return [n for n in names if not n.startswith("vae_")]
+
+
+def vae_golden_names():
+    names = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN_DIR, "vae_*.pt")))
+    return names
 
 
 def load_golden(name):

@@ -80,5 +80,55 @@ def main():
         print(f"{name}: loss={float(loss.detach()):.6f} norm={float(norm):.6f} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def make_vd_vae():
+    """VD-VAE fixture: the reference's noise (torch.randn_like inside vaes.sample_from_gaussian)
+    is replaced by pre-drawn eps (saved in the fixture) so the step is reproducible anywhere."""
+    ref = _ref.load()
+    from pytorch_generative.models.vae import vaes as rvaes
+    from pytorch_generative.models.vae import vd_vae as rvd
+
+    from oracle import models as omodels
+
+    torch.manual_seed(0)
+    cfg = [(2, 3), (2, 2), (1, 2), (1, 1)]
+    kwargs = dict(in_channels=3, out_channels=3, input_resolution=16, stack_configs=cfg,
+                  latent_channels=4, hidden_channels=16, bottleneck_channels=8)
+    rk = dict(kwargs, stack_configs=[rvd.StackConfig(*c) for c in cfg])
+    model = ref.models.VeryDeepVAE(**rk)
+    with torch.no_grad():
+        for b in model._biases:
+            b.normal_(0, 0.1)
+    x = make_input((2, 3, 16, 16), "cifar")
+    state0 = _ref.clone_state(model)
+    eg = torch.Generator().manual_seed(4321)
+    eps = [torch.randn(s, generator=eg) for s in omodels.vd_vae_noise_shapes(state0, 2, 16)]
+    it = iter(eps)
+    orig = rvaes.sample_from_gaussian
+    rvaes.sample_from_gaussian = lambda mu, log_sig: mu + log_sig.exp() * next(it)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    try:
+        opt.zero_grad()
+        logits, kl = model(x)
+    finally:
+        rvaes.sample_from_gaussian = orig
+    import torch.nn.functional as F
+    recon = F.binary_cross_entropy_with_logits(logits, x, reduction="none").sum(dim=(1, 2, 3))
+    loss = (recon + kl).mean()
+    loss.backward()
+    norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1e50)
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None)
+             for k, p in model.named_parameters()}
+    opt.step()
+    out = {"ctor": "VeryDeepVAE", "kwargs": kwargs, "lr": 5e-4, "x": x, "eps": eps, "state0": state0,
+           "logits": logits.detach().clone(), "kl": kl.detach().clone(),
+           "recon_mean": recon.mean().detach().clone(), "kl_mean": kl.mean().detach().clone(),
+           "loss": loss.detach().clone(), "grads": grads, "grad_norm": norm.detach().clone(),
+           "state1": _ref.clone_state(model), "torch_version": torch.__version__}
+    path = os.path.join(HERE, "vae_vd_vae_small.pt")
+    torch.save(out, path)
+    print(f"vd_vae_small: elbo={float(loss):.6f} kl={float(kl.mean()):.6f} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     main()
+    make_vd_vae()

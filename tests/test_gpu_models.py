@@ -206,3 +206,96 @@ def test_graphed_step_equals_eager_step(dev):
         if not k.endswith("_kv.bias"):
             _util.assert_close(p2, p1, 2e-2, f"{k} after 7 steps")
     assert abs(float(o2.state_block[1]) - 5e-3 * 0.999977 ** 7) < 1e-8
+
+
+@pytest.mark.parametrize("name", _util.vae_golden_names())
+def test_vd_vae_golden_step(dev, name):
+    """VD-VAE (BASELINE.json configs[4]) against the reference's golden step: logits, per-sample
+    KL, ELBO terms, every parameter gradient, grad norm and the parameters after one Adam step,
+    with the reference's noise replayed through the model's noise hook."""
+    import pytorch_generative_amd as pg
+    from pytorch_generative_amd import ops, optim
+    from pytorch_generative_amd.models import vaes
+
+    g = _util.load_golden(name)
+    model = getattr(pg.models, g["ctor"])(**g["kwargs"])
+    model.load_state_dict(g["state0"], strict=True)
+    model = model.to(dev)
+    opt = optim.FlatAdam(model.parameters(), lr=g["lr"])
+    x = g["x"].to(dev)
+    eps = iter([e.to(dev) for e in g["eps"]])
+    vaes.set_noise_fn(lambda shape, device: next(eps))
+    try:
+        opt.zero_grad()
+        logits, kl = model(x)
+    finally:
+        vaes.set_noise_fn(None)
+    _util.assert_close(logits, g["logits"], TOL, "logits")
+    _util.assert_close(kl, g["kl"], TOL, "kl per sample")
+    recon, klm = ops.elbo_terms(logits, x, kl)
+    _util.assert_close(recon, g["recon_mean"], TOL, "recon")
+    _util.assert_close(klm, g["kl_mean"], TOL, "kl mean")
+    loss = recon + klm
+    _util.assert_close(loss, g["loss"], TOL, "elbo")
+    loss.backward()
+    for k, p in model.named_parameters():
+        want = g["grads"][k]
+        if want is None or float(want.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) <= 1e-6 * float(g["grad_norm"]), k
+        else:
+            _util.assert_close(p.grad, want, GRAD_TOL, f"grad {k}")
+    opt.step()
+    _util.assert_close(opt.grad_norm(), g["grad_norm"], TOL, "grad norm")
+
+
+def test_vae_pool_upsample_and_gauss_heads(dev):
+    """The VAE-only kernels against torch-CPU / the oracle formulas."""
+    import torch.nn.functional as F
+
+    from oracle import ops as oops
+    from pytorch_generative_amd import ops
+
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 8, 12, generator=gen)
+    dy = torch.randn(2, 5, 4, 6, generator=gen)
+    xo = x.clone().requires_grad_(True)
+    F.avg_pool2d(xo, 2, 2).backward(dy)
+    xg = x.to(dev).requires_grad_(True)
+    yg = ops.avg_pool2(xg)
+    _util.assert_close(yg, F.avg_pool2d(x, 2, 2), 1e-6, "avgpool")
+    yg.backward(dy.to(dev))
+    _util.assert_close(xg.grad, xo.grad, 1e-6, "avgpool grad")
+    du = torch.randn(2, 5, 16, 24, generator=gen)
+    xo = x.clone().requires_grad_(True)
+    F.interpolate(xo, scale_factor=2, mode="nearest").backward(du)
+    xg = x.to(dev).requires_grad_(True)
+    ug = ops.upsample2_nearest(xg)
+    assert torch.equal(ug.cpu(), F.interpolate(x, scale_factor=2, mode="nearest"))
+    ug.backward(du.to(dev))
+    _util.assert_close(xg.grad, xo.grad, 1e-6, "upsample grad")
+
+    c = 3
+    q = torch.randn(2, 2 * c, 4, 4, generator=gen) * 0.5
+    p = torch.randn(2, 2 * c + 5, 4, 4, generator=gen) * 0.5
+    eps = torch.randn(2, c, 4, 4, generator=gen)
+    gz, gk = torch.randn(2, c, 4, 4, generator=gen), torch.randn(2, generator=gen)
+    qo, po = q.clone().requires_grad_(True), p.clone().requires_grad_(True)
+    zo = oops.sample_from_gaussian(qo[:, :c], qo[:, c:], eps)
+    klo = oops.gaussian_kl_div(qo[:, :c], qo[:, c:], po[:, :c], po[:, c:2 * c]).sum(dim=(1, 2, 3))
+    ((zo * gz).sum() + (klo * gk).sum()).backward()
+    qg, pg_ = q.to(dev).requires_grad_(True), p.to(dev).requires_grad_(True)
+    zg, klg = ops.gaussian_head_pair(qg, pg_, eps.to(dev), c)
+    _util.assert_close(zg, zo, 1e-5, "z")
+    _util.assert_close(klg, klo, 1e-5, "kl pair")
+    ((zg * gz.to(dev)).sum() + (klg * gk.to(dev)).sum()).backward()
+    _util.assert_close(qg.grad, qo.grad, 1e-5, "dq")
+    _util.assert_close(pg_.grad, po.grad, 1e-5, "dp")
+    qo = q.clone().requires_grad_(True)
+    klu = oops.unit_gaussian_kl_div(qo[:, :c], qo[:, c:]).sum(dim=(1, 2, 3))
+    zu = oops.sample_from_gaussian(qo[:, :c], qo[:, c:], eps)
+    ((zu * gz).sum() + (klu * gk).sum()).backward()
+    qg = q.to(dev).requires_grad_(True)
+    zg, klg = ops.gaussian_head_unit(qg, eps.to(dev), c)
+    _util.assert_close(klg, klu, 1e-5, "kl unit")
+    ((zg * gz.to(dev)).sum() + (klg * gk.to(dev)).sum()).backward()
+    _util.assert_close(qg.grad, qo.grad, 1e-5, "dq unit")

@@ -61,6 +61,17 @@ def test_state_dict_layout_matches_reference(name):
             assert torch.equal(model.state_dict()[k], v), k  # causal masks bit-exact
 
 
+@pytest.mark.parametrize("name", _util.vae_golden_names())
+def test_vae_state_dict_layout_matches_reference(name):
+    import pytorch_generative_amd as pg
+
+    g = _util.load_golden(name)
+    model = getattr(pg.models, g["ctor"])(**g["kwargs"])
+    want = {k: tuple(v.shape) for k, v in g["state0"].items() if k not in ("_c", "_h", "_w")}
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == want
+    model.load_state_dict(g["state0"], strict=True)
+
+
 def test_hip_path_has_no_cpu_fallback():
     import pytorch_generative_amd as pg
 

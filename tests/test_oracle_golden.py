@@ -53,3 +53,21 @@ def test_strict_attention_first_pixel_is_bias():
     out = oops.causal_attention(torch.randn(2, 6, 4, 4), None, p, "", 1, 4, True)
     assert torch.allclose(out[:, :, 0, 0], p["_proj.bias"].expand(2, 8), atol=1e-6)
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("name", _util.vae_golden_names())
+def test_oracle_matches_vae_golden(name):
+    g = _util.load_golden(name)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in g["state0"].items() if otrain.is_param(k)}
+    logits, kl = omodels.vd_vae(leaves, g["x"], g["eps"])
+    recon, klm, elbo = omodels.elbo_terms(logits, g["x"], kl)
+    _util.assert_close(logits, g["logits"], 1e-5, "logits")
+    _util.assert_close(kl, g["kl"], 1e-5, "kl")
+    _util.assert_close(elbo, g["loss"], 1e-5, "elbo")
+    grads = torch.autograd.grad(elbo, list(leaves.values()), allow_unused=True)
+    for k, go in zip(leaves, grads):
+        want = g["grads"][k]
+        if want is None:
+            assert go is None or float(go.abs().max()) == 0.0, k
+        else:
+            _util.assert_close(go, want, 2e-4, f"grad {k}")

@@ -114,3 +114,45 @@ def test_model_forward_loss_grads_and_adam_step(ref, name):
     assert abs(o_norm - float(norm)) <= 1e-5 * float(norm)
     for k, p in model.named_parameters():
         assert torch.allclose(state[k], p.detach(), rtol=1e-5, atol=1e-6), k
+
+
+def test_vd_vae_forward_elbo_and_grads(ref):
+    """VD-VAE (vd_vae.py) with the reference's noise replayed: vaes.sample_from_gaussian is
+    resolved by attribute lookup at call time, so it is patched to consume pre-drawn eps."""
+    from pytorch_generative.models.vae import vaes as rvaes
+    from pytorch_generative.models.vae import vd_vae as rvd
+
+    torch.manual_seed(0)
+    cfg = [rvd.StackConfig(2, 2), rvd.StackConfig(1, 2), rvd.StackConfig(1, 1)]
+    model = ref.models.VeryDeepVAE(3, 3, input_resolution=8, stack_configs=cfg, latent_channels=4,
+                                   hidden_channels=8, bottleneck_channels=4)
+    with torch.no_grad():
+        for b in model._biases:
+            b.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 8, 8, generator=g)
+    state = _ref.clone_state(model)
+    shapes = omodels.vd_vae_noise_shapes(state, 2, 8)
+    eg = torch.Generator().manual_seed(4321)
+    eps = [torch.randn(s, generator=eg) for s in shapes]
+    it = iter(eps)
+    orig = rvaes.sample_from_gaussian
+    rvaes.sample_from_gaussian = lambda mu, log_sig: mu + log_sig.exp() * next(it)
+    try:
+        logits, kl = model(x)
+    finally:
+        rvaes.sample_from_gaussian = orig
+    recon, klm, elbo = omodels.elbo_terms(logits, x, kl)
+    elbo.backward()
+    # oracle
+    leaves = {k: v.clone().requires_grad_(True) for k, v in state.items() if otrain.is_param(k)}
+    o_logits, o_kl = omodels.vd_vae(leaves, x, eps)
+    _, _, o_elbo = omodels.elbo_terms(o_logits, x, o_kl)
+    grads = torch.autograd.grad(o_elbo, list(leaves.values()), allow_unused=True)
+    assert torch.allclose(o_logits, logits.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(o_kl, kl.detach(), rtol=1e-5, atol=1e-4)
+    for (k, p), go in zip(model.named_parameters(), grads):
+        if p.grad is None:
+            assert go is None or float(go.abs().max()) == 0.0, k
+        else:
+            assert torch.allclose(go, p.grad, rtol=1e-4, atol=1e-5), k
