@@ -178,6 +178,9 @@ int pg_avgpool2_bwd(const float* dy, float* dx, int planes, int OH, int OW, void
 /* nearest-neighbour x2 upsample: x (planes, IH, IW) -> y (planes, 2*IH, 2*IW) */
 int pg_upsample2_fwd(const float* x, float* y, int planes, int IH, int IW, void* stream);
 int pg_upsample2_bwd(const float* dy, float* dx, int planes, int IH, int IW, void* stream);
+/* 2x2 phase split (space-to-depth) and its inverse: x (planes, 2H, 2W) <-> xs (4, planes, H, W),
+ * xs[2*pr+pc][plane][r][c] = x[plane][2r+pr][2c+pc]. merge==0 writes xs, merge==1 writes x. */
+int pg_phase_split2(float* x, float* xs, int planes, int H, int W, int merge, void* stream);
 /* Fused Gaussian head. q, p: (N, >=2C, L) conv outputs holding [mean | log_std] in channels
  * [0,C) / [C,2C), read in place through batch strides q_bs / p_bs (floats). eps, z: (N, C, L).
  *   mode 0: z = mu_q + exp(s_q) eps ; kl[n] += sum KL(q || N(0,1))       (vae.py:91-93)

@@ -184,6 +184,70 @@ def vd_vae_noise_shapes(p, n, input_resolution):
     return shapes
 
 
+# ------------------------------------------------------------------------- VAE / Beta-VAE
+def _residual_stack(p, pre, x):
+    """ResidualStack / ResidualBlock forward, vaes.py:92-95,118-119."""
+    for b in range(_count(p, pre + "_net.") if any(k.startswith(pre + "_net.") for k in p) else 0):
+        if f"{pre}_net.{b}._net.1.weight" not in p:
+            continue
+        h = F.conv2d(F.relu(x), p[f"{pre}_net.{b}._net.1.weight"], p[f"{pre}_net.{b}._net.1.bias"], padding=1)
+        x = x + F.conv2d(F.relu(h), p[f"{pre}_net.{b}._net.3.weight"], p[f"{pre}_net.{b}._net.3.bias"])
+    return F.relu(x)
+
+
+def _seq_indices(p, pre):
+    return sorted({int(k[len(pre):].split(".")[0]) for k in p if k.startswith(pre)})
+
+
+def _vae_encoder(p, pre, x):
+    """Encoder.forward, vaes.py:140-181: (4x4 s2 conv, ReLU)*, ResidualStack, 3x3 conv."""
+    for idx in _seq_indices(p, pre + "_net."):
+        key = f"{pre}_net.{idx}."
+        if key + "weight" in p:
+            w = p[key + "weight"]
+            if w.shape[-1] == 4:
+                x = F.relu(F.conv2d(x, w, p[key + "bias"], stride=2, padding=1))
+            else:
+                x = F.conv2d(x, w, p[key + "bias"], padding=1)
+        else:
+            x = _residual_stack(p, key, x)
+    return x
+
+
+def _vae_decoder(p, pre, x):
+    """Decoder.forward, vaes.py:208-241: 3x3 conv, ResidualStack, (4x4 s2 ConvTranspose, ReLU)* —
+    no ReLU after the last transposed convolution."""
+    idxs = _seq_indices(p, pre + "_net.")
+    tconvs = [i for i in idxs if f"{pre}_net.{i}.weight" in p and p[f"{pre}_net.{i}.weight"].shape[-1] == 4]
+    for idx in idxs:
+        key = f"{pre}_net.{idx}."
+        if key + "weight" in p:
+            w = p[key + "weight"]
+            if w.shape[-1] == 4:
+                x = F.conv_transpose2d(x, w, p[key + "bias"], stride=2, padding=1)
+                if idx != tconvs[-1]:
+                    x = F.relu(x)
+            else:
+                x = F.conv2d(x, w, p[key + "bias"], padding=1)
+        else:
+            x = _residual_stack(p, key, x)
+    return x
+
+
+def vae(p, x, eps, beta=1.0):
+    """VAE.forward (vae.py:79-94) / BetaVAE.forward (beta_vae.py:58-60): returns (logits, beta*kl)."""
+    h = x
+    for i in range(_count(p, "_encoder.")):
+        h = _vae_encoder(p, f"_encoder.{i}.", h)
+    c = h.shape[1] // 2
+    mean, log_std = h[:, :c], h[:, c:]
+    kl = ops.unit_gaussian_kl_div(mean, log_std).sum(dim=(1, 2, 3))
+    z = ops.sample_from_gaussian(mean, log_std, eps)
+    for i in range(_count(p, "_decoder.")):
+        z = _vae_decoder(p, f"_decoder.{i}.", z)
+    return z, beta * kl
+
+
 def elbo_terms(logits, x, kl):
     """loss_fn of the VAE reproduce()s, vae.py:149-159: (recon.mean(), kl.mean(), elbo.mean())."""
     recon = F.binary_cross_entropy_with_logits(logits, x, reduction="none").sum(dim=(1, 2, 3))

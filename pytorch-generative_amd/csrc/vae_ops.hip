@@ -59,6 +59,25 @@ __global__ void sum2x2_kernel(const float* __restrict__ dy, float* __restrict__ 
   }
 }
 
+// ---- 2x2 phase split / merge (space-to-depth): x (planes, 2H, 2W) <-> xs (4, planes, H, W) with
+// xs[2*pr + pc][plane][r][c] = x[plane][2r + pr][2c + pc]. Stride-2 4x4 convolutions and their
+// transposes (vaes.py:153-160, 228-235) are evaluated as four stride-1 2x2 tap convolutions on
+// the phases.
+__global__ void phase_split_kernel(float* x, float* xs, size_t total,
+                                   int H, int W, size_t phase_elems, int merge) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;  // total = planes * 2H * 2W
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c2 = (int)(i % (2 * W));
+    const size_t t = i / (2 * W);
+    const int r2 = (int)(t % (2 * H));
+    const size_t plane = t / (2 * H);
+    const size_t j = (size_t)(2 * (r2 & 1) + (c2 & 1)) * phase_elems +
+                     (plane * H + (r2 >> 1)) * (size_t)W + (c2 >> 1);
+    if (merge) x[i] = xs[j];
+    else xs[j] = x[i];
+  }
+}
+
 // ---- Gaussian heads --------------------------------------------------------------------------
 // q: (N, >=2C, L) with [mean | log_std] in channels [0,C) and [C,2C); p: same layout or NULL.
 //   p == NULL : KL(q || N(0,1)) = -0.5 (1 + 2 s - e^{2s} - mu^2)                 vaes.py:17-19
@@ -187,6 +206,16 @@ PG_EXPORT int pg_upsample2_bwd(const float* dy, float* dx, int planes, int IH, i
   const size_t total = (size_t)planes * IH * IW;
   hipLaunchKernelGGL(sum2x2_kernel, dim3(vblocks(total)), dim3(VT), 0, VST, dy, dx, total, IH, IW);
   PG_LAUNCH_CHECK("pg_upsample2_bwd");
+  return 0;
+}
+
+/* merge == 0: xs <- split(x); merge == 1: x <- merge(xs).  x: (planes, 2H, 2W), xs: (4, planes, H, W) */
+PG_EXPORT int pg_phase_split2(float* x, float* xs, int planes, int H, int W, int merge, void* stream) {
+  PG_REQUIRE(x && xs && planes > 0 && H > 0 && W > 0, PG_EINVAL, "pg_phase_split2: bad arguments");
+  const size_t total = (size_t)planes * 4 * H * W;
+  hipLaunchKernelGGL(phase_split_kernel, dim3(vblocks(total)), dim3(VT), 0, VST, x, xs, total, H, W,
+                     (size_t)planes * H * W, merge);
+  PG_LAUNCH_CHECK("pg_phase_split2");
   return 0;
 }
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "pg_avgpool2_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
     "pg_upsample2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
     "pg_upsample2_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
+    "pg_phase_split2": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_s]),
     "pg_gauss_head_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_l, c_l, c_i, c_s]),
     "pg_gauss_head_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_l, c_l, c_i, c_s]),
     "pg_vec_mean_accum": (c_i, [c_f, c_i, c_f, c_s]),

@@ -4,6 +4,7 @@ from pytorch_generative_amd.nn.attention import CausalAttention, image_positiona
 from pytorch_generative_amd.nn.convolution import (
     CausalConv2d,
     Conv2d,
+    ConvTranspose2d,
     GatedActivation,
     NCHWLayerNorm,
 )
@@ -13,6 +14,7 @@ __all__ = [
     "image_positional_encoding",
     "CausalConv2d",
     "Conv2d",
+    "ConvTranspose2d",
     "GatedActivation",
     "NCHWLayerNorm",
 ]

@@ -31,10 +31,19 @@ class Conv2d(nn.Conv2d):
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if _pair(self.stride) != (1, 1) or _pair(self.dilation) != (1, 1) or self.groups != 1:
-            raise ValueError("pytorch_generative_amd.nn.Conv2d supports stride=1, dilation=1, groups=1")
+        if _pair(self.dilation) != (1, 1) or self.groups != 1:
+            raise ValueError("pytorch_generative_amd.nn.Conv2d supports dilation=1, groups=1")
         if self.padding_mode != "zeros" or isinstance(self.padding, str):
             raise ValueError("pytorch_generative_amd.nn.Conv2d supports integer zero padding only")
+        self._down2 = False
+        if _pair(self.stride) != (1, 1):
+            # the one strided shape on the path: the VAE encoder's 4x4 / stride 2 / padding 1
+            # down-sampling convolution (reference models/vae/vaes.py:153-160)
+            if (_pair(self.stride), _pair(self.kernel_size), _pair(self.padding)) != ((2, 2), (4, 4), (1, 1)):
+                raise ValueError(
+                    "pytorch_generative_amd.nn.Conv2d supports stride 1, or stride 2 with kernel 4 and padding 1"
+                )
+            self._down2 = True
         self._spec = None
 
     def _active_taps(self):
@@ -48,10 +57,62 @@ class Conv2d(nn.Conv2d):
         return self._spec
 
     def forward(self, x, *, crop=None, in_act=None, res=None):
+        if self._down2:
+            return self._forward_down2(x, in_act, res)
         return ops.conv2d_taps(
             x, self.weight, self.bias, self._conv_spec(), out_hw=crop, in_act=_ACTS[in_act],
             res=res, weight_param=self.weight, bias_param=self.bias,
         )
+
+    def _forward_down2(self, x, in_act, res):
+        """out[a, b] = sum_{u,v} w[u, v] x[2a + u - 1, 2b + v - 1] evaluated on the four 2x2 phases
+        of x: phase 0 (even rows/cols) pairs with taps u in (1, 3) at offsets (0, +1), phase 1 with
+        u in (0, 2) at offsets (-1, 0) — four stride-1 2x2 tap convolutions chained through the
+        fused residual input."""
+        xs = ops.phase_split(x)
+        _, _, _, h, w = xs.shape
+        out = res
+        for pr in (0, 1):
+            for pc in (0, 1):
+                wsel = self.weight[:, :, (1 - pr)::2, (1 - pc)::2].contiguous()
+                spec = _PHASE_SPECS[(pr, pc)]
+                last = (pr, pc) == (1, 1)
+                out = ops.conv2d_taps(xs[2 * pr + pc], wsel, self.bias if last else None, spec,
+                                      out_hw=(h, w), in_act=_ACTS[in_act], res=out)
+        return out
+
+
+# phase p of the input contributes through a 2-tap filter at offsets (0, +1) (p = 0, padding 0)
+# or (-1, 0) (p = 1, padding 1); see Conv2d._forward_down2 / ConvTranspose2d.forward.
+_PHASE_SPECS = {
+    (pr, pc): ops.ConvSpec(2, 2, pr, pc) for pr in (0, 1) for pc in (0, 1)
+}
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    """The VAE decoder's 4x4 / stride 2 / padding 1 transposed convolution
+    (reference models/vae/vaes.py:228-235) on the HIP tap kernels:
+    out[2a + p] = sum_{u = p+1 (mod 2)} w[u] x[a + (p + 1 - u) / 2] — every output phase is a
+    stride-1 2x2 tap convolution of x; the four phases are interleaved by one merge kernel."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        ok = (_pair(self.stride), _pair(self.kernel_size), _pair(self.padding)) == ((2, 2), (4, 4), (1, 1))
+        if not ok or _pair(self.output_padding) != (0, 0) or self.groups != 1 or _pair(self.dilation) != (1, 1):
+            raise ValueError("pytorch_generative_amd.nn.ConvTranspose2d supports kernel 4, stride 2, padding 1")
+
+    def forward(self, x, *, in_act=None):
+        wt = self.weight.transpose(0, 1)  # (Cout, Cin, 4, 4)
+        phases = []
+        for pr in (0, 1):
+            rows = (3, 1) if pr == 0 else (2, 0)  # taps at offsets (-1, 0) resp. (0, +1)
+            for pc in (0, 1):
+                cols = (3, 1) if pc == 0 else (2, 0)
+                wsel = wt[:, :, rows, :][:, :, :, cols].contiguous()
+                spec = _PHASE_SPECS[(1 - pr, 1 - pc)]
+                phases.append(ops.conv2d_taps(x, wsel, self.bias, spec, out_hw=x.shape[2:],
+                                              in_act=_ACTS[in_act]))
+        return ops.phase_merge(torch.stack(phases))
 
 
 class CausalConv2d(Conv2d):

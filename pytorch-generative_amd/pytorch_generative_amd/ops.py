@@ -198,8 +198,10 @@ def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
     """y = conv(act(x)) + bias (+ res), cropped to out_hw (defaults to the full extent)."""
     if out_hw is None:
         out_hw = spec.full_out(x.shape[2], x.shape[3])
+    # outputs beyond the "full" extent read only zero padding; allow up to one kernel's worth
+    # (used by the phase-decomposed stride-2 convolutions)
     full = spec.full_out(x.shape[2], x.shape[3])
-    if out_hw[0] > full[0] or out_hw[1] > full[1] or min(out_hw) < 1:
+    if out_hw[0] > full[0] + spec.kh or out_hw[1] > full[1] + spec.kw or min(out_hw) < 1:
         raise ValueError(f"conv2d: requested output {out_hw} exceeds the full extent {full}")
     return _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act,
                            _sink(weight_param), _sink(bias_param))
@@ -670,3 +672,59 @@ class _ElboMean(torch.autograd.Function):
 def elbo_terms(logits, x, kl):
     """Returns (recon_loss.mean(), kl_div.mean()) of the reference VAE loss_fn (vae.py:149-159)."""
     return _ElboMean.apply(logits, x, kl)
+
+
+class _PhaseSplit(torch.autograd.Function):
+    """x (N, C, 2H, 2W) -> (4, N, C, H, W) with out[2*pr+pc, n, c, r, q] = x[n, c, 2r+pr, 2q+pc]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _chk(x, "phase_split.x")
+        n, c, h2, w2 = x.shape
+        if h2 % 2 or w2 % 2:
+            raise ValueError("phase_split: H and W must be even")
+        xs = torch.empty((4, n, c, h2 // 2, w2 // 2), device=x.device, dtype=torch.float32)
+        _lib.check(lib.pg_phase_split2(x.data_ptr(), xs.data_ptr(), n * c, h2 // 2, w2 // 2, 0, _stream()),
+                   "pg_phase_split2")
+        return xs
+
+    @staticmethod
+    def backward(ctx, dxs):
+        lib = _lib.load()
+        dxs = _chk(dxs, "phase_split.dxs")
+        _, n, c, h, w = dxs.shape
+        dx = torch.empty((n, c, 2 * h, 2 * w), device=dxs.device, dtype=torch.float32)
+        _lib.check(lib.pg_phase_split2(dx.data_ptr(), dxs.data_ptr(), n * c, h, w, 1, _stream()),
+                   "pg_phase_split2")
+        return dx
+
+
+class _PhaseMerge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xs):
+        lib = _lib.load()
+        xs = _chk(xs, "phase_merge.xs")
+        _, n, c, h, w = xs.shape
+        x = torch.empty((n, c, 2 * h, 2 * w), device=xs.device, dtype=torch.float32)
+        _lib.check(lib.pg_phase_split2(x.data_ptr(), xs.data_ptr(), n * c, h, w, 1, _stream()),
+                   "pg_phase_split2")
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        lib = _lib.load()
+        dx = _chk(dx, "phase_merge.dx")
+        n, c, h2, w2 = dx.shape
+        dxs = torch.empty((4, n, c, h2 // 2, w2 // 2), device=dx.device, dtype=torch.float32)
+        _lib.check(lib.pg_phase_split2(dx.data_ptr(), dxs.data_ptr(), n * c, h2 // 2, w2 // 2, 0, _stream()),
+                   "pg_phase_split2")
+        return dxs
+
+
+def phase_split(x):
+    return _PhaseSplit.apply(x)
+
+
+def phase_merge(xs):
+    return _PhaseMerge.apply(xs)

@@ -129,6 +129,44 @@ def make_vd_vae():
     print(f"vd_vae_small: elbo={float(loss):.6f} kl={float(kl.mean()):.6f} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def make_beta_vae():
+    """Beta-VAE fixture (stride-2 4x4 convs + transposed convs, unit-Gaussian KL), noise replayed."""
+    ref = _ref.load()
+    from pytorch_generative.models.vae import vaes as rvaes
+    import torch.nn.functional as F
+
+    torch.manual_seed(0)
+    kwargs = dict(in_channels=3, out_channels=3, beta=4.0, latent_channels=8, strides=[2, 4],
+                  hidden_channels=16, residual_channels=8)
+    model = ref.models.BetaVAE(**kwargs)
+    x = make_input((2, 3, 32, 32), "cifar")
+    state0 = _ref.clone_state(model)
+    eps = torch.randn(2, 8, 4, 4, generator=torch.Generator().manual_seed(4321))
+    orig = rvaes.sample_from_gaussian
+    rvaes.sample_from_gaussian = lambda mu, log_sig: mu + log_sig.exp() * eps
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    try:
+        opt.zero_grad()
+        logits, kl = model(x)
+    finally:
+        rvaes.sample_from_gaussian = orig
+    recon = F.binary_cross_entropy_with_logits(logits, x, reduction="none").sum(dim=(1, 2, 3))
+    loss = (recon + kl).mean()
+    loss.backward()
+    norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1e50)
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    opt.step()
+    out = {"ctor": "BetaVAE", "kwargs": kwargs, "lr": 1e-3, "x": x, "eps": [eps], "state0": state0,
+           "logits": logits.detach().clone(), "kl": kl.detach().clone(),
+           "recon_mean": recon.mean().detach().clone(), "kl_mean": kl.mean().detach().clone(),
+           "loss": loss.detach().clone(), "grads": grads, "grad_norm": norm.detach().clone(),
+           "state1": _ref.clone_state(model), "torch_version": torch.__version__}
+    path = os.path.join(HERE, "vae_beta_vae_small.pt")
+    torch.save(out, path)
+    print(f"beta_vae_small: elbo={float(loss):.6f} kl={float(kl.mean()):.6f} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     main()
     make_vd_vae()
+    make_beta_vae()

@@ -209,8 +209,8 @@ def test_graphed_step_equals_eager_step(dev):
 
 
 @pytest.mark.parametrize("name", _util.vae_golden_names())
-def test_vd_vae_golden_step(dev, name):
-    """VD-VAE (BASELINE.json configs[4]) against the reference's golden step: logits, per-sample
+def test_vae_golden_step(dev, name):
+    """Beta-VAE / VD-VAE (BASELINE.json configs[4]) against the reference's golden step: logits, per-sample
     KL, ELBO terms, every parameter gradient, grad norm and the parameters after one Adam step,
     with the reference's noise replayed through the model's noise hook."""
     import pytorch_generative_amd as pg

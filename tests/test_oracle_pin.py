@@ -156,3 +156,31 @@ def test_vd_vae_forward_elbo_and_grads(ref):
             assert go is None or float(go.abs().max()) == 0.0, k
         else:
             assert torch.allclose(go, p.grad, rtol=1e-4, atol=1e-5), k
+
+
+def test_beta_vae_forward_elbo_and_grads(ref):
+    from pytorch_generative.models.vae import vaes as rvaes
+
+    torch.manual_seed(0)
+    model = ref.models.BetaVAE(3, 3, beta=4.0, latent_channels=4, strides=[2, 4], hidden_channels=8,
+                               residual_channels=4)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 16, 16, generator=g)
+    state = _ref.clone_state(model)
+    eps = torch.randn(2, 4, 2, 2, generator=torch.Generator().manual_seed(4321))
+    orig = rvaes.sample_from_gaussian
+    rvaes.sample_from_gaussian = lambda mu, log_sig: mu + log_sig.exp() * eps
+    try:
+        logits, kl = model(x)
+    finally:
+        rvaes.sample_from_gaussian = orig
+    _, _, elbo = omodels.elbo_terms(logits, x, kl)
+    elbo.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in state.items() if otrain.is_param(k)}
+    o_logits, o_kl = omodels.vae(leaves, x, eps, beta=4.0)
+    _, _, o_elbo = omodels.elbo_terms(o_logits, x, o_kl)
+    grads = torch.autograd.grad(o_elbo, list(leaves.values()), allow_unused=True)
+    assert torch.allclose(o_logits, logits.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(o_kl, kl.detach(), rtol=1e-5, atol=1e-4)
+    for (k, p), go in zip(model.named_parameters(), grads):
+        assert torch.allclose(go, p.grad, rtol=1e-4, atol=1e-5), k
