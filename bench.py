@@ -42,6 +42,14 @@ OTHER_MODELS = {
     "pixel_cnn": ("PixelCNN", dict(in_channels=1, out_channels=1, n_residual=15,
                                    residual_channels=32, head_channels=32),
                   (1, 28, 28), 1e-3, 0.999977, 0.964e9, 31.6e6),
+    # BASELINE.json configs[4]: VAE conv stacks + KL on 64x64x3 (ELBO loss, vae.py:149-159)
+    "beta_vae": ("BetaVAE", dict(in_channels=3, out_channels=3, beta=4.0, latent_channels=16,
+                                 strides=[2, 2, 2, 2], hidden_channels=64, residual_channels=32),
+                 (3, 64, 64), 1e-3, 1.0, 1.57e9, 17.6e6),
+    "vd_vae": ("VeryDeepVAE", dict(in_channels=3, out_channels=3, input_resolution=64,
+                                   stack_configs=[(3, 5), (3, 5), (2, 4), (2, 3), (2, 2), (1, 1)],
+                                   latent_channels=16, hidden_channels=64, bottleneck_channels=32),
+               (3, 64, 64), 5e-4, 1.0, 10.96e9, 354e6),
 }
 HEADS, DK, DV, L = 4, 4, 4, 784
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix == vector peak (no TF32 on gfx950)
@@ -202,7 +210,12 @@ def main():
         reducer = parallel.FlatGradAllReduce(opt)
         reducer.broadcast_parameters(src=0)
     x = synthetic_batch(args.batch, rank, chw).to(device)
-    loss_fn = lambda xx, preds: ops.bce_with_logits_sum_mean(preds, xx)  # noqa: E731
+    if args.model in ("beta_vae", "vd_vae"):
+        def loss_fn(xx, preds):  # ELBO: recon.mean() + kl.mean()
+            recon, klm = ops.elbo_terms(preds[0], xx, preds[1])
+            return recon + klm
+    else:
+        loss_fn = lambda xx, preds: ops.bce_with_logits_sum_mean(preds, xx)  # noqa: E731
 
     def eager_step():
         opt.zero_grad()

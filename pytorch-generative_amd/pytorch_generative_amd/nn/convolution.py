@@ -105,10 +105,10 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         wt = self.weight.transpose(0, 1)  # (Cout, Cin, 4, 4)
         phases = []
         for pr in (0, 1):
-            rows = (3, 1) if pr == 0 else (2, 0)  # taps at offsets (-1, 0) resp. (0, +1)
+            # output phase 0 uses kernel rows (3, 1) at offsets (-1, 0), phase 1 rows (2, 0) at
+            # (0, +1): strided slices + flip (no index tensors: hipGraph-capturable)
             for pc in (0, 1):
-                cols = (3, 1) if pc == 0 else (2, 0)
-                wsel = wt[:, :, rows, :][:, :, :, cols].contiguous()
+                wsel = wt[:, :, (1 - pr)::2, (1 - pc)::2].flip(2, 3).contiguous()
                 spec = _PHASE_SPECS[(1 - pr, 1 - pc)]
                 phases.append(ops.conv2d_taps(x, wsel, self.bias, spec, out_hw=x.shape[2:],
                                               in_act=_ACTS[in_act]))
