@@ -36,6 +36,7 @@ struct TapArgs {
   int swp_shift, rpi;  // staging: lanes per tile row = 1 << swp_shift, rows per wave iteration
   int stage_vec, qshift;  // float4 staging (IW % 4 == 0, aligned): lanes per row = 1 << qshift
   int pix_threads, CT;    // threads per cout-tile group, cout tiles per block
+  int w_off;              // float offset of the staged-weight area inside LDS
   float inv_tile_h;
   int vec;  // OW%4==0 and 16B-aligned out/res: float4 epilogue
   int tapoff[PG_MAX_TAPS];
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(512) conv_taps_kernel(const TapArgs a) {
   if (a.stage_vec) {  // vec4 staging only writes in-range elements: zero the tile once
     for (int i = tid_all; i < a.CIB * a.ch_stride; i += blockDim.x) lds[i] = 0.f;
   }
+  float* wl = lds + a.w_off;  // staged weights (16-byte aligned)
 
   for (int ci0 = 0; ci0 < a.Cin; ci0 += a.CIB) {
     const int cib = min(a.CIB, a.Cin - ci0);
@@ -84,22 +86,44 @@ __global__ void __launch_bounds__(512) conv_taps_kernel(const TapArgs a) {
       pg_stage_rows<ACT>(lds, a.CIB * a.ch_stride, a.ch_stride, a.tile_h, a.tile_w, a.inv_tile_h,
                          in_n + (size_t)ci0 * a.IH * a.IW, (size_t)a.IH * a.IW, a.IH, a.IW, cib,
                          row0 + a.min_dr, a.min_dc, a.swp_shift, a.rpi, wave, nwaves, lane);
+    // this chunk's weights for the block's CT cout tiles: [ci][tap][CT][16] next to the x tile.
+    // (They used to be read through the scalar cache inside the loop: with Cin*T*16 floats per
+    // cout tile the working set thrashes the 16 KB scalar cache and every (ci, tap) step waited
+    // ~0.5 us for L2 — measured 4x off the FMA bound. LDS broadcast reads have ~100-cycle latency.)
+    {
+      const int per_ci = a.T * a.CT * COB;
+      const float* wsrc = a.wpk + (size_t)ci0 * a.T * a.b_pad;
+      for (int i = tid_all; i < cib * per_ci; i += blockDim.x) {
+        const int ci = i / per_ci;
+        const int rem = i - ci * per_ci;
+        const int t = rem / (a.CT * COB);
+        const int gj = rem - t * (a.CT * COB);  // g*16 + j
+        int co = blockIdx.y * a.CT * COB + gj;
+        co = co < a.b_pad ? co : a.b_pad - 1;   // idle group of an odd tile count: any valid column
+        wl[i] = wsrc[((size_t)ci * a.T + t) * a.b_pad + co];
+      }
+    }
     __syncthreads();
     for (int ci = 0; ci < cib; ++ci) {
       const float* xl = lds + ci * a.ch_stride + lane_base;
-      const float* wrow = a.wpk + ((size_t)(ci0 + ci) * a.T) * a.b_pad + co0c;
+      const float4* wrow = reinterpret_cast<const float4*>(wl + (ci * a.T * a.CT + grp) * COB);
 #pragma unroll 4
       for (int t = 0; t < a.T; ++t) {
-        const float* wp = wrow + (size_t)t * a.b_pad;  // wave-uniform -> scalar loads
+        const float4* wp = wrow + t * a.CT * (COB / 4);  // group-uniform address: LDS broadcast
         const int off = a.tapoff[t];
         const float x0 = xl[off], x1 = xl[off + 1], x2 = xl[off + 2], x3 = xl[off + 3];
 #pragma unroll
-        for (int j = 0; j < COB; ++j) {
-          const float w = wp[j];
-          acc[0][j] = fmaf(w, x0, acc[0][j]);
-          acc[1][j] = fmaf(w, x1, acc[1][j]);
-          acc[2][j] = fmaf(w, x2, acc[2][j]);
-          acc[3][j] = fmaf(w, x3, acc[3][j]);
+        for (int j4 = 0; j4 < COB / 4; ++j4) {
+          const float4 w4 = wp[j4];
+          const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * j4 + jj;
+            acc[0][j] = fmaf(wv[jj], x0, acc[0][j]);
+            acc[1][j] = fmaf(wv[jj], x1, acc[1][j]);
+            acc[2][j] = fmaf(wv[jj], x2, acc[2][j]);
+            acc[3][j] = fmaf(wv[jj], x3, acc[3][j]);
+          }
         }
       }
     }
@@ -398,7 +422,8 @@ PG_EXPORT int pg_conv2d_taps(const float* in, const float* wpk, const float* bia
   const int ytiles = b_pad / COB;
   dim3 grid((unsigned)(N * a.tiles_per_img), (unsigned)((ytiles + a.CT - 1) / a.CT));
   threads *= a.CT;
-  const size_t shmem = ((size_t)CIB * a.ch_stride + 4) * sizeof(float);  // + dump word
+  a.w_off = ((CIB * a.ch_stride + 4 + 3) / 4) * 4;  // x tile + dump word, rounded to 16 bytes
+  const size_t shmem = ((size_t)a.w_off + (size_t)CIB * T * a.CT * COB) * sizeof(float);
   switch (in_act) {
     case PG_ACT_RELU: hipLaunchKernelGGL(conv_taps_kernel<PG_ACT_RELU>, grid, dim3(threads), shmem, st, a); break;
     case PG_ACT_ELU:  hipLaunchKernelGGL(conv_taps_kernel<PG_ACT_ELU>, grid, dim3(threads), shmem, st, a); break;
