@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WG_THREADS = 256;
 constexpr int CO_CHUNK = 64;  // dy channels staged per block
 constexpr int CI_CHUNK = 32;  // x channels staged per block (2 MFMA column tiles)
-constexpr int LDS_BUDGET_FLOATS = 36000;  // ~144 KB: one workgroup per CU, big tiles (staging is latency bound)
+constexpr int LDS_BUDGET_FLOATS = 18000;  // ~72 KB -> two workgroups per CU: one stages while the other runs MFMAs (measured best of 36k/18k/9.5k)
 
 struct WgArgs {
   const float* x; const float* dy; float* dw; float* db;
