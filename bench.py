@@ -165,7 +165,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=1024,
+                    help="per-GPU batch (weak scaling); 1024 = the saturating batch SURVEY.md §8(d) names for 28x28 models")
     ap.add_argument("--model", default="image_gpt", choices=["image_gpt", *OTHER_MODELS])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
