@@ -65,7 +65,7 @@ def synthetic_batch(batch, rank, chw=(1, 28, 28)):
 def attention_kernel_roofline(batch, device, iters=10):
     """Times the three causal-attention kernels live with HIP events on the stream they are
     launched on, through the C-ABI, at the bench's exact shapes and on random data. The dominant
-    kernel of the step is attn_bwd_dkv_kernel<4,4> (pg_causal_attn_bwd_dkv).
+    kernel of the step is attn_dkv_m44_kernel (pg_causal_attn_bwd_dkv; matrix-core path, d_k = d_v = 4).
     Algorithmic FLOPs (DESIGN.md §4): pairs = N*heads*L*(L+1)/2 allowed (query, key) pairs;
       fwd   2*dk + 2*dv          (QK^T, PV)
       dQ    2*dk + 2*dv + 2*dk   (QK^T recompute, dP = dO V^T, dQ = dS K)
@@ -306,7 +306,7 @@ def main():
             out["roofline"] = {
                 "bound": "mfma",  # fp32: matrix peak == vector peak == 157.3 TF on gfx950; this
                                   # kernel is fp32 VALU/exp bound
-                "kernel": "attn_bwd_dkv_kernel<4,4> (pg_causal_attn_bwd_dkv)",
+                "kernel": "attn_dkv_m44_kernel (pg_causal_attn_bwd_dkv)",
                 "achieved": r["dkv"]["tflops"],
                 "peak": FP32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -315,8 +315,8 @@ def main():
                 "launch_ms": r["dkv"]["launch_ms"],
                 "flop_per_launch": r["dkv"]["flop_per_launch"],
                 "other_kernels": {
-                    "attn_fwd_kernel<4,4>": r["fwd"],
-                    "attn_bwd_dq_kernel<4,4>": r["dq"],
+                    "attn_fwd_m44_kernel": r["fwd"],
+                    "attn_dq_m44_kernel": r["dq"],
                 },
                 # whole step against SURVEY.md §8(d)'s per-image algorithmic work (1.223 GF, 26.2 MB)
                 "step_tflops": value * 1.223e9 / 1e12,

@@ -23,7 +23,7 @@
 //  * exp via v_exp_f32 in the log2 domain (scale*log2(e) folded into q resp. k).
 #include <stdlib.h>
 
-#include "common.h"
+#include "attention_args.h"
 
 namespace {
 
@@ -31,18 +31,7 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr float POS_BIG = 1.0e30f;
 constexpr int QPL = 2;  // rows owned per lane
 
-struct AttnArgs {
-  const float* q; const float* k; const float* v; const float* o; const float* d_o;
-  const float* lse2_in;
-  float* o_out; float* lse2_out; float* delta; float* dq; float* dk; float* dv;
-  int N, heads, L, dk_dim, dv_dim, strict;
-  long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;
-  float scale, scale2;  // 1/sqrt(dk), log2(e)/sqrt(dk)
-  int blocks_per_wg;    // 64-row blocks per workgroup (<= 16); waves = ceil(blocks_per_wg / 2)
-  int kt, kt2;          // rows per LDS tile (fwd/dQ resp. dK/dV), multiples of 64, sized so that a
-                        // whole (n, head) fits when LDS allows: barriers between tiles would
-                        // re-serialise the balanced pairing
-};
+using AttnArgs = PgAttnArgs;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -500,7 +489,7 @@ __global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(const AttnArgs a) {
   }
 }
 
-enum { K_FWD = 0, K_DQ = 1, K_DKV = 2 };
+enum { K_FWD = PG_ATTN_FWD, K_DQ = PG_ATTN_DQ, K_DKV = PG_ATTN_DKV };
 
 template <int DK, int DV>
 void launch_one(int which, const AttnArgs& a, dim3 grid, dim3 block, hipStream_t st) {
@@ -557,21 +546,20 @@ int check_dims(const char* who, int N, int heads, int L, int dk, int dv, int str
 
 }  // namespace
 
-// attention_mfma.hip: matrix-core variant for d_k = 4 (returns 1 = handled, 0 = not covered)
-int pg_attn_fwd_mfma_try(const float* q, const float* k, const float* v, float* o, float* lse2, int N,
-                         int heads, int L, int dk, int dv, long q_bs, long k_bs, long v_bs, long o_bs,
-                         int strict, hipStream_t st);
-
+// d_k = d_v = 4 (ImageGPT) runs on the matrix cores (attention_mfma.hip); PG_ATTN_MFMA=0 forces the
+// VALU row-owner kernels above (A/B measurements, tests of both paths).
 static bool use_mfma_attention() {
   static const bool on = []() {
-    // Opt-in (PG_ATTN_MFMA=1). Measured on MI355X (ImageGPT shape, B=512): the matrix-core
-    // forward runs 0.39 ms vs 0.34 ms for the VALU row-owner kernel — with d_v = 4 the MFMA only
-    // replaces 4 of ~12 VALU instructions per pair and pays for it with per-tile masks, the
-    // wave-uniform rescale test and 118 VGPRs (4 waves/SIMD). Kept for d_v >= 16 follow-up work.
     const char* e = getenv("PG_ATTN_MFMA");
-    return e && e[0] == '1';
+    return !(e && e[0] == '0');
   }();
   return on;
+}
+
+// launch `which` on whichever kernel family covers the shape
+static int launch_any(int which, AttnArgs& a, hipStream_t st) {
+  if (use_mfma_attention() && pg_attn_mfma_launch(which, a, st) == 1) return 0;
+  return launch_attn(which, a, st);
 }
 
 PG_EXPORT int pg_causal_attn_fwd(const float* q, const float* k, const float* v, float* o,
@@ -580,19 +568,13 @@ PG_EXPORT int pg_causal_attn_fwd(const float* q, const float* k, const float* v,
   PG_REQUIRE(q && k && v && o && lse2, PG_EINVAL, "pg_causal_attn_fwd: null pointer");
   int rc = check_dims("pg_causal_attn_fwd", N, heads, L, dk, dv, strict);
   if (rc) return rc;
-  if (use_mfma_attention()) {
-    rc = pg_attn_fwd_mfma_try(q, k, v, o, lse2, N, heads, L, dk, dv, q_bs, k_bs, v_bs, o_bs, strict,
-                              (hipStream_t)stream);
-    if (rc == 1) return 0;
-    if (rc < 0) return -rc - 1000;
-  }
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.o_out = o; a.lse2_out = lse2;
   a.N = N; a.heads = heads; a.L = L; a.dk_dim = dk; a.dv_dim = dv; a.strict = strict;
   a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
   a.scale = 1.f / sqrtf((float)dk);
   a.scale2 = a.scale * 1.44269504088896340736f;
-  rc = launch_attn(K_FWD, a, (hipStream_t)stream);
+  rc = launch_any(K_FWD, a, (hipStream_t)stream);
   PG_REQUIRE(rc == 0, rc, "pg_causal_attn_fwd: unsupported head dims");
   PG_LAUNCH_CHECK("pg_causal_attn_fwd");
   return 0;
@@ -616,12 +598,12 @@ int attn_bwd_impl(int which_mask, const float* q, const float* k, const float* v
   a.scale = 1.f / sqrtf((float)dk_dim);
   a.scale2 = a.scale * 1.44269504088896340736f;
   if (which_mask & 1) {
-    rc = launch_attn(K_DQ, a, (hipStream_t)stream);
+    rc = launch_any(K_DQ, a, (hipStream_t)stream);
     PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: unsupported head dims");
     PG_LAUNCH_CHECK("pg_causal_attn_bwd(dq)");
   }
   if (which_mask & 2) {
-    rc = launch_attn(K_DKV, a, (hipStream_t)stream);
+    rc = launch_any(K_DKV, a, (hipStream_t)stream);
     PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: unsupported head dims");
     PG_LAUNCH_CHECK("pg_causal_attn_bwd(dkv)");
   }

@@ -140,6 +140,10 @@ ATTN_CASES = [
     (2, 3, 8, 16, 9, 7, True),     # odd everything
     (1, 2, 48, 40, 8, 8, False),   # padded head dims (64-template)
     (1, 1, 4, 4, 18, 18, True),    # L = 324: more than one 256-query block
+    (3, 2, 4, 4, 28, 28, True),    # matrix-core path (d_k = d_v = 4), strict mask
+    (1, 3, 4, 4, 7, 9, False),     # matrix-core path, L = 63: scalar staging, ragged last group
+    (1, 1, 4, 4, 32, 32, False),   # matrix-core path, L = 1024: 16 blocks = 8 waves
+    (1, 2, 4, 4, 36, 36, True),    # matrix-core path, L = 1296: two workgroups per (n, head)
 ]
 
 

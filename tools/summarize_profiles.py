@@ -36,7 +36,7 @@ for k in fetch:
         "hbm_read_bytes": fetch[k] * 1024 * read_factor,
         "hbm_write_bytes": (write.get(k) or 0.0) * 1024 * write_factor,
     }
-dkv = [k for k in table if "attn_bwd_dkv_kernel" in k][0]
+dkv = [k for k in table if ("attn_dkv_m44_kernel" in k or "attn_bwd_dkv_kernel" in k)][0]
 out = {
     "per_gpu_batch": batch,
     "calibration": {"kernel": add, "read_factor": read_factor, "write_factor": write_factor},
