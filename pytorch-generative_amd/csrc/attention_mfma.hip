@@ -1,35 +1,38 @@
 // attention_mfma.hip — matrix-core causal attention (forward, dQ, dK/dV) for d_k = d_v = 4, gfx950.
 //
-// ImageGPT (16 embed / 4 heads, BASELINE.json configs[1]) has d_k = d_v = 4: exactly the
-// contraction depth of v_mfma_f32_16x16x4_f32 and exactly the tile edge of v_mfma_f32_4x4x1_16b_f32.
-// Both are fp32 in / fp32 accumulate — no precision is given up. Measured on MI355X
+// ImageGPT (16 embed / 4 heads, BASELINE.json configs[1]) has d_k = d_v = 4: the contraction depth of
+// v_mfma_f32_16x16x4_f32 and the tile edge of v_mfma_f32_4x4x1_16b_f32. Measured on MI355X
 // (tools/exp/ubench.hip): an fp32 MFMA and VALU work do NOT overlap on a SIMD
 // (SQ_VALU_MFMA_COEXEC_CYCLES = 0; MFMA + VALU streams cost the sum of their parts), so the matrix
-// pipe buys cheaper multiply-adds, not a second pipe: a 16x16x4 tile costs 33 cycles for 4 scores
+// pipe buys cheaper multiply-adds, not a second pipe: a 16x16x4 fp32 tile costs 33 cycles for 4 scores
 // per lane (16 v_fma = 58), a 4x4x1 costs 10.5 for 4 output FMAs per lane (14.4), v_exp_f32 10-12.
+// A bf16 16x16x32 MFMA costs 17.7 cycles AND runs under other waves' v_exp: the score products of
+// the forward and dQ kernels therefore go through it as exact three-way bf16 splits ("bf16x3",
+// below) — fp32-level accuracy, no precision is given up anywhere on this path.
 //
 // One 16 keys x 16 queries tile, forward:
-//   S^T = K Q^T            v_mfma_f32_16x16x4_f32   A[i][k] = K^T[k][key0+i]   (ds_read_b32)
-//                                                   B[k][j] = q[query0+j][k]   (VGPR, held)
-//                                                   C       = -m (running max, splat) -> D = s - m
+//   S^T - m = K Q^T - m    one 16x16 MFMA: A = keys streamed from LDS, B = queries held in VGPRs,
+//                          the running max m (per query) folded into the contraction
 //     D layout: lane (j = lane&15, g = lane>>4), VGPR r  <->  key 4g+r, query j
-//   P = exp2(S^T)          4 x v_exp_f32 per lane
+//   P = exp2(S^T - m)      4 x v_exp_f32 per lane
 //   O += P^T V             4 x v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products):
 //     block b = lane>>2 = (g, query quad qb); step r: A_b[i'] = P[key 4g+r][query 4qb+i'] — VGPR r
 //     of the S^T tile AS IT IS, no cross-lane movement; B_b[j'] = V[key 4g+r][j'] — component r of
 //     one ds_read_b128 from the V^T plane; D_b[i'][j'] = O partial [query 4qb+i'][channel j'].
 //   No lane is padding in either instruction. The four key subsets g of a query keep lane-local
-//   running max / sum / output and are merged once per 64-query block.
-// The running max is folded into the C operand (s - m costs nothing) and updated LAZILY: the first
-// tile sets every lane's m to its exact maximum; afterwards m moves only when a tile's probability
-// sum shows that some score ran more than ~2^8 above it (one wave-uniform test per 4 groups).
-// dQ and dK/dV use the same two instructions: S and dP^T = V dO^T (C = -lse2 resp. -delta, so
-// exp2(D) = P and D = dP - delta come straight out of the matrix pipe), then dQ += dS K, or
-// dV += P^T dO and dK += dS^T Q as 4x4x1 outer-product accumulations.
+//   sums / outputs (same m) and are added once per 64-query block.
+// m is updated LAZILY: the first tile sets every query's m to its exact maximum; afterwards m moves
+// only when a tile's probability sum shows that some score ran more than ~2^8 above it (one
+// wave-uniform test per 4 groups).
+// dQ and dK/dV have the same shape: S and dP^T = V dO^T with -lse2 resp. -delta folded in, so
+// exp2(D) = P and D = dP - delta come straight out of the matrix pipe, then dQ += dS K, or
+// dV += P^T dO and dK += dS^T Q as 4x4x1 outer-product accumulations. (dK/dV still uses the fp32
+// 16x16x4 tile with the constants in the C operand: its streamed side would need 96 B of chunks per
+// query and no longer fit two workgroups per CU.)
 // A wave works on a 64-row block = four 16-row groups at a time (one K/V fragment feeds four
 // independent MFMA/exp chains); blocks are handed out in balanced pairs exactly as in attention.hip.
-// Measured (N=1024, 4 heads, L=784): fwd 0.45 ms, dQ 0.56 ms, dK/dV 0.62 ms vs 0.62 / 0.65 / 0.69 ms
-// for the VALU row-owner kernels.
+// Measured (N=1024, 4 heads, L=784): fwd 0.40 ms, dQ 0.47 ms, dK/dV 0.59 ms vs 0.62 / 0.65 / 0.69 ms
+// for the VALU row-owner kernels; ~0.14 ms of each is staging, per-block set-up and the diagonal.
 #include <type_traits>
 
 #include "attention_args.h"
@@ -41,18 +44,12 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr float POS_BIG = 1.0e30f;
 constexpr float PSUM_TH = 1024.0f;  // a 4-key probability sum above this (some p > 2^8) triggers a rescale
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+#define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
 #define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_4x4x1f32((A), (B), (C), 0, 0, 0)
 
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// A 4-VGPR splat the compiler must keep materialised (it is the C operand of every score MFMA;
-// rebuilding it with 4 v_mov per MFMA would cost as much VALU as the subtraction it replaces).
-__device__ __forceinline__ f32x4 splat_opaque(float x) {
-  f32x4 v = {x, x, x, x};
-  asm volatile("" : "+v"(v));
-  return v;
-}
 
 // out[i] = value of lane 4*(lane/4) + i, the i-th lane of this lane's 4x4x1 block (DPP quad_perm)
 __device__ __forceinline__ void quad_all(float x, float (&out)[4]) {
@@ -68,6 +65,99 @@ __device__ __forceinline__ float gsum(float x) {
   x += __shfl_xor(x, 16, 64);
   x += __shfl_xor(x, 32, 64);
   return x;
+}
+
+// ---- fp32 products on the bf16 matrix pipe ("bf16x3") --------------------------------------------
+// x = h + m + l with h, m, l bf16 (8 + 8 + 8 significand bits: |x - h - m - l| <= 2^-24 |x|).
+// A 4-deep fp32 dot product x.y + c then is one v_mfma_f32_16x16x32_bf16 (K = 32 = 8 slots of 4):
+//   lane group kg = lane>>4 | streamed operand (LDS chunk) | resident operand (VGPRs)
+//        0                  | [ yh | ym ]                  | [ xh | xh ]      yh.xh + ym.xh
+//        1                  | [ yh | ym ]  (same chunk)    | [ xm | xm ]      yh.xm + ym.xm
+//        2                  | [ yl | yh ]                  | [ xh | xl ]      yl.xh + yh.xl
+//        3                  | [ 1 1 1 0 | 0 ]  (constant)  | [ ch cm cl 0 | 0 ]   c = ch + cm + cl
+// Every bf16 x bf16 product is exact in the fp32 accumulator; the dropped terms (ym.xl, yl.xm,
+// yl.xl) are <= 3 * 2^-24 |x||y| — fp32 rounding level. The per-column constant c (minus the running
+// max, minus lse2, minus delta) rides in the contraction, so no C operand registers are needed.
+// Measured (tools/exp/ubench.hip): 17.7 cycles per instruction vs 33 for v_mfma_f32_16x16x4_f32,
+// and unlike the fp32 MFMA it overlaps with v_exp_f32 issued by other waves of the SIMD.
+struct Split3 { __bf16 h, m, l; };
+__device__ __forceinline__ Split3 split3(float x) {
+  Split3 s;
+  s.h = (__bf16)x;
+  const float r1 = x - (float)s.h;
+  s.m = (__bf16)r1;
+  s.l = (__bf16)(r1 - (float)s.m);
+  return s;
+}
+
+// resident operand of one row x[0..3] (+ the row's additive constant c) for this lane's group kg
+__device__ __forceinline__ bf16x8 resident_operand(const float (&x)[4], float c, int kg) {
+  bf16x8 v;
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    const Split3 s = split3(x[dd]);
+    v[dd] = kg == 1 ? s.m : s.h;
+    v[4 + dd] = kg == 0 ? s.h : (kg == 1 ? s.m : s.l);
+  }
+  const Split3 cc = split3(c);
+  if (kg == 3) {
+    v[0] = cc.h; v[1] = cc.m; v[2] = cc.l; v[3] = (__bf16)0.f;
+    v[4] = v[5] = v[6] = v[7] = (__bf16)0.f;
+  }
+  return v;
+}
+
+// replace the additive constant of a resident operand (lanes of group 3 only; branch-free: the
+// operand is rewritten in place as two selected dwords)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned int pack_bf16(__bf16 lo, __bf16 hi) {
+  return (unsigned int)__builtin_bit_cast(unsigned short, lo) |
+         ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+__device__ __forceinline__ void set_constant(bf16x8& v, float c, int kg) {
+  const Split3 cc = split3(c);
+  u32x4 w = __builtin_bit_cast(u32x4, v);
+  w[0] = kg == 3 ? pack_bf16(cc.h, cc.m) : w[0];
+  w[1] = kg == 3 ? pack_bf16(cc.l, (__bf16)0.f) : w[1];
+  v = __builtin_bit_cast(bf16x8, w);
+}
+
+// streamed chunks of one row y[0..3]: c0[row] = [yh | ym], c2[row] = [yl | yh] (8 bf16 = 16 bytes each)
+__device__ __forceinline__ void put_chunks(bf16x8* __restrict__ c0, bf16x8* __restrict__ c2, int row,
+                                           const float (&y)[4]) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    const Split3 s = split3(y[dd]);
+    a[dd] = s.h; a[4 + dd] = s.m;
+    b[dd] = s.l; b[4 + dd] = s.h;
+  }
+  c0[row] = a;
+  c2[row] = b;
+}
+
+// 4 channel values of row m (0 beyond L); the load itself is unconditional (clamped address), so the
+// loads of a whole staging pass are in flight together
+__device__ __forceinline__ void load_row4(float (&x)[4], const float* __restrict__ src, int L, int m) {
+  const int mc = m < L ? m : L - 1;
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) x[dd] = src[(size_t)dd * L + mc];
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) x[dd] = m < L ? x[dd] : 0.f;
+}
+
+// the constant chunk [1 1 1 0 | 0 0 0 0] read by lane group 3
+__device__ __forceinline__ bf16x8 ones_chunk() {
+  bf16x8 v;
+  v[0] = v[1] = v[2] = (__bf16)1.f;
+  v[3] = v[4] = v[5] = v[6] = v[7] = (__bf16)0.f;
+  return v;
+}
+
+// max over the four key subsets g = lane>>4
+__device__ __forceinline__ float gmax(float x) {
+  x = fmaxf(x, __shfl_xor(x, 16, 64));
+  return fmaxf(x, __shfl_xor(x, 32, 64));
 }
 
 // Copy rows [r0, r1) (multiples of 16) of `nch` channel planes (global plane stride L) into LDS
@@ -127,11 +217,14 @@ __device__ __forceinline__ Ids ids() {
 }
 
 // ------------------------------------------------------------------------------ forward
+// LDS per workgroup: K chunks c0/c2 [Lp] x 16 B, V^T planes [4][Lp] fp32, the ones chunk.
 __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
   extern __shared__ float4 lds4[];
   const int Lp = a.lp;
-  float* kt = reinterpret_cast<float*>(lds4);  // K^T [4][Lp]
-  float* vt = kt + 4 * Lp;                     // V^T [4][Lp]
+  bf16x8* kc0 = reinterpret_cast<bf16x8*>(lds4);
+  bf16x8* kc2 = kc0 + Lp;
+  float* vt = reinterpret_cast<float*>(kc2 + Lp);  // V^T [4][Lp]
+  bf16x8* ones = reinterpret_cast<bf16x8*>(vt + 4 * Lp);
   const Ids d = ids();
   const int lane = d.lane, qi = d.qi, g = d.g, jc = d.jc;
   const int h = blockIdx.y, n = blockIdx.z;
@@ -148,11 +241,32 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
   float* lsep = a.lse2_out + ((size_t)n * a.heads + h) * L;
 
   const int rows = 64 * (first + nb);
-  stage_planes(kt, Lp, kp, 4, L, 0, rows, a.vec, 1.f, 0.f);
-  stage_planes(vt, Lp, vp, 4, L, 0, rows, a.vec, 1.f, 0.f);
-  __syncthreads();
   const int lo = first + d.wave, hi = first + nb - 1 - d.wave;
+  // K -> bf16x3 chunks, V -> V^T planes: one pass, all global loads of an iteration first
+  for (int m0 = 0; m0 < rows; m0 += 2 * blockDim.x) {
+    float kx[2][4], vx[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * blockDim.x + threadIdx.x;
+      load_row4(kx[u], kp, L, m);
+      load_row4(vx[u], vp, L, m);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * blockDim.x + threadIdx.x;
+      if (m < rows) {
+        put_chunks(kc0, kc2, m, kx[u]);
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) vt[dd * Lp + m] = vx[u][dd];
+      }
+    }
+  }
+  if (threadIdx.x == 0) *ones = ones_chunk();
+  __syncthreads();
   if (lo > hi) return;
+  // streamed-operand address of this lane: groups 0,1 -> c0[key], 2 -> c2[key], 3 -> the ones chunk
+  const bf16x8* abase = g == 3 ? ones : (g == 2 ? kc2 : kc0) + qi;
+  const int astride = g == 3 ? 0 : 1;
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -162,20 +276,24 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
     const int q0 = 64 * blk;
     const int ngrp = min(4, (L - q0 + 15) >> 4);  // 16-query groups of this block that exist
 
-    float qf[4], mcur[4], lsum[4];
-    f32x4 negm[4], acc[4];
+    float mcur[4], lsum[4];
+    bf16x8 bq[4];
+    f32x4 acc[4];
     int qidx[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       qidx[t] = q0 + 16 * t + qi;
-      qf[t] = qidx[t] < L ? qp[(size_t)g * L + qidx[t]] * a.scale2 : 0.f;
-      mcur[t] = 0.f;  // provisional: the first tile (FORCE) moves every lane's m to its exact maximum
-      negm[t] = splat_opaque(0.f);
+      float qv[4];
+      load_row4(qv, qp, L, qidx[t]);
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) qv[dd] *= a.scale2;
+      mcur[t] = 0.f;  // provisional: the first tile (FORCE) moves every query's m to its exact maximum
+      bq[t] = resident_operand(qv, 0.f, g);
       lsum[t] = 0.f;
       acc[t] = zero4;
     }
 
-    // move group t's running max up (or, c < 0, down: first tile only) by c and rescale its state
+    // move group t's running max (one per query, shared by its four key subsets) by c and rescale
     auto shift_max = [&](int t, float c) {
       const float alpha = ex2(-c);
       float al[4];
@@ -184,7 +302,7 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[t][i] *= al[i];
       mcur[t] += c;
-      negm[t] = splat_opaque(-mcur[t]);
+      set_constant(bq[t], -mcur[t], g);
     };
 
     // One 16-key tile against groups [TMIN, 4): scores for all of them, exponentials, ONE overflow
@@ -192,15 +310,15 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
     //   MASK 0: no lane is cut (tile strictly below every diagonal)
     //   MASK 1: group TMIN is on its diagonal, per-lane causal predicate for it
     //   MASK 2: predicate for every group (the very first tile of block 0)
-    //   FORCE : set every lane's m to the exact maximum of its allowed scores (first tile)
-    auto step = [&](int k0, float kf, const f32x4& vf, auto TMIN_, auto MASK_, auto FORCE_) {
+    //   FORCE : set every query's m to the exact maximum of its allowed scores (first tile)
+    auto step = [&](int k0, const bf16x8& kf, const f32x4& vf, auto TMIN_, auto MASK_, auto FORCE_) {
       constexpr int TMIN = decltype(TMIN_)::value, MASK = decltype(MASK_)::value;
       constexpr bool FORCE = decltype(FORCE_)::value;
       f32x4 s[4];
       float p[4][4], ps[4];
       int lim[4];
 #pragma unroll
-      for (int t = TMIN; t < 4; ++t) s[t] = MFMA16(kf, qf[t], negm[t]);
+      for (int t = TMIN; t < 4; ++t) s[t] = MFMA16B(kf, bq[t], zero4);
 #pragma unroll
       for (int t = TMIN; t < 4; ++t) {
         const bool cut = MASK == 2 || (MASK == 1 && t == TMIN);
@@ -213,14 +331,15 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
 #pragma unroll
       for (int t = TMIN + 1; t < 4; ++t) pmax = fmaxf(pmax, ps[t]);
       if (FORCE || __any(pmax > PSUM_TH)) {
-        // some score ran more than ~2^8 above its lane's running max: move the max up, rescale
+        // some score ran more than ~2^8 above its query's running max: move the max up, rescale
 #pragma unroll
         for (int t = TMIN; t < 4; ++t) {
           const bool cut = MASK == 2 || (MASK == 1 && t == TMIN);
           float c = NEG_BIG;
 #pragma unroll
           for (int r = 0; r < 4; ++r) c = fmaxf(c, (!cut || r <= lim[t]) ? s[t][r] : NEG_BIG);
-          if (cut) c = lim[t] >= 0 ? c : 0.f;  // no allowed key in this lane's subset: leave m alone
+          c = gmax(c);
+          c = c > 0.5f * NEG_BIG ? c : 0.f;  // query without any allowed key so far: leave m alone
           if (!FORCE) c = fmaxf(c, 0.f);
           shift_max(t, c);
 #pragma unroll
@@ -236,19 +355,19 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
         for (int t = TMIN; t < 4; ++t) acc[t] = MFMA4(p[t][r], vf[r], acc[t]);
       }
     };
-    auto frag_k = [&](int k0) { return kt[g * Lp + k0 + qi]; };
+    auto frag_k = [&](int k0) { return abase[astride * k0]; };
     auto frag_v = [&](int k0) { return *reinterpret_cast<const f32x4*>(vt + jc * Lp + k0 + 4 * g); };
 
-    // ---- first tile: every lane that will ever see an allowed key sees one here (queries >= 16:
+    // ---- first tile: every query that will ever see an allowed key sees one here (queries >= 16:
     //      the whole tile; queries < 16 have no other tile)
     if (q0 == 0) step(0, frag_k(0), frag_v(0), I<0>{}, I<2>{}, B<true>{});
     else step(0, frag_k(0), frag_v(0), I<0>{}, I<0>{}, B<true>{});
 
     // ---- full tiles (strictly below every group's diagonal): 4 groups per K/V fragment
-    float kfn = frag_k(16);
+    bf16x8 kfn = frag_k(16);
     f32x4 vfn = frag_v(16);
     for (int k0 = 16; k0 < q0; k0 += 16) {
-      const float kf = kfn;
+      const bf16x8 kf = kfn;
       const f32x4 vf = vfn;
       kfn = frag_k(k0 + 16);
       vfn = frag_v(k0 + 16);
@@ -262,23 +381,18 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
     if (ngrp > 2) step(q0 + 32, frag_k(q0 + 32), frag_v(q0 + 32), I<2>{}, I<1>{}, B<false>{});
     if (ngrp > 3) step(q0 + 48, frag_k(q0 + 48), frag_v(q0 + 48), I<3>{}, I<1>{}, B<false>{});
 
-    // ---- merge the four key subsets g of every query, normalise, store
+    // ---- sum the four key subsets g of every query (they share m), normalise, store
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (t < ngrp) {
-        const float m = lsum[t] > 0.f ? mcur[t] : NEG_BIG;  // a subset without allowed keys has no max
-        float mx = fmaxf(m, __shfl_xor(m, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float f = ex2(m - mx);
-        const float l = gsum(lsum[t] * f);
-        float fq[4], iq[4], ov[4];
-        quad_all(f, fq);
+        const float l = gsum(lsum[t]);
+        float iq[4], ov[4];
         quad_all(l > 0.f ? 1.f / l : 0.f, iq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ov[i] = gsum(acc[t][i] * fq[i]) * iq[i];
+        for (int i = 0; i < 4; ++i) ov[i] = gsum(acc[t][i]) * iq[i];
         if (g == 0) {
           store_rows4(op + (size_t)jc * L, L, q0 + 16 * t + d.qb4, a.vec, ov[0], ov[1], ov[2], ov[3]);
-          if (qidx[t] < L) lsep[qidx[t]] = l > 0.f ? mx + log2f(l) : POS_BIG;
+          if (qidx[t] < L) lsep[qidx[t]] = l > 0.f ? mcur[t] + log2f(l) : POS_BIG;
         }
       }
     }
@@ -287,11 +401,16 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
 
 // ------------------------------------------------------------------------------ backward: dQ
 // Also writes delta[l] = sum_j dO[l][j] * O[l][j] (read by the dK/dV kernel).
+// LDS per workgroup: K chunks, V chunks (2 x 16 B per key each), K^T planes [4][Lp] fp32, ones chunk.
 __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
   extern __shared__ float4 lds4[];
   const int Lp = a.lp;
-  float* kt = reinterpret_cast<float*>(lds4);
-  float* vt = kt + 4 * Lp;
+  bf16x8* kc0 = reinterpret_cast<bf16x8*>(lds4);
+  bf16x8* kc2 = kc0 + Lp;
+  bf16x8* vc0 = kc2 + Lp;
+  bf16x8* vc2 = vc0 + Lp;
+  float* kt = reinterpret_cast<float*>(vc2 + Lp);  // K^T [4][Lp]
+  bf16x8* ones = reinterpret_cast<bf16x8*>(kt + 4 * Lp);
   const Ids d = ids();
   const int qi = d.qi, g = d.g, jc = d.jc;
   const int h = blockIdx.y, n = blockIdx.z;
@@ -310,11 +429,34 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
   const size_t row = ((size_t)n * a.heads + h) * L;
 
   const int rows = 64 * (first + nb);
-  stage_planes(kt, Lp, kp, 4, L, 0, rows, a.vec, 1.f, 0.f);
-  stage_planes(vt, Lp, vp, 4, L, 0, rows, a.vec, 1.f, 0.f);
-  __syncthreads();
   const int lo = first + d.wave, hi = first + nb - 1 - d.wave;
+  // K, V -> bf16x3 chunks, K -> K^T planes: one pass, all global loads of an iteration first
+  for (int m0 = 0; m0 < rows; m0 += 2 * blockDim.x) {
+    float kx[2][4], vx[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * blockDim.x + threadIdx.x;
+      load_row4(kx[u], kp, L, m);
+      load_row4(vx[u], vp, L, m);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * blockDim.x + threadIdx.x;
+      if (m < rows) {
+        put_chunks(kc0, kc2, m, kx[u]);
+        put_chunks(vc0, vc2, m, vx[u]);
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) kt[dd * Lp + m] = kx[u][dd];
+      }
+    }
+  }
+  if (threadIdx.x == 0) *ones = ones_chunk();
+  __syncthreads();
   if (lo > hi) return;
+  // streamed-operand addresses of this lane: groups 0,1 -> c0[key], 2 -> c2[key], 3 -> ones chunk
+  const bf16x8* kbase = g == 3 ? ones : (g == 2 ? kc2 : kc0) + qi;
+  const bf16x8* vbase = g == 3 ? ones : (g == 2 ? vc2 : vc0) + qi;
+  const int astride = g == 3 ? 0 : 1;
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -324,32 +466,36 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
     const int q0 = 64 * blk;
     const int ngrp = min(4, (L - q0 + 15) >> 4);
 
-    float qf[4], gf[4];
-    f32x4 nl[4], nd[4], acc[4];
+    bf16x8 bq[4], bg[4];  // resident operands: q (constant -lse2) and dO (constant -delta)
+    f32x4 acc[4];
     int qidx[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       qidx[t] = q0 + 16 * t + qi;
       const bool ok = qidx[t] < L;
-      const int qc = ok ? qidx[t] : L - 1;
-      qf[t] = ok ? qp[(size_t)g * L + qc] * a.scale2 : 0.f;
-      gf[t] = ok ? gp[(size_t)g * L + qc] : 0.f;
-      const float ov = ok ? op[(size_t)g * L + qc] : 0.f;
-      const float dl = gsum(gf[t] * ov);
-      if (ok && g == 0) a.delta[row + qc] = dl;
-      const float lse = ok ? a.lse2_in[row + qc] : POS_BIG;
-      nl[t] = splat_opaque(-lse);
-      nd[t] = splat_opaque(-dl);
+      float qv[4], gv[4], ov[4], dl = 0.f;
+      load_row4(qv, qp, L, qidx[t]);
+      load_row4(gv, gp, L, qidx[t]);
+      load_row4(ov, op, L, qidx[t]);
+      const float lse = ok ? a.lse2_in[row + qidx[t]] : POS_BIG;
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {
+        qv[dd] *= a.scale2;
+        dl = fmaf(gv[dd], ov[dd], dl);
+      }
+      if (ok && g == 0) a.delta[row + qidx[t]] = dl;
+      bq[t] = resident_operand(qv, -lse, g);
+      bg[t] = resident_operand(gv, -dl, g);
       acc[t] = zero4;
     }
 
     // One 16-key tile against groups [TMIN, 4): P = exp2(S - lse), dS = P * (dP - delta), dQ += dS K.
     // MASK: group TMIN is on its diagonal (per-lane causal predicate).
-    struct Frag { float kf, va; f32x4 kq; };
+    struct Frag { bf16x8 ka, va; f32x4 kq; };
     auto frag = [&](int k0) {
       Frag f;
-      f.kf = kt[g * Lp + k0 + qi];
-      f.va = vt[g * Lp + k0 + qi];
+      f.ka = kbase[astride * k0];
+      f.va = vbase[astride * k0];
       f.kq = *reinterpret_cast<const f32x4*>(kt + jc * Lp + k0 + 4 * g);
       return f;
     };
@@ -360,8 +506,8 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
       float ds[4][4];
 #pragma unroll
       for (int t = TMIN; t < 4; ++t) {
-        s[t] = MFMA16(f.kf, qf[t], nl[t]);
-        dp[t] = MFMA16(f.va, gf[t], nd[t]);
+        s[t] = MFMA16B(f.ka, bq[t], zero4);
+        dp[t] = MFMA16B(f.va, bg[t], zero4);
       }
 #pragma unroll
       for (int t = TMIN; t < 4; ++t) {
@@ -427,12 +573,34 @@ __global__ void __launch_bounds__(512) attn_dkv_m44_kernel(const PgAttnArgs a) {
   const size_t row = ((size_t)n * a.heads + h) * L;
 
   const int r0 = 64 * first, r1 = 64 * NB;
-  stage_planes(qt, Lp, qp, 4, L, r0, r1, a.vec, 1.f, 0.f);
-  stage_planes(gt, Lp, gp, 4, L, r0, r1, a.vec, 1.f, 0.f);
-  stage_planes(nlse, Lp, a.lse2_in + row, 1, L, r0, r1, a.vec, -1.f, NEG_BIG);
-  stage_planes(ndel, Lp, a.delta + row, 1, L, r0, r1, a.vec, -1.f, 0.f);
-  __syncthreads();
   const int lo = first + d.wave, hi = first + nb - 1 - d.wave;
+  // q, dO -> planes, -lse2, -delta: one pass, all global loads of an iteration first
+  for (int m0 = r0; m0 < r1; m0 += 2 * blockDim.x) {
+    float qx[2][4], gx[2][4], lx[2], dx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * blockDim.x + threadIdx.x;
+      load_row4(qx[u], qp, L, m);
+      load_row4(gx[u], gp, L, m);
+      const int mc = m < L ? m : L - 1;
+      lx[u] = a.lse2_in[row + mc];
+      dx[u] = a.delta[row + mc];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * blockDim.x + threadIdx.x;
+      if (m < r1) {
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          qt[dd * Lp + m] = qx[u][dd];
+          gt[dd * Lp + m] = gx[u][dd];
+        }
+        nlse[m] = m < L ? -lx[u] : NEG_BIG;
+        ndel[m] = m < L ? -dx[u] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
   if (lo > hi) return;
   const int q_end = ((L + 15) >> 4) << 4;
 
@@ -544,8 +712,10 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   const int bpw = NB < 16 ? NB : 16;
   a.blocks_per_wg = bpw;
   a.lp = 64 * NB + 16;  // plane stride == 16 (mod 64): conflict-free b32 and b128 fragment reads
-  const size_t planes = which == PG_ATTN_DKV ? 10 : 8;
-  const size_t shmem = planes * (size_t)a.lp * sizeof(float);
+  // in 4-byte units per row — fwd: K chunks (2 x 16 B) + V^T planes; dQ: K and V chunks + K^T planes;
+  // dK/dV: 10 planes; plus the ones chunk
+  const size_t planes = which == PG_ATTN_DKV ? 10 : (which == PG_ATTN_DQ ? 20 : 12);
+  const size_t shmem = planes * (size_t)a.lp * sizeof(float) + 16;
   if (shmem > 160 * 1024) return 0;
   bool vec = a.L % 4 == 0;
   if (which == PG_ATTN_FWD)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing ablations of attention_mfma.hip (results are WRONG by construction; timing only):
-#   abl1: exp2 -> one multiply      abl2: 4x4x1 MFMA -> one FMA     abl3: both
-#   abl4: 16x16x4 MFMA -> one FMA + splat
+#   abl1: no main loops (edges, staging, prologue, epilogue only)   abl2: no edge steps
+#   abl3: no staging   abl4: no main loops and no edge steps
 set -e
 cd "$(dirname "$0")/../.."
 SRC=pytorch-generative_amd/csrc/attention_mfma.hip
@@ -11,16 +11,21 @@ others=$(ls $OBJ/*.o | grep -v attention_mfma.o)
 for v in 1 2 3 4; do
   tmp=pytorch-generative_amd/csrc/_abl$v.hip
   cp $SRC $tmp
-  if [ $((v & 1)) -ne 0 ] && [ $v -ne 4 ]; then
-    sed -i 's|__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }|__device__ __forceinline__ float ex2(float x) { return x * 0.999f; }|' $tmp
-  fi
-  if [ $((v & 2)) -ne 0 ]; then
-    sed -i 's|#define MFMA4(A, B, C) .*|__device__ __forceinline__ f32x4 abl4(float a, float b, f32x4 c) { c[0] = __builtin_fmaf(a, b, c[0]); return c; }\n#define MFMA4(A, B, C) abl4((A), (B), (C))|' $tmp
-  fi
-  if [ $v -eq 4 ]; then
-    sed -i 's|#define MFMA16(A, B, C) .*|__device__ __forceinline__ f32x4 abl16(float a, float b, f32x4 c) { float t = a * b; return f32x4{c[0] + t, c[1] + t, c[2] - t, c[3] - t}; }\n#define MFMA16(A, B, C) abl16((A), (B), (C))|' $tmp
-  fi
-  /opt/rocm/bin/hipcc $FLAGS -c $tmp -o tools/exp/_abl$v.o
+  python3 - $tmp $v <<'PY'
+import sys,re
+p,v=sys.argv[1],int(sys.argv[2])
+s=open(p).read()
+if v in (1,4):
+    s=s.replace('for (int k0 = 16; k0 < q0; k0 += 16) {','for (int k0 = 16; k0 < 0; k0 += 16) {')
+    s=s.replace('for (int k0 = 0; k0 < q0; k0 += 16) {','for (int k0 = 0; k0 < 0; k0 += 16) {')
+    s=s.replace('for (int q0t = kb0 + 64; q0t < q_end; q0t += 16) {','for (int q0t = kb0 + 64; q0t < 0; q0t += 16) {')
+if v in (2,4):
+    s=re.sub(r'\n    (if \([^\n]*\) )?step\([^\n]*B<(true|false)>\{\}\);(?=\n)', lambda m: m.group(0) if 'for (' in m.group(0) else '', s)
+if v==3:
+    s=re.sub(r'for \(int m0 = (0|r0); m0 < (rows|r1); m0 \+= 2 \* blockDim.x\) \{', lambda m: 'for (int m0 = 0; m0 < 0; m0 += 2 * blockDim.x) {', s)
+open(p,'w').write(s)
+PY
+  /opt/rocm/bin/hipcc $FLAGS -c $tmp -o tools/exp/_abl$v.o 2>&1 | grep -E "error" || true
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $others tools/exp/_abl$v.o -o tools/exp/libpg_abl$v.so
   rm -f $tmp tools/exp/_abl$v.o
 done

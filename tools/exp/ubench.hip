@@ -11,6 +11,9 @@ __global__ void __launch_bounds__(512) ub(float* out, int iters) {
   float x[8];
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 pk[8];
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  bf16x8 ba, bb;
+  for (int i = 0; i < 8; ++i) { ba[i] = (__bf16)(threadIdx.x * 1e-3f + i); bb[i] = (__bf16)(1.0f + i * 0.01f); }
   const f32x2 pka = {threadIdx.x * 1e-3f, 2e-3f}, pkb = {1.0f + blockIdx.x * 1e-6f, 0.999f};
   const float a = threadIdx.x * 1e-3f, b = 1.0f + blockIdx.x * 1e-6f;
 #pragma unroll
@@ -26,6 +29,11 @@ __global__ void __launch_bounds__(512) ub(float* out, int iters) {
       if (MODE == 5) { acc[i] = MFMA16(x[i], b, acc[i]); x[i] = __builtin_amdgcn_exp2f(x[i]); }
       if (MODE == 6) { acc[i] = MFMA4(x[i], b, acc[i]); x[i] = __builtin_fmaf(x[i], b, a); }
       if (MODE == 7) x[i] = __builtin_amdgcn_rcpf(x[i]);
+      if (MODE == 12) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i], 0, 0, 0);
+      if (MODE == 13) { acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i], 0, 0, 0); x[i] = __builtin_amdgcn_exp2f(x[i]); }
+      if (MODE == 14) { acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i], 0, 0, 0); x[i] = __builtin_fmaf(x[i], b, a); x[(i + 1) & 7] = __builtin_fmaf(x[(i + 1) & 7], b, a); }
+      if (MODE == 15) { acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i], 0, 0, 0); acc[(i + 4) & 7] = MFMA4(a, b, acc[(i + 4) & 7]); }
+      if (MODE == 16) { acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i], 0, 0, 0); x[i] = __builtin_amdgcn_exp2f(x[i]); x[(i + 1) & 7] = __builtin_amdgcn_exp2f(x[(i + 1) & 7]); x[(i + 2) & 7] = __builtin_amdgcn_exp2f(x[(i + 2) & 7]); x[(i + 3) & 7] = __builtin_amdgcn_exp2f(x[(i + 3) & 7]); }
       if (MODE == 8) pk[i] = __builtin_elementwise_fma(pk[i], pkb, pka);
       if (MODE == 9) { pk[i] = __builtin_elementwise_fma(pk[i], pkb, pka); acc[i] = MFMA16(a, b, acc[i]); }
       if (MODE == 10) { pk[i] = pk[i] + pka; }
@@ -49,6 +57,11 @@ extern "C" int ub_run(int mode, float* out, int iters, int blocks, int threads, 
     case 5: hipLaunchKernelGGL(ub<5>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 6: hipLaunchKernelGGL(ub<6>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 7: hipLaunchKernelGGL(ub<7>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
+    case 12: hipLaunchKernelGGL(ub<12>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
+    case 13: hipLaunchKernelGGL(ub<13>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
+    case 14: hipLaunchKernelGGL(ub<14>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
+    case 15: hipLaunchKernelGGL(ub<15>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
+    case 16: hipLaunchKernelGGL(ub<16>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 8: hipLaunchKernelGGL(ub<8>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 9: hipLaunchKernelGGL(ub<9>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 10: hipLaunchKernelGGL(ub<10>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
