@@ -108,6 +108,13 @@ int pg_nchw_layernorm_bwd(const float* x, const float* gamma, const float* mean,
                           float* dbeta, int N, int C, int L, float* workspace,
                           size_t workspace_floats, void* stream);
 size_t pg_nchw_layernorm_bwd_workspace_floats(int N, int C, int L);
+/* Same, with dx = LN backward + dx_add: the gradient of the residual (skip) branch that leaves the
+ * same x — `x + f(LN(x))` in every transformer / PixelSNAIL block (image_gpt.py:50-52) — is added in
+ * the kernel's epilogue instead of by a separate autograd accumulation pass. dx_add must not alias dx. */
+int pg_nchw_layernorm_bwd_res(const float* x, const float* gamma, const float* mean,
+                              const float* rstd, const float* dy, const float* dx_add, float* dx,
+                              float* dgamma, float* dbeta, int N, int C, int L, float* workspace,
+                              size_t workspace_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused causal attention core.  nn/attention.py:147-160:
@@ -197,6 +204,24 @@ int pg_gauss_head_bwd(const float* q, const float* p, const float* eps, const fl
 /* out[0] += mean(v[0..n)) ; out[i] = g[0]*scale (its backward) */
 int pg_vec_mean_accum(const float* v, int n, float* out, void* stream);
 int pg_fill_scaled(const float* g, float scale, float* out, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The transformer block's position-wise MLP, fused.  models/autoregressive/image_gpt.py:43-52:
+ *   y = res + W2 gelu(W1 x + b1) + b2     (Conv2d(C,Hd,1) -> GELU -> Conv2d(Hd,C,1), `x + self._out(..)`)
+ * x, res, y, dy, dx: (N, C, L); w1: (Hd, C); w2: (C, Hd); exact (erf) GELU. The hidden tensor is
+ * never written to memory; backward recomputes it. Instantiated for C = 16, Hd = 64, L % 16 == 0
+ * (PG_ESHAPE otherwise: the caller runs the three unfused operators). res may be NULL.
+ * Backward: dx is written; dw1/db1/dw2/db2 are ADDED to (per-workgroup partial rows in `workspace`,
+ * then a deterministic reduce); d(res) = dy is the caller's. x and dy must be 16-byte aligned.
+ * ------------------------------------------------------------------------------------- */
+int pg_mlp_gelu_fwd(const float* x, const float* w1, const float* b1, const float* w2,
+                    const float* b2, const float* res, float* y, int N, int C, int Hd, int L,
+                    void* stream);
+int pg_mlp_gelu_bwd(const float* x, const float* w1, const float* b1, const float* w2,
+                    const float* dy, float* dx, float* dw1, float* db1, float* dw2, float* db2,
+                    int N, int C, int Hd, int L, float* workspace, size_t workspace_floats,
+                    void* stream);
+size_t pg_mlp_gelu_bwd_workspace_floats(int N, int L);
 
 /* ---------------------------------------------------------------------------------------
  * Optimiser step as timed by the reference (trainer.py:183-191): global grad L2 norm

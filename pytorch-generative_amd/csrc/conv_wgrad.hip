@@ -450,6 +450,7 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     dim3 grid((unsigned)gx, (unsigned)co_chunks, (unsigned)ci_chunks);
     if (ncot <= 1) launch_pw_wgrad<1>(p, ncit, grid, st);
     else if (ncot == 2) launch_pw_wgrad<2>(p, ncit, grid, st);
+    else if (ncot == 3) launch_pw_wgrad<3>(p, ncit, grid, st);  // 48 = the merged q|k|v projection
     else launch_pw_wgrad<4>(p, ncit, grid, st);
     PG_LAUNCH_CHECK("pg_conv2d_wgrad(1x1)");
     launch_reduce(workspace, stride, (int)gx, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);

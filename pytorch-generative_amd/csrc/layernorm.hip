@@ -81,8 +81,8 @@ template <int CREG>
 __global__ void __launch_bounds__(LN_THREADS)
 ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
               const float* __restrict__ mean, const float* __restrict__ rstd,
-              const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ part,
-              int N, int C, int L) {
+              const float* __restrict__ dy, const float* __restrict__ dx_add,
+              float* __restrict__ dx, float* __restrict__ part, int N, int C, int L) {
   extern __shared__ float red[];  // [2][C][waves]
   constexpr int nw = LN_THREADS / 64;
   constexpr int CR = CREG > 0 ? CREG : 1;
@@ -91,7 +91,7 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
   const float invC = 1.f / (float)C;
 
   if (CREG > 0) {
-    float xv[LN_PPL][CR], dv[LN_PPL][CR], mu[LN_PPL], rs[LN_PPL];
+    float xv[LN_PPL][CR], dv[LN_PPL][CR], av[LN_PPL][CR], mu[LN_PPL], rs[LN_PPL];
     size_t base[LN_PPL];
     bool live[LN_PPL];
 #pragma unroll
@@ -107,6 +107,7 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
       for (int c = 0; c < CR; ++c) {
         xv[it][c] = c < C ? x[base[it] + (size_t)c * L] : 0.f;
         dv[it][c] = (c < C && live[it]) ? dy[base[it] + (size_t)c * L] : 0.f;
+        av[it][c] = (dx_add != nullptr && c < C) ? dx_add[base[it] + (size_t)c * L] : 0.f;  // skip-path gradient
       }
     }
     float pg[CR], pb[CR];
@@ -126,7 +127,8 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
 #pragma unroll
       for (int c = 0; c < CR; ++c) {
         if (c < C) {
-          if (live[it]) dx[base[it] + (size_t)c * L] = rs[it] * (dv[it][c] * gamma[c] - mg - xv[it][c] * mgx);
+          if (live[it])
+            dx[base[it] + (size_t)c * L] = rs[it] * (dv[it][c] * gamma[c] - mg - xv[it][c] * mgx) + av[it][c];
           pg[c] = fmaf(dv[it][c], xv[it][c], pg[c]);
           pb[c] += dv[it][c];
         }
@@ -164,7 +166,9 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
       for (int c = 0; c < C; ++c) {
         const float xh = (x[base + (size_t)c * L] - mu) * rs;
         const float d = live ? dy[base + (size_t)c * L] : 0.f;
-        if (live) dx[base + (size_t)c * L] = rs * (d * gamma[c] - mg - xh * mgx);
+        if (live)
+          dx[base + (size_t)c * L] = rs * (d * gamma[c] - mg - xh * mgx) +
+                                     (dx_add != nullptr ? dx_add[base + (size_t)c * L] : 0.f);
         const float wg = pg_wave_sum(d * xh), wb = pg_wave_sum(d);
         if (lane == 0) {
           red[(0 * C + c) * nw + wave] += wg;
@@ -238,29 +242,47 @@ PG_EXPORT int pg_nchw_layernorm_fwd(const float* x, const float* gamma, const fl
   return 0;
 }
 
-PG_EXPORT int pg_nchw_layernorm_bwd(const float* x, const float* gamma, const float* mean,
-                                    const float* rstd, const float* dy, float* dx, float* dgamma,
-                                    float* dbeta, int N, int C, int L, float* workspace,
-                                    size_t workspace_floats, void* stream) {
+namespace {
+int ln_bwd_impl(const char* who, const float* x, const float* gamma, const float* mean, const float* rstd,
+                const float* dy, const float* dx_add, float* dx, float* dgamma, float* dbeta, int N,
+                int C, int L, float* workspace, size_t workspace_floats, void* stream) {
   PG_REQUIRE(x && gamma && mean && rstd && dy && dx && dgamma && dbeta && workspace, PG_EINVAL,
-             "pg_nchw_layernorm_bwd: null pointer");
-  PG_REQUIRE(N > 0 && C > 0 && L > 0, PG_EINVAL, "pg_nchw_layernorm_bwd: bad dims");
-  PG_REQUIRE(C <= 2048, PG_ESHAPE, "pg_nchw_layernorm_bwd: C=%d > 2048", C);
+             "%s: null pointer", who);
+  PG_REQUIRE(N > 0 && C > 0 && L > 0, PG_EINVAL, "%s: bad dims", who);
+  PG_REQUIRE(C <= 2048, PG_ESHAPE, "%s: C=%d > 2048", who, C);
   PG_REQUIRE(workspace_floats >= pg_nchw_layernorm_bwd_workspace_floats(N, C, L), PG_EINVAL,
-             "pg_nchw_layernorm_bwd: workspace too small");
+             "%s: workspace too small", who);
   const long blocks = ln_bwd_blocks(N, L);
   dim3 grid((unsigned)blocks);
   const size_t shmem = (size_t)2 * C * (LN_THREADS / 64) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (C <= 16)
-    hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx, workspace, N, C, L);
+    hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx_add, dx, workspace, N, C, L);
   else if (C <= 32)
-    hipLaunchKernelGGL(ln_bwd_kernel<32>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx, workspace, N, C, L);
+    hipLaunchKernelGGL(ln_bwd_kernel<32>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx_add, dx, workspace, N, C, L);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel<0>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx, workspace, N, C, L);
-  PG_LAUNCH_CHECK("pg_nchw_layernorm_bwd");
+    hipLaunchKernelGGL(ln_bwd_kernel<0>, grid, dim3(LN_THREADS), shmem, st, x, gamma, mean, rstd, dy, dx_add, dx, workspace, N, C, L);
+  PG_LAUNCH_CHECK(who);
   hipLaunchKernelGGL(rows_reduce_add_kernel, dim3((unsigned)((2 * C + 7) / 8)), dim3(256), 0, st,
                      workspace, (int)blocks, 2 * C, dgamma, dbeta, C);
-  PG_LAUNCH_CHECK("pg_nchw_layernorm_bwd(reduce)");
+  PG_LAUNCH_CHECK(who);
   return 0;
+}
+}  // namespace
+
+PG_EXPORT int pg_nchw_layernorm_bwd(const float* x, const float* gamma, const float* mean,
+                                    const float* rstd, const float* dy, float* dx, float* dgamma,
+                                    float* dbeta, int N, int C, int L, float* workspace,
+                                    size_t workspace_floats, void* stream) {
+  return ln_bwd_impl("pg_nchw_layernorm_bwd", x, gamma, mean, rstd, dy, nullptr, dx, dgamma, dbeta, N, C,
+                     L, workspace, workspace_floats, stream);
+}
+
+PG_EXPORT int pg_nchw_layernorm_bwd_res(const float* x, const float* gamma, const float* mean,
+                                        const float* rstd, const float* dy, const float* dx_add,
+                                        float* dx, float* dgamma, float* dbeta, int N, int C, int L,
+                                        float* workspace, size_t workspace_floats, void* stream) {
+  PG_REQUIRE(dx_add, PG_EINVAL, "pg_nchw_layernorm_bwd_res: null pointer");
+  return ln_bwd_impl("pg_nchw_layernorm_bwd_res", x, gamma, mean, rstd, dy, dx_add, dx, dgamma, dbeta, N,
+                     C, L, workspace, workspace_floats, stream);
 }

@@ -43,6 +43,12 @@ SIGNATURES = {
     "pg_nchw_layernorm_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_flt, c_s]),
     "pg_nchw_layernorm_bwd": (
         c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_z, c_s]),
+    "pg_mlp_gelu_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_s]),
+    "pg_mlp_gelu_bwd": (
+        c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_z, c_s]),
+    "pg_mlp_gelu_bwd_workspace_floats": (c_z, [c_i, c_i]),
+    "pg_nchw_layernorm_bwd_res": (
+        c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_z, c_s]),
     "pg_nchw_layernorm_bwd_workspace_floats": (c_z, [c_i, c_i, c_i]),
     "pg_causal_attn_fwd": (
         c_i,

@@ -33,8 +33,14 @@ class TransformerBlock(nn.Module):
         )
 
     def forward(self, x):
-        x = self._attn(self._ln1(x), res=x)              # x + attn(ln1(x))
-        hidden = self._out[0](self._ln2(x))
+        # skip=True: the residual branch's gradient is added inside the LayerNorm backward kernel
+        y, x = self._ln1(x, skip=True)
+        x = self._attn(y, res=x)                         # x + attn(ln1(x))
+        y, x = self._ln2(x, skip=True)
+        if ops.mlp_gelu_supported(y, self._out[0], self._out[2]):
+            # fc1 -> GELU -> fc2 -> + x in one kernel each way: the hidden tensor stays in registers
+            return ops.mlp_gelu(y, self._out[0], self._out[2], res=x)
+        hidden = self._out[0](y)
         # exact GELU fused into the MLP-out kernel's input load, residual into its epilogue
         return self._out[2](hidden, in_act="gelu", res=x)  # x + mlp(ln2(x))
 

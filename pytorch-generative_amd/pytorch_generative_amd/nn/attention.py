@@ -55,12 +55,25 @@ class CausalAttention(nn.Module):
         self._proj = Conv2d(
             in_channels=self._out_channels, out_channels=self._out_channels, kernel_size=1
         )
+        if extra_input_channels == 0:
+            # layout hint for FlatAdam: q and kv parameters back to back, so that the two projections
+            # of the same input run as ONE convolution over the merged views (ops.conv_pair_views)
+            self._kv.weight._pg_follows = self._q.weight
+            self._kv.bias._pg_follows = self._q.bias
 
     def forward(self, x, extra_x=None, *, res=None):
         """x feeds q, k and v; extra_x (optional) is concatenated for k and v only.
 
         `res` (extension) is added to the projected output inside the projection kernel.
         """
+        if extra_x is None and ops.FUSE_PAIR:
+            views = ops.conv_pair_views(self._q, self._kv)
+            if views is not None:
+                qkv = ops.conv2d_pair(x, self._q, self._kv, views, self._q._conv_spec())
+                out = ops.causal_attention_qkv(
+                    qkv, self._n_heads, self._embed_channels, self._out_channels, self._mask_center
+                )
+                return self._proj(out, res=res)
         q = self._q(x)
         if extra_x is not None:
             x = torch.cat((x, extra_x), dim=1)

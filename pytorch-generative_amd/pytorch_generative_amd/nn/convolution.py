@@ -170,7 +170,13 @@ class GatedActivation(nn.Module):
 class NCHWLayerNorm(nn.LayerNorm):
     """LayerNorm over the channel dimension of NCHW tensors (no permutes: one lane per pixel)."""
 
-    def forward(self, x):
+    def forward(self, x, *, skip=False):
+        """skip=True (extension) returns (LN(x), x): feed the second value to the residual add of
+        `x + f(LN(x))` and its gradient is folded into LN's backward kernel."""
         if len(self.normalized_shape) != 1 or not self.elementwise_affine:
             raise ValueError("NCHWLayerNorm expects a single affine channel dimension")
+        if skip and not ops.FUSE_LNSKIP:
+            return ops.nchw_layernorm(x, self.weight, self.bias, self.eps), x
+        if skip:
+            return ops.nchw_layernorm_skip(x, self.weight, self.bias, self.eps)
         return ops.nchw_layernorm(x, self.weight, self.bias, self.eps)

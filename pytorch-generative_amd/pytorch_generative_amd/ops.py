@@ -13,6 +13,8 @@ kernels, and the flat buffer is what RCCL all-reduces. Without `_pg_grad` the us
 
 import math
 
+import os
+
 import torch
 
 from pytorch_generative_amd import _lib
@@ -134,6 +136,11 @@ class _ConvTaps(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        need = ctx.needs_input_grad
+        return _ConvTaps.backward_impl(ctx, dy, need[0], need[1], ctx.has_bias and need[2])
+
+    @staticmethod
+    def backward_impl(ctx, dy, need_dx, need_w, need_b):
         lib = _lib.load()
         x, weight = ctx.saved_tensors
         spec = ctx.spec
@@ -141,7 +148,7 @@ class _ConvTaps(torch.autograd.Function):
         n, cin, ih, iw = x.shape
         _, cout, oh, ow = dy.shape
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             wpk_t = _pack(lib, weight, spec, transpose=True)
             dx = torch.empty_like(x)
             # ReLU's derivative is applied in the dgrad kernel's epilogue; for ELU/GELU (exp/erf:
@@ -162,8 +169,6 @@ class _ConvTaps(torch.autograd.Function):
                                    ctx.in_act, _stream()),
                     "pg_act_bwd",
                 )
-        need_w = ctx.needs_input_grad[1]
-        need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if need_w or need_b:
             gw, gb = ctx.gw, ctx.gb
             if gw is None:
@@ -193,6 +198,72 @@ class _ConvTaps(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None
 
 
+# A/B switches for measurements (PG_FUSE_PAIR=0 / PG_FUSE_LNSKIP=0 select the unfused graphs)
+FUSE_PAIR = os.environ.get("PG_FUSE_PAIR", "1") != "0"
+FUSE_LNSKIP = os.environ.get("PG_FUSE_LNSKIP", "1") != "0"
+
+
+def _adjacent_view(a, b, shape):
+    """One tensor over `a` followed immediately by `b` in the same storage (None if they are not
+    laid out that way): FlatAdam places declared pairs back to back (optim.py, `_pg_follows`)."""
+    if a is None or b is None or a.dtype != torch.float32 or b.dtype != torch.float32:
+        return None
+    if not (a.is_contiguous() and b.is_contiguous()) or a.device != b.device:
+        return None
+    if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+        return None
+    if a.data_ptr() + 4 * a.numel() != b.data_ptr():
+        return None
+    strides, acc = [], 1
+    for d in reversed(shape):
+        strides.append(acc)
+        acc *= d
+    return a.as_strided(tuple(shape), tuple(reversed(strides)), a.storage_offset())
+
+
+def conv_pair_views(conv_a, conv_b):
+    """(weight, bias, weight-grad sink, bias-grad sink) of the concatenated convolution
+    [conv_a; conv_b] as zero-copy views, or None when the two modules' parameters / gradient sinks
+    are not adjacent in the flat buffers (then the caller runs the two convolutions separately)."""
+    wa, wb = conv_a.weight, conv_b.weight
+    if conv_a.bias is None or conv_b.bias is None or wa.shape[1:] != wb.shape[1:]:
+        return None
+    ca, cb = wa.shape[0], wb.shape[0]
+    wshape = (ca + cb,) + tuple(wa.shape[1:])
+    w = _adjacent_view(wa.data, wb.data, wshape)
+    b = _adjacent_view(conv_a.bias.data, conv_b.bias.data, (ca + cb,))
+    gw = _adjacent_view(_sink(wa), _sink(wb), wshape)
+    gb = _adjacent_view(_sink(conv_a.bias), _sink(conv_b.bias), (ca + cb,))
+    if w is None or b is None or gw is None or gb is None:
+        return None
+    return w, b, gw, gb
+
+
+class _ConvPair(torch.autograd.Function):
+    """y = [conv_a(x); conv_b(x)] (channel concatenation) as ONE tap convolution over the merged
+    parameter views: x is read once, one data gradient (no autograd accumulation pass over dx), one
+    weight-gradient launch writing straight into the merged gradient sinks."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb, views, spec, out_hw):
+        w, b, gw, gb = views
+        out = _ConvTaps.forward(ctx, x, w, b, None, spec, out_hw, ACT_NONE, gw, gb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        need = ctx.needs_input_grad
+        dx, _, _, _, *_ = _ConvTaps.backward_impl(ctx, dy, need[0], need[1] or need[3], need[2] or need[4])
+        return dx, None, None, None, None, None, None, None
+
+
+def conv2d_pair(x, conv_a, conv_b, views, spec, out_hw=None):
+    if out_hw is None:
+        out_hw = spec.full_out(x.shape[2], x.shape[3])
+    return _ConvPair.apply(x, conv_a.weight, conv_a.bias, conv_b.weight, conv_b.bias, views, spec,
+                           tuple(out_hw))
+
+
 def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
                 weight_param=None, bias_param=None):
     """y = conv(act(x)) + bias (+ res), cropped to out_hw (defaults to the full extent)."""
@@ -208,12 +279,85 @@ def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
 
 
 # --------------------------------------------------------------------------------------------
+# fused position-wise MLP (Conv2d 1x1 -> GELU -> Conv2d 1x1 [+ residual])
+# --------------------------------------------------------------------------------------------
+FUSE_MLP = os.environ.get("PG_FUSE_MLP", "1") != "0"
+
+
+def mlp_gelu_supported(x, conv1, conv2):
+    """The fused kernels are instantiated for the ImageGPT block shape (C = 16 -> 64 -> 16, 1x1,
+    L % 16 == 0); anything else runs as conv -> gelu -> conv."""
+    if not FUSE_MLP or conv1.bias is None or conv2.bias is None:
+        return False
+    w1, w2 = conv1.weight, conv2.weight
+    return (tuple(w1.shape) == (64, 16, 1, 1) and tuple(w2.shape) == (16, 64, 1, 1)
+            and x.shape[1] == 16 and (x.shape[2] * x.shape[3]) % 16 == 0)
+
+
+class _MlpGelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res, sinks):
+        lib = _lib.load()
+        x = _chk(x, "mlp_gelu.x")
+        w1, b1, w2, b2 = (_chk(t, "mlp_gelu.param") for t in (w1, b1, w2, b2))
+        if res is not None:
+            res = _chk(res, "mlp_gelu.res")
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        _lib.check(
+            lib.pg_mlp_gelu_fwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                b2.data_ptr(), _p(res), y.data_ptr(), n, c, w1.shape[0], h * w,
+                                _stream()),
+            "pg_mlp_gelu_fwd",
+        )
+        ctx.save_for_backward(x, w1, b1, w2)
+        ctx.sinks, ctx.has_res = sinks, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w1, b1, w2 = ctx.saved_tensors
+        dy = _chk(dy, "mlp_gelu.dy")
+        n, c, h, w = x.shape
+        hd = w1.shape[0]
+        dx = torch.empty_like(x)
+        grads, outs = [], []
+        for sink, like in zip(ctx.sinks, (w1, b1, w2, None)):
+            if sink is not None:
+                grads.append(sink)
+                outs.append(None)
+            else:
+                t = torch.zeros(c, device=x.device) if like is None else torch.zeros_like(like)
+                grads.append(t)
+                outs.append(t)
+        ws_n = lib.pg_mlp_gelu_bwd_workspace_floats(n, h * w)
+        ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
+        _lib.check(
+            lib.pg_mlp_gelu_bwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                dy.data_ptr(), dx.data_ptr(), grads[0].data_ptr(),
+                                grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), n, c,
+                                hd, h * w, ws.data_ptr(), ws_n, _stream()),
+            "pg_mlp_gelu_bwd",
+        )
+        return dx, outs[0], outs[1], outs[2], outs[3], (dy if ctx.has_res else None), None
+
+
+def mlp_gelu(x, conv1, conv2, res=None):
+    """res + conv2(gelu(conv1(x))) for two 1x1 convolutions, hidden activations kept in registers
+    (check mlp_gelu_supported first)."""
+    sinks = (_sink(conv1.weight), _sink(conv1.bias), _sink(conv2.weight), _sink(conv2.bias))
+    return _MlpGelu.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias, res, sinks)
+
+
+# --------------------------------------------------------------------------------------------
 # NCHW LayerNorm
 # --------------------------------------------------------------------------------------------
 class _NCHWLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, gg, gb):
+    def forward(ctx, x, gamma, beta, eps, gg, gb, with_skip=False):
         lib = _lib.load()
+        x_in = x
         x = _chk(x, "layernorm.x")
         n, c, h, w = x.shape
         if gamma.numel() != c:
@@ -228,12 +372,19 @@ class _NCHWLayerNorm(torch.autograd.Function):
         )
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.gg, ctx.gb = gg, gb
+        if with_skip:
+            # second output: x itself (autograd aliases it). Whatever gradient reaches x through this
+            # alias — the residual branch of `x + f(LN(x))` — is added in the backward kernel's
+            # epilogue instead of by a separate accumulation pass over the activation.
+            return y, x_in
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         lib = _lib.load()
         x, gamma, mean, rstd = ctx.saved_tensors
+        if dy is None:  # only the skip output was used
+            return dskip, None, None, None, None, None, None
         dy = _chk(dy, "layernorm.dy")
         n, c, h, w = x.shape
         dx = torch.empty_like(x)
@@ -247,17 +398,33 @@ class _NCHWLayerNorm(torch.autograd.Function):
             gb = db
         ws_n = lib.pg_nchw_layernorm_bwd_workspace_floats(n, c, h * w)
         ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
-        _lib.check(
-            lib.pg_nchw_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                      rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), gg.data_ptr(),
-                                      gb.data_ptr(), n, c, h * w, ws.data_ptr(), ws_n, _stream()),
-            "pg_nchw_layernorm_bwd",
-        )
-        return dx, dg, db, None, None, None
+        if dskip is None:
+            _lib.check(
+                lib.pg_nchw_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), gg.data_ptr(),
+                                          gb.data_ptr(), n, c, h * w, ws.data_ptr(), ws_n, _stream()),
+                "pg_nchw_layernorm_bwd",
+            )
+        else:
+            dskip = _chk(dskip, "layernorm.dskip")
+            _lib.check(
+                lib.pg_nchw_layernorm_bwd_res(x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                              rstd.data_ptr(), dy.data_ptr(), dskip.data_ptr(),
+                                              dx.data_ptr(), gg.data_ptr(), gb.data_ptr(), n, c,
+                                              h * w, ws.data_ptr(), ws_n, _stream()),
+                "pg_nchw_layernorm_bwd_res",
+            )
+        return dx, dg, db, None, None, None, None
 
 
 def nchw_layernorm(x, weight, bias, eps=1e-5):
     return _NCHWLayerNorm.apply(x, weight, bias, float(eps), _sink(weight), _sink(bias))
+
+
+def nchw_layernorm_skip(x, weight, bias, eps=1e-5):
+    """(LN(x), x): use the second output for the residual branch of `x + f(LN(x))`; its gradient is
+    then added to LN's input gradient inside the backward kernel."""
+    return _NCHWLayerNorm.apply(x, weight, bias, float(eps), _sink(weight), _sink(bias), True)
 
 
 # --------------------------------------------------------------------------------------------
@@ -313,6 +480,63 @@ class _CausalAttention(torch.autograd.Function):
             "pg_causal_attn_bwd",
         )
         return dq, dkv, None, None, None, None
+
+
+class _CausalAttentionQKV(torch.autograd.Function):
+    """Same core on ONE (N, embed + embed + vdim, H, W) tensor [q | k | v] — the output of the merged
+    q/kv projection (conv2d_pair); its gradient is produced as one tensor of the same layout."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_heads, embed, vdim, strict):
+        lib = _lib.load()
+        qkv = _chk(qkv, "attention.qkv")
+        n, ch, h, w = qkv.shape
+        if ch != 2 * embed + vdim:
+            raise ValueError("attention: qkv channel count != 2 * embed + value dims")
+        if embed % n_heads or vdim % n_heads:
+            raise ValueError("attention: channels not divisible by n_heads")
+        L = h * w
+        dk, dv = embed // n_heads, vdim // n_heads
+        o = torch.empty((n, vdim, h, w), device=qkv.device, dtype=torch.float32)
+        lse2 = torch.empty((n, n_heads, L), device=qkv.device, dtype=torch.float32)
+        base, bs = qkv.data_ptr(), ch * L
+        _lib.check(
+            lib.pg_causal_attn_fwd(base, base + 4 * embed * L, base + 8 * embed * L, o.data_ptr(),
+                                   lse2.data_ptr(), n, n_heads, L, dk, dv, bs, bs, bs, vdim * L,
+                                   int(strict), _stream()),
+            "pg_causal_attn_fwd",
+        )
+        ctx.save_for_backward(qkv, o, lse2)
+        ctx.cfg = (n_heads, embed, vdim, int(strict))
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        lib = _lib.load()
+        qkv, o, lse2 = ctx.saved_tensors
+        n_heads, embed, vdim, strict = ctx.cfg
+        d_o = _chk(d_o, "attention.d_o")
+        n, ch, h, w = qkv.shape
+        L = h * w
+        dk, dv = embed // n_heads, vdim // n_heads
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse2)
+        base, gbase, bs = qkv.data_ptr(), dqkv.data_ptr(), ch * L
+        _lib.check(
+            lib.pg_causal_attn_bwd(
+                base, base + 4 * embed * L, base + 8 * embed * L, o.data_ptr(), d_o.data_ptr(),
+                lse2.data_ptr(), delta.data_ptr(), gbase, gbase + 4 * embed * L,
+                gbase + 8 * embed * L, n, n_heads, L, dk, dv, bs, bs, bs, vdim * L, vdim * L, bs, bs,
+                bs, strict, _stream(),
+            ),
+            "pg_causal_attn_bwd",
+        )
+        return dqkv, None, None, None, None
+
+
+def causal_attention_qkv(qkv, n_heads, embed_channels, value_channels, mask_center):
+    """causal_attention on the merged [q | k | v] tensor."""
+    return _CausalAttentionQKV.apply(qkv, n_heads, embed_channels, value_channels, bool(mask_center))
 
 
 def causal_attention(q, kv, n_heads, embed_channels, value_channels, mask_center):

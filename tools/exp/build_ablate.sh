@@ -9,7 +9,7 @@ OBJ=pytorch-generative_amd/build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-fp-atomics -Ipytorch-generative_amd/csrc"
 others=$(ls $OBJ/*.o | grep -v attention_mfma.o)
 for v in 1 2 3 4; do
-  tmp=pytorch-generative_amd/csrc/_abl$v.hip
+  tmp=/tmp/_abl$v.hip
   cp $SRC $tmp
   python3 - $tmp $v <<'PY'
 import sys,re
