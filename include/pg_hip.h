@@ -224,6 +224,40 @@ int pg_mlp_gelu_bwd(const float* x, const float* w1, const float* b1, const floa
 size_t pg_mlp_gelu_bwd_workspace_floats(int N, int L);
 
 /* ---------------------------------------------------------------------------------------
+ * Everything of an ImageGPT transformer block except the attention core, fused (gpt_block.hip).
+ * models/autoregressive/image_gpt.py:21-52 and the model loop :104-109, C = 16, hidden Hd = 64:
+ *   head: qkv (N,48,L) = [W_q; W_kv] LN1(x) + [b_q; b_kv]       (_ln1, _attn._q, _attn._kv)
+ *   tail: x_mid = x + W_p o + b_p ; x_new = x + x_mid + W_2 gelu(W_1 LN2(x_mid) + b_1) + b_2
+ *         (_attn._proj + residual, _ln2, _out, residual, and the model loop's `x = x + block(x)`)
+ * Backward recomputes x_mid, the LayerNorms and the hidden activations from (x, o).
+ *   tail_bwd: dx_new -> d_o (gradient of the attention output) and gx (all of dx_new that reaches x
+ *             except through LN1); head_bwd: dx = LN1'(W^T dqkv) + gx.
+ * Parameter gradients are ADDED to (partial rows in `workspace` + deterministic reduce).
+ * Instantiated for C = 16, Hd = 64, L % 16 == 0 (PG_ESHAPE otherwise: run the unfused operators).
+ * dqkv, o and dx_new must be 16-byte aligned.
+ * ------------------------------------------------------------------------------------- */
+int pg_gpt_block_head_fwd(const float* x, const float* ln_w, const float* ln_b, const float* wq,
+                          const float* bq, const float* wkv, const float* bkv, float* qkv, int N,
+                          int C, int L, float eps, void* stream);
+int pg_gpt_block_head_bwd(const float* x, const float* ln_w, const float* ln_b, const float* wq,
+                          const float* wkv, const float* dqkv, const float* gx, float* dx,
+                          float* dln_w, float* dln_b, float* dwq, float* dbq, float* dwkv,
+                          float* dbkv, int N, int C, int L, float eps, float* workspace,
+                          size_t workspace_floats, void* stream);
+size_t pg_gpt_block_head_bwd_workspace_floats(int N, int L);
+int pg_gpt_block_tail_fwd(const float* o, const float* x, const float* wp, const float* bp,
+                          const float* ln_w, const float* ln_b, const float* w1, const float* b1,
+                          const float* w2, const float* b2, float* x_new, int N, int C, int Hd,
+                          int L, float eps, void* stream);
+int pg_gpt_block_tail_bwd(const float* o, const float* x, const float* wp, const float* bp,
+                          const float* ln_w, const float* ln_b, const float* w1, const float* b1,
+                          const float* w2, const float* dx_new, float* d_o, float* gx, float* dwp,
+                          float* dbp, float* dln_w, float* dln_b, float* dw1, float* db1,
+                          float* dw2, float* db2, int N, int C, int Hd, int L, float eps,
+                          float* workspace, size_t workspace_floats, void* stream);
+size_t pg_gpt_block_tail_bwd_workspace_floats(int N, int L);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser step as timed by the reference (trainer.py:183-191): global grad L2 norm
  * (clip_grad_norm_) + torch.optim.Adam over ONE flat parameter/grad buffer.
  * state (device, 8 floats): [0]=step count, [1]=lr, [2]=sum of squares (scratch),

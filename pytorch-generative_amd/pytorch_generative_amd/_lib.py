@@ -43,6 +43,12 @@ SIGNATURES = {
     "pg_nchw_layernorm_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_flt, c_s]),
     "pg_nchw_layernorm_bwd": (
         c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_z, c_s]),
+    "pg_gpt_block_head_fwd": (c_i, [c_f] * 8 + [c_i, c_i, c_i, c_flt, c_s]),
+    "pg_gpt_block_head_bwd": (c_i, [c_f] * 14 + [c_i, c_i, c_i, c_flt, c_f, c_z, c_s]),
+    "pg_gpt_block_head_bwd_workspace_floats": (c_z, [c_i, c_i]),
+    "pg_gpt_block_tail_fwd": (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_i, c_flt, c_s]),
+    "pg_gpt_block_tail_bwd": (c_i, [c_f] * 20 + [c_i, c_i, c_i, c_i, c_flt, c_f, c_z, c_s]),
+    "pg_gpt_block_tail_bwd_workspace_floats": (c_z, [c_i, c_i]),
     "pg_mlp_gelu_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_s]),
     "pg_mlp_gelu_bwd": (
         c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_z, c_s]),

@@ -32,6 +32,21 @@ class TransformerBlock(nn.Module):
             pg_nn.Conv2d(in_channels=4 * n_channels, out_channels=n_channels, kernel_size=1),
         )
 
+    def _fused_ok(self, x):
+        return ops.gpt_block_supported(x, self._ln1, self._attn._q, self._attn._kv, self._attn._proj,
+                                       self._ln2, self._out[0], self._out[2])
+
+    def forward_plus_input(self, x):
+        """x + self(x) — what the model loop computes (reference image_gpt.py:107) — on the fused
+        head / attention / tail kernels (gpt_block.hip) when the block has the BASELINE shape."""
+        if not self._fused_ok(x):
+            return ops.add(x, self.forward(x))
+        attn = self._attn
+        qkv, xs = ops.gpt_block_head(x, self._ln1, attn._q, attn._kv)
+        o = ops.causal_attention_qkv(qkv, attn._n_heads, attn._embed_channels, attn._out_channels,
+                                     attn._mask_center)
+        return ops.gpt_block_tail(o, xs, attn._proj, self._ln2, self._out[0], self._out[2])
+
     def forward(self, x):
         # skip=True: the residual branch's gradient is added inside the LayerNorm backward kernel
         y, x = self._ln1(x, skip=True)
@@ -77,5 +92,5 @@ class ImageGPT(base.AutoregressiveModel):
     def forward(self, x):
         x = self._input(ops.add_broadcast_batch(x, self._pos))
         for block in self._transformer:
-            x = ops.add(x, block(x))
+            x = block.forward_plus_input(x)
         return self._out(self._ln(x))

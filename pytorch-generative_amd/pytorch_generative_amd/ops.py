@@ -351,6 +351,142 @@ def mlp_gelu(x, conv1, conv2, res=None):
 
 
 # --------------------------------------------------------------------------------------------
+# ImageGPT transformer block minus the attention core: fused head / tail (gpt_block.hip)
+# --------------------------------------------------------------------------------------------
+FUSE_BLOCK = os.environ.get("PG_FUSE_BLOCK", "1") != "0"
+
+
+def _grad_targets(params):
+    """Per parameter: (tensor the kernel adds into, value to return to autograd): the direct sink if
+    the parameter has one (then autograd gets None), else a fresh zero tensor."""
+    tgt, ret = [], []
+    for p in params:
+        sink = _sink(p)
+        if sink is not None:
+            tgt.append(sink)
+            ret.append(None)
+        else:
+            z = torch.zeros_like(p)
+            tgt.append(z)
+            ret.append(z)
+    return tgt, ret
+
+
+class _GPTBlockHead(torch.autograd.Function):
+    """(qkv, x) = ([W_q; W_kv] LN1(x) + b, x). The second output aliases x: whatever gradient reaches it
+    (the residual routes of the block) is added to LN1's input gradient inside the backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, lnw, lnb, wq, bq, wkv, bkv, eps, params):
+        lib = _lib.load()
+        x_in = x
+        x = _chk(x, "gpt_block_head.x")
+        n, c, h, w = x.shape
+        qkv = torch.empty((n, 3 * c, h, w), device=x.device, dtype=torch.float32)
+        _lib.check(
+            lib.pg_gpt_block_head_fwd(x.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), wq.data_ptr(),
+                                      bq.data_ptr(), wkv.data_ptr(), bkv.data_ptr(), qkv.data_ptr(),
+                                      n, c, h * w, eps, _stream()),
+            "pg_gpt_block_head_fwd",
+        )
+        ctx.save_for_backward(x, lnw, lnb, wq, wkv)
+        ctx.eps, ctx.params = eps, params
+        return qkv, x_in
+
+    @staticmethod
+    def backward(ctx, dqkv, gx):
+        lib = _lib.load()
+        x, lnw, lnb, wq, wkv = ctx.saved_tensors
+        n, c, h, w = x.shape
+        if dqkv is None:
+            return gx, None, None, None, None, None, None, None, None
+        dqkv = _chk(dqkv, "gpt_block_head.dqkv")
+        gx = torch.zeros_like(x) if gx is None else _chk(gx, "gpt_block_head.gx")
+        dx = torch.empty_like(x)
+        tgt, ret = _grad_targets(ctx.params)  # order: lnw, lnb, wq, bq, wkv, bkv
+        ws_n = lib.pg_gpt_block_head_bwd_workspace_floats(n, h * w)
+        ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
+        _lib.check(
+            lib.pg_gpt_block_head_bwd(x.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), wq.data_ptr(),
+                                      wkv.data_ptr(), dqkv.data_ptr(), gx.data_ptr(), dx.data_ptr(),
+                                      tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr(),
+                                      tgt[3].data_ptr(), tgt[4].data_ptr(), tgt[5].data_ptr(), n, c,
+                                      h * w, ctx.eps, ws.data_ptr(), ws_n, _stream()),
+            "pg_gpt_block_head_bwd",
+        )
+        return (dx, *ret, None, None)
+
+
+class _GPTBlockTail(torch.autograd.Function):
+    """x_new = x + x_mid + mlp(LN2(x_mid)), x_mid = x + W_p o + b_p (projection, both residuals of the
+    block and the model loop's `x + block(x)`)."""
+
+    @staticmethod
+    def forward(ctx, o, x, wp, bp, lnw, lnb, w1, b1, w2, b2, eps, params):
+        lib = _lib.load()
+        o = _chk(o, "gpt_block_tail.o")
+        x = _chk(x, "gpt_block_tail.x")
+        n, c, h, w = x.shape
+        x_new = torch.empty_like(x)
+        _lib.check(
+            lib.pg_gpt_block_tail_fwd(o.data_ptr(), x.data_ptr(), wp.data_ptr(), bp.data_ptr(),
+                                      lnw.data_ptr(), lnb.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                      w2.data_ptr(), b2.data_ptr(), x_new.data_ptr(), n, c,
+                                      w1.shape[0], h * w, eps, _stream()),
+            "pg_gpt_block_tail_fwd",
+        )
+        ctx.save_for_backward(o, x, wp, bp, lnw, lnb, w1, b1, w2)
+        ctx.eps, ctx.params = eps, params
+        return x_new
+
+    @staticmethod
+    def backward(ctx, d):
+        lib = _lib.load()
+        o, x, wp, bp, lnw, lnb, w1, b1, w2 = ctx.saved_tensors
+        d = _chk(d, "gpt_block_tail.dx_new")
+        n, c, h, w = x.shape
+        d_o, gx = torch.empty_like(o), torch.empty_like(x)
+        tgt, ret = _grad_targets(ctx.params)  # order: wp, bp, lnw, lnb, w1, b1, w2, b2
+        ws_n = lib.pg_gpt_block_tail_bwd_workspace_floats(n, h * w)
+        ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
+        _lib.check(
+            lib.pg_gpt_block_tail_bwd(o.data_ptr(), x.data_ptr(), wp.data_ptr(), bp.data_ptr(),
+                                      lnw.data_ptr(), lnb.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                      w2.data_ptr(), d.data_ptr(), d_o.data_ptr(), gx.data_ptr(),
+                                      tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr(),
+                                      tgt[3].data_ptr(), tgt[4].data_ptr(), tgt[5].data_ptr(),
+                                      tgt[6].data_ptr(), tgt[7].data_ptr(), n, c, w1.shape[0], h * w,
+                                      ctx.eps, ws.data_ptr(), ws_n, _stream()),
+            "pg_gpt_block_tail_bwd",
+        )
+        return (d_o, gx, *ret, None, None)
+
+
+def gpt_block_supported(x, ln1, q, kv, proj, ln2, fc1, fc2):
+    """The fused block kernels cover the BASELINE.json ImageGPT block: 16 channels, 1x1 projections
+    with biases, 64 hidden units, L % 16 == 0."""
+    if not FUSE_BLOCK or x.shape[1] != 16 or (x.shape[2] * x.shape[3]) % 16 != 0:
+        return False
+    shapes = (tuple(q.weight.shape), tuple(kv.weight.shape), tuple(proj.weight.shape),
+              tuple(fc1.weight.shape), tuple(fc2.weight.shape))
+    if shapes != ((16, 16, 1, 1), (32, 16, 1, 1), (16, 16, 1, 1), (64, 16, 1, 1), (16, 64, 1, 1)):
+        return False
+    if any(m.bias is None for m in (q, kv, proj, fc1, fc2)):
+        return False
+    return tuple(ln1.normalized_shape) == (16,) and tuple(ln2.normalized_shape) == (16,)
+
+
+def gpt_block_head(x, ln1, q, kv):
+    params = (ln1.weight, ln1.bias, q.weight, q.bias, kv.weight, kv.bias)
+    return _GPTBlockHead.apply(x, *params, float(ln1.eps), params)
+
+
+def gpt_block_tail(o, x, proj, ln2, fc1, fc2):
+    params = (proj.weight, proj.bias, ln2.weight, ln2.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+    return _GPTBlockTail.apply(o, x, *params, float(ln2.eps), params)
+
+
+# --------------------------------------------------------------------------------------------
 # NCHW LayerNorm
 # --------------------------------------------------------------------------------------------
 class _NCHWLayerNorm(torch.autograd.Function):

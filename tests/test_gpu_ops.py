@@ -358,3 +358,32 @@ def test_fused_mlp_gelu_matches_unfused_oracle(dev, n, h, w, use_res):
         _util.assert_close(rg.grad, ro.grad, TOL, "mlp dres")
     for got, want, name in zip((c1.weight, c1.bias, c2.weight, c2.bias), ps, ("dw1", "db1", "dw2", "db2")):
         _util.assert_close(got.grad, want.grad, TOL, f"mlp {name}")
+
+
+@pytest.mark.parametrize("n,hw", [(2, 28), (1, 4), (3, 12)])
+def test_fused_gpt_block_matches_operator_composition(dev, n, hw):
+    """forward_plus_input (head / attention / tail kernels of gpt_block.hip) against the same block
+    evaluated operator by operator: output, input gradient and all 16 parameter gradients."""
+    from pytorch_generative_amd import ops
+    from pytorch_generative_amd.models import image_gpt
+
+    torch.manual_seed(0)
+    blk = image_gpt.TransformerBlock(16, 4).to(dev)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    x = _rand(n, 16, hw, hw, seed=1).to(dev)
+    d = _rand(n, 16, hw, hw, seed=2).to(dev)
+    xa = x.clone().requires_grad_(True)
+    assert blk._fused_ok(xa)
+    ya = blk.forward_plus_input(xa)
+    ya.backward(d)
+    ga = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    blk.zero_grad()
+    xb = x.clone().requires_grad_(True)
+    yb = ops.add(xb, blk.forward(xb))
+    yb.backward(d)
+    _util.assert_close(ya, yb, TOL, "block fwd")
+    _util.assert_close(xa.grad, xb.grad, TOL, "block dx")
+    for k, p in blk.named_parameters():
+        _util.assert_close(ga[k], p.grad, TOL, f"block grad {k}")
