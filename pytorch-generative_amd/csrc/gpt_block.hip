@@ -294,22 +294,37 @@ __global__ void __launch_bounds__(GB_THREADS) tail_bwd_kernel(const BlockArgs a)
   float* ty = th + HD * TS;                              // LN2^T   [16][TS]
   float* tx = ty + C * TS;                               // dx_mid^T[16][TS]
 
-  float wpf[4], wpt[4], w1f[4][4], w2t[4][4], w1t[4][4];
-  f32x4 b1r[4];
+  // Weight fragments depend on the lane only, not on the wave or the tile: the workgroup keeps ONE
+  // copy in LDS ([fragment][lane], conflict-free ds_read_b32) instead of 64 VGPRs per lane — with
+  // them in registers the kernel needs 316 registers (one wave per SIMD, measured 196 us per launch).
+  //   w1f[m][r] = W1[16m+j][4g+r]      A[i = hidden 16m+j][k <-> c 4g+r]       (H recompute)
+  //   w2t[m][r] = W2[4g+r][16m+j]      A[i = hidden 16m+j][k <-> co 4g+r]      (dG = W_2^T D)
+  //   w1t[m][r] = W1[16m+4g+r][j]      A[i = c j][k <-> hidden 16m+4g+r]       (dY = W_1^T dH)
+  //   b1r[m][r] = b1[16m+4g+r]
+  float* wl = lds + (size_t)4 * (2 * HD + 2 * C) * TS;  // [64 fragments][64 lanes]
+  if (wv == 0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        wl[(0 + 4 * m + r) * 64 + lane] = a.w1[(16 * m + j) * C + 4 * g + r];
+        wl[(16 + 4 * m + r) * 64 + lane] = a.w2[(4 * g + r) * HD + 16 * m + j];
+        wl[(32 + 4 * m + r) * 64 + lane] = a.w1[(16 * m + 4 * g + r) * C + j];
+        wl[(48 + 4 * m + r) * 64 + lane] = a.b1[16 * m + 4 * g + r];
+      }
+    }
+  }
+  __syncthreads();
+  const float* wlane = wl + lane;
+#define W1F(m, r) wlane[(0 + 4 * (m) + (r)) * 64]
+#define W2T(m, r) wlane[(16 + 4 * (m) + (r)) * 64]
+#define W1T(m, r) wlane[(32 + 4 * (m) + (r)) * 64]
+#define B1R(m, r) wlane[(48 + 4 * (m) + (r)) * 64]
+  float wpf[4], wpt[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     wpf[r] = a.wp[j * C + 4 * g + r];    // A[i = co j][k <-> ci 4g+r]      (x_mid recompute)
     wpt[r] = a.wp[(4 * g + r) * C + j];  // A[i = ci j][k <-> co 4g+r]      (d_o = W_p^T d x_mid)
-  }
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      w1f[m][r] = a.w1[(16 * m + j) * C + 4 * g + r];      // H recompute
-      w2t[m][r] = a.w2[(4 * g + r) * HD + 16 * m + j];     // A[i = hidden 16m+j][k <-> co 4g+r]: dG = W_2^T D
-      w1t[m][r] = a.w1[(16 * m + 4 * g + r) * C + j];      // A[i = c j][k <-> hidden 16m+4g+r]: dY = W_1^T dH
-      b1r[m][r] = a.b1[16 * m + 4 * g + r];
-    }
   }
   const f32x4 bpv = load_vec(a.bp, g);
   const f32x4 gam = load_vec(a.g2, g), bet = load_vec(a.be2, g);
@@ -345,12 +360,12 @@ __global__ void __launch_bounds__(GB_THREADS) tail_bwd_kernel(const BlockArgs a)
     f32x4 h[4], dg[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      h[m] = b1r[m];
+      h[m] = f32x4{B1R(m, 0), B1R(m, 1), B1R(m, 2), B1R(m, 3)};
       dg[m] = zero4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        h[m] = MFMA16(w1f[m][r], y[r], h[m]);
-        dg[m] = MFMA16(w2t[m][r], dv[r], dg[m]);
+        h[m] = MFMA16(W1F(m, r), y[r], h[m]);
+        dg[m] = MFMA16(W2T(m, r), dv[r], dg[m]);
       }
     }
     // ---- G, dH = dG * gelu'(H); dY = W_1^T dH
@@ -367,7 +382,7 @@ __global__ void __launch_bounds__(GB_THREADS) tail_bwd_kernel(const BlockArgs a)
         tg[hid * TS + j] = hv * cdf;
         th[hid * TS + j] = dh;
         db1[m][r] += dh;
-        dy = MFMA16(w1t[m][r], dh, dy);
+        dy = MFMA16(W1T(m, r), dh, dy);
       }
     }
     // ---- LN2 backward, d x_mid = D + LN2'(dY)
@@ -412,6 +427,10 @@ __global__ void __launch_bounds__(GB_THREADS) tail_bwd_kernel(const BlockArgs a)
     }
   }
 
+#undef W1F
+#undef W2T
+#undef W1T
+#undef B1R
   // ---- one partial row per workgroup
   __syncthreads();
   float* mine = lds + (size_t)wv * T_PART;
@@ -598,8 +617,15 @@ PG_EXPORT int pg_gpt_block_tail_bwd(const float* o, const float* x, const float*
   set_geometry(a, N, L, eps);
   const int blocks = bwd_blocks(N, L);
   hipStream_t st = (hipStream_t)stream;
-  const size_t tr = (size_t)4 * (2 * HD + 2 * C) * TS, rd = (size_t)4 * T_PART;
-  hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)blocks), dim3(GB_THREADS), (tr > rd ? tr : rd) * sizeof(float), st, a);
+  const size_t tr = (size_t)4 * (2 * HD + 2 * C) * TS + 64 * 64, rd = (size_t)4 * T_PART;
+  const size_t shmem = (tr > rd ? tr : rd) * sizeof(float);  // 66.4 KB: above the 64 KB default
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)blocks), dim3(GB_THREADS), shmem, st, a);
   PG_LAUNCH_CHECK("pg_gpt_block_tail_bwd");
   SegArgs r = {};
   r.part = workspace; r.rows = blocks; r.stride = T_PART; r.nseg = 8;

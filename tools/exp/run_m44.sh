@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
 {
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -15
-for cfg in 1 0 1 0; do echo "FUSE_BLOCK=$cfg"; PG_FUSE_BLOCK=$cfg timeout 300 python bench.py --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -x -q -m gpu -k "block or golden or graphed" 2>&1 | tail -4
+for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done
 } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/run.log
