@@ -304,8 +304,8 @@ def main():
         elif world == 1:
             r = attention_kernel_roofline(args.batch, device)
             out["roofline"] = {
-                "bound": "mfma",  # fp32: matrix peak == vector peak == 157.3 TF on gfx950; this
-                                  # kernel is fp32 VALU/exp bound
+                "bound": "mfma",  # fp32: matrix peak == vector peak == 157.3 TF on gfx950; the
+                                  # kernel is fp32-MFMA + v_exp issue bound
                 "kernel": "attn_dkv_m44_kernel (pg_causal_attn_bwd_dkv)",
                 "achieved": r["dkv"]["tflops"],
                 "peak": FP32_PEAK_TFLOPS,

@@ -4,8 +4,8 @@ traffic of every kernel from the FETCH_SIZE / WRITE_SIZE PMC passes.
 
 Units/corrections (MI355X_MICROARCH.md §HBM): counters are KiB; on gfx950 FETCH_SIZE reports 1/2 of
 the bytes of wide coalesced reads. Calibrated in the same run on a kernel with a known byte count
-(ATen's float4 add: reads 2*n*4 B, writes n*4 B): read factor and write factor are stored next to
-the numbers."""
+(head_fwd_kernel of gpt_block.hip: reads x = N*16*L*4 B, writes qkv = N*48*L*4 B, nothing else of
+size): read factor and write factor are stored next to the numbers."""
 import json
 import os
 import shutil
@@ -25,10 +25,10 @@ def per_launch(tag, counter):
 
 
 fetch, write = per_launch("fetch", "FETCH_SIZE"), per_launch("write", "WRITE_SIZE")
-add = [k for k in fetch if "CUDAFunctor_add<float>" in k][0]
-n_add = batch * 16 * 784  # the residual-gradient adds are (B,16,28,28)
-read_factor = (2 * n_add * 4) / (fetch[add] * 1024)
-write_factor = (n_add * 4) / (write[add] * 1024)
+add = [k for k in fetch if "head_fwd_kernel" in k][0]
+n_px = batch * 784  # pixels per launch
+read_factor = (n_px * 16 * 4) / (fetch[add] * 1024)
+write_factor = (n_px * 48 * 4) / (write[add] * 1024)
 table = {}
 for k in fetch:
     table[k] = {
