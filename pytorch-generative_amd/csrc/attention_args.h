@@ -15,6 +15,11 @@ struct PgAttnArgs {
                         // sized so that a whole (n, head) fits when LDS allows: barriers between
                         // tiles would re-serialise the balanced pairing
   int lp, vec;          // MFMA kernels: LDS plane stride (== 16 mod 64); float4 staging allowed
+  // MFMA kernels: the 64-row blocks each wave of the workgroup processes, heaviest first (LPT
+  // assignment made on the host so that every wave — and with a wave count that is a multiple of 4,
+  // every SIMD — gets the same share of the causal triangle)
+  unsigned char bcount[8];
+  unsigned char blist[8][16];
 };
 
 enum { PG_ATTN_FWD = 0, PG_ATTN_DQ = 1, PG_ATTN_DKV = 2 };

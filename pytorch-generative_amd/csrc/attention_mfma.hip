@@ -33,6 +33,9 @@
 // independent MFMA/exp chains); blocks are handed out in balanced pairs exactly as in attention.hip.
 // Measured (N=1024, 4 heads, L=784): fwd 0.40 ms, dQ 0.47 ms, dK/dV 0.59 ms vs 0.62 / 0.65 / 0.69 ms
 // for the VALU row-owner kernels; ~0.14 ms of each is staging, per-block set-up and the diagonal.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "attention_args.h"
@@ -160,32 +163,6 @@ __device__ __forceinline__ float gmax(float x) {
   return fmaxf(x, __shfl_xor(x, 32, 64));
 }
 
-// Copy rows [r0, r1) (multiples of 16) of `nch` channel planes (global plane stride L) into LDS
-// planes of stride Lp, computing mul * x, rows >= L filled with `fill`.
-__device__ __forceinline__ void stage_planes(float* __restrict__ dst, int Lp, const float* __restrict__ src,
-                                             int nch, int L, int r0, int r1, bool vec, float mul, float fill) {
-  if (vec) {  // L % 4 == 0 and 16-byte aligned planes: a quad is entirely in or out
-    const int nq = (r1 - r0) >> 2;
-    for (int idx = threadIdx.x; idx < nch * nq; idx += blockDim.x) {
-      const int c = idx / nq;
-      const int m = r0 + 4 * (idx - c * nq);
-      float4 t = make_float4(fill, fill, fill, fill);
-      if (m < L) {
-        t = *reinterpret_cast<const float4*>(src + (size_t)c * L + m);
-        t.x *= mul; t.y *= mul; t.z *= mul; t.w *= mul;
-      }
-      *reinterpret_cast<float4*>(dst + c * Lp + m) = t;
-    }
-  } else {
-    const int nr = r1 - r0;
-    for (int idx = threadIdx.x; idx < nch * nr; idx += blockDim.x) {
-      const int c = idx / nr;
-      const int m = r0 + (idx - c * nr);
-      dst[c * Lp + m] = m < L ? src[(size_t)c * L + m] * mul : fill;
-    }
-  }
-}
-
 // Store a lane's 4 consecutive rows (row0..row0+3) of channel plane `plane`.
 __device__ __forceinline__ void store_rows4(float* __restrict__ plane, int L, int row0, bool vec,
                                             float v0, float v1, float v2, float v3) {
@@ -230,9 +207,6 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
   const int h = blockIdx.y, n = blockIdx.z;
   const int L = a.L;
   const int NB = (L + 63) >> 6;
-  const int wg = gridDim.x - 1 - blockIdx.x;  // heaviest workgroups first
-  const int first = wg * a.blocks_per_wg;
-  const int nb = min(a.blocks_per_wg, NB - first);
 
   const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
   const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
@@ -240,8 +214,8 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
   float* op = a.o_out + (size_t)n * a.o_bs + (size_t)h * 4 * L;
   float* lsep = a.lse2_out + ((size_t)n * a.heads + h) * L;
 
-  const int rows = 64 * (first + nb);
-  const int lo = first + d.wave, hi = first + nb - 1 - d.wave;
+  const int rows = 64 * NB;
+  const int nmine = a.bcount[d.wave];  // this wave's blocks: a.blist[wave][0..nmine)
   // K -> bf16x3 chunks, V -> V^T planes: one pass, all global loads of an iteration first
   for (int m0 = 0; m0 < rows; m0 += 2 * blockDim.x) {
     float kx[2][4], vx[2][4];
@@ -263,16 +237,15 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
   }
   if (threadIdx.x == 0) *ones = ones_chunk();
   __syncthreads();
-  if (lo > hi) return;
+  if (nmine == 0) return;
   // streamed-operand address of this lane: groups 0,1 -> c0[key], 2 -> c2[key], 3 -> the ones chunk
   const bf16x8* abase = g == 3 ? ones : (g == 2 ? kc2 : kc0) + qi;
   const int astride = g == 3 ? 0 : 1;
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1 && lo == hi) break;
-    const int blk = pass == 0 ? hi : lo;
+  for (int it = 0; it < nmine; ++it) {
+    const int blk = a.blist[d.wave][it];
     const int q0 = 64 * blk;
     const int ngrp = min(4, (L - q0 + 15) >> 4);  // 16-query groups of this block that exist
 
@@ -416,9 +389,6 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
   const int h = blockIdx.y, n = blockIdx.z;
   const int L = a.L;
   const int NB = (L + 63) >> 6;
-  const int wg = gridDim.x - 1 - blockIdx.x;
-  const int first = wg * a.blocks_per_wg;
-  const int nb = min(a.blocks_per_wg, NB - first);
 
   const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
   const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
@@ -428,8 +398,8 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
   float* dqp = a.dq + (size_t)n * a.dq_bs + (size_t)h * 4 * L;
   const size_t row = ((size_t)n * a.heads + h) * L;
 
-  const int rows = 64 * (first + nb);
-  const int lo = first + d.wave, hi = first + nb - 1 - d.wave;
+  const int rows = 64 * NB;
+  const int nmine = a.bcount[d.wave];  // this wave's blocks: a.blist[wave][0..nmine)
   // K, V -> bf16x3 chunks, K -> K^T planes: one pass, all global loads of an iteration first
   for (int m0 = 0; m0 < rows; m0 += 2 * blockDim.x) {
     float kx[2][4], vx[2][4];
@@ -452,7 +422,7 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
   }
   if (threadIdx.x == 0) *ones = ones_chunk();
   __syncthreads();
-  if (lo > hi) return;
+  if (nmine == 0) return;
   // streamed-operand addresses of this lane: groups 0,1 -> c0[key], 2 -> c2[key], 3 -> ones chunk
   const bf16x8* kbase = g == 3 ? ones : (g == 2 ? kc2 : kc0) + qi;
   const bf16x8* vbase = g == 3 ? ones : (g == 2 ? vc2 : vc0) + qi;
@@ -460,9 +430,8 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1 && lo == hi) break;
-    const int blk = pass == 0 ? hi : lo;
+  for (int it = 0; it < nmine; ++it) {
+    const int blk = a.blist[d.wave][it];
     const int q0 = 64 * blk;
     const int ngrp = min(4, (L - q0 + 15) >> 4);
 
@@ -561,8 +530,6 @@ __global__ void __launch_bounds__(512) attn_dkv_m44_kernel(const PgAttnArgs a) {
   const int h = blockIdx.y, n = blockIdx.z;
   const int L = a.L;
   const int NB = (L + 63) >> 6;
-  const int first = blockIdx.x * a.blocks_per_wg;  // smallest keys (most queries) first
-  const int nb = min(a.blocks_per_wg, NB - first);
 
   const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
   const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
@@ -572,8 +539,8 @@ __global__ void __launch_bounds__(512) attn_dkv_m44_kernel(const PgAttnArgs a) {
   float* dvp = a.dv + (size_t)n * a.dv_bs + (size_t)h * 4 * L;
   const size_t row = ((size_t)n * a.heads + h) * L;
 
-  const int r0 = 64 * first, r1 = 64 * NB;
-  const int lo = first + d.wave, hi = first + nb - 1 - d.wave;
+  const int r0 = 0, r1 = 64 * NB;
+  const int nmine = a.bcount[d.wave];  // this wave's key blocks: a.blist[wave][0..nmine)
   // q, dO -> planes, -lse2, -delta: one pass, all global loads of an iteration first
   for (int m0 = r0; m0 < r1; m0 += 2 * blockDim.x) {
     float qx[2][4], gx[2][4], lx[2], dx[2];
@@ -601,14 +568,13 @@ __global__ void __launch_bounds__(512) attn_dkv_m44_kernel(const PgAttnArgs a) {
     }
   }
   __syncthreads();
-  if (lo > hi) return;
+  if (nmine == 0) return;
   const int q_end = ((L + 15) >> 4) << 4;
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1 && lo == hi) break;
-    const int blk = pass == 0 ? lo : hi;
+  for (int it = 0; it < nmine; ++it) {
+    const int blk = a.blist[d.wave][it];
     const int kb0 = 64 * blk;
     const int ngrp = min(4, (L - kb0 + 15) >> 4);
 
@@ -705,32 +671,59 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+// waves per workgroup: forward / dK,dV use 4 (a multiple of the 4 SIMDs; 3-4 workgroups per CU),
+// dQ (68 KB of LDS: two workgroups per CU) 8. PG_ATTN_WAVES="f,q,k" overrides for tuning.
+static void attn_waves(int* w) {
+  static int cfg[3] = {0, 0, 0};
+  if (cfg[0] == 0) {
+    cfg[0] = 4; cfg[1] = 8; cfg[2] = 4;
+    if (const char* e = getenv("PG_ATTN_WAVES")) {
+      int f = 0, q = 0, k = 0;
+      if (sscanf(e, "%d,%d,%d", &f, &q, &k) == 3 && f >= 1 && f <= 8 && q >= 1 && q <= 8 && k >= 1 && k <= 8) {
+        cfg[0] = f; cfg[1] = q; cfg[2] = k;
+      }
+    }
+  }
+  w[0] = cfg[0]; w[1] = cfg[1]; w[2] = cfg[2];
+}
+
 int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   if (a0.dk_dim != 4 || a0.dv_dim != 4) return 0;
   PgAttnArgs a = a0;
   const int NB = (a.L + 63) / 64;
-  const int bpw = NB < 16 ? NB : 16;
-  a.blocks_per_wg = bpw;
   a.lp = 64 * NB + 16;  // plane stride == 16 (mod 64): conflict-free b32 and b128 fragment reads
   // in 4-byte units per row — fwd: K chunks (2 x 16 B) + V^T planes; dQ: K and V chunks + K^T planes;
   // dK/dV: 10 planes; plus the ones chunk
   const size_t planes = which == PG_ATTN_DKV ? 10 : (which == PG_ATTN_DQ ? 20 : 12);
   const size_t shmem = planes * (size_t)a.lp * sizeof(float) + 16;
   if (shmem > 160 * 1024) return 0;
-  bool vec = a.L % 4 == 0;
+  int wcfg[3];
+  attn_waves(wcfg);
+  int W = wcfg[which];
+  if (W > NB) W = NB;
+  if ((NB + W - 1) / W > 16) return 0;  // block lists hold 16 entries per wave
+  // LPT: blocks by decreasing cost (later query blocks / earlier key blocks stream more), each to
+  // the least loaded wave
+  long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int w = 0; w < 8; ++w) a.bcount[w] = 0;
+  for (int rank = NB - 1; rank >= 0; --rank) {
+    const int blk = which == PG_ATTN_DKV ? NB - 1 - rank : rank;
+    int best = 0;
+    for (int w = 1; w < W; ++w)
+      if (load[w] < load[best] && a.bcount[w] < 16) best = w;
+    if (a.bcount[best] >= 16) return 0;
+    a.blist[best][a.bcount[best]++] = (unsigned char)blk;
+    load[best] += 4 * rank + 5;
+  }
+  a.vec = a.L % 4 == 0 ? 1 : 0;
   if (which == PG_ATTN_FWD)
-    vec = vec && aligned16(a.k) && aligned16(a.v) && aligned16(a.o_out) && a.k_bs % 4 == 0 &&
-          a.v_bs % 4 == 0 && a.o_bs % 4 == 0;
+    a.vec = a.vec && aligned16(a.o_out) && a.o_bs % 4 == 0;
   else if (which == PG_ATTN_DQ)
-    vec = vec && aligned16(a.k) && aligned16(a.v) && aligned16(a.dq) && a.k_bs % 4 == 0 &&
-          a.v_bs % 4 == 0 && a.dq_bs % 4 == 0;
+    a.vec = a.vec && aligned16(a.dq) && a.dq_bs % 4 == 0;
   else
-    vec = vec && aligned16(a.q) && aligned16(a.d_o) && aligned16(a.lse2_in) && aligned16(a.delta) &&
-          aligned16(a.dk) && aligned16(a.dv) && a.q_bs % 4 == 0 && a.do_bs % 4 == 0 &&
-          a.dk_bs % 4 == 0 && a.dv_bs % 4 == 0;
-  a.vec = vec ? 1 : 0;
-  dim3 grid((unsigned)((NB + bpw - 1) / bpw), (unsigned)a.heads, (unsigned)a.N);
-  dim3 block((unsigned)(64 * ((bpw + 1) / 2)));
+    a.vec = a.vec && aligned16(a.dk) && aligned16(a.dv) && a.dk_bs % 4 == 0 && a.dv_bs % 4 == 0;
+  dim3 grid(1u, (unsigned)a.heads, (unsigned)a.N);
+  dim3 block((unsigned)(64 * W));
   const void* fn = which == PG_ATTN_FWD  ? reinterpret_cast<const void*>(attn_fwd_m44_kernel)
                    : which == PG_ATTN_DQ ? reinterpret_cast<const void*>(attn_dq_m44_kernel)
                                          : reinterpret_cast<const void*>(attn_dkv_m44_kernel);
