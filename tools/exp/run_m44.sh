@@ -1,5 +1,8 @@
-mkdir -p gpurun_out
-{
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'])"; done
-} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/run.log
+mkdir -p gpurun_out/stats
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/stats/*
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats -o s -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/stats/log.txt 2>&1
+find $R/gpurun_out/stats -name "*kernel_trace.csv" -delete
+find $R/gpurun_out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $R/gpurun_out/stats/kernel_stats.csv
+tail -1 $R/gpurun_out/stats/log.txt | cut -c1-200
