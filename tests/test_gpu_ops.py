@@ -316,6 +316,8 @@ def test_merged_qkv_projection_matches_separate_convs(dev):
     ref = pg_nn.CausalAttention(in_channels=16, n_heads=4, embed_channels=16, out_channels=16).to(dev)
     fused = pg_nn.CausalAttention(in_channels=16, n_heads=4, embed_channels=16, out_channels=16).to(dev)
     fused.load_state_dict(ref.state_dict())
+    if not ops.FUSE_PAIR:
+        pytest.skip("PG_FUSE_PAIR=0")
     opt = optim.FlatAdam(fused.parameters(), lr=1e-3)
     assert ops.conv_pair_views(fused._q, fused._kv) is not None
     assert ops.conv_pair_views(ref._q, ref._kv) is None
@@ -349,6 +351,8 @@ def test_fused_mlp_gelu_matches_unfused_oracle(dev, n, h, w, use_res):
         yo = yo + ro
     yo.backward(dy)
     xg, rg = x.to(dev).requires_grad_(True), res.to(dev).requires_grad_(True)
+    if not ops.FUSE_MLP:
+        pytest.skip("PG_FUSE_MLP=0")
     assert ops.mlp_gelu_supported(xg, c1, c2)
     yg = ops.mlp_gelu(xg, c1, c2, res=rg if use_res else None)
     yg.backward(dy.to(dev))
@@ -375,6 +379,8 @@ def test_fused_gpt_block_matches_operator_composition(dev, n, hw):
     x = _rand(n, 16, hw, hw, seed=1).to(dev)
     d = _rand(n, 16, hw, hw, seed=2).to(dev)
     xa = x.clone().requires_grad_(True)
+    if not ops.FUSE_BLOCK:
+        pytest.skip("PG_FUSE_BLOCK=0")
     assert blk._fused_ok(xa)
     ya = blk.forward_plus_input(xa)
     ya.backward(d)

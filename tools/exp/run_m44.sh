@@ -1,8 +1,9 @@
-mkdir -p gpurun_out/stats
-cd /tmp && export TMPDIR=/tmp
+mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-rm -rf $R/gpurun_out/stats/*
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats -o s -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/stats/log.txt 2>&1
-find $R/gpurun_out/stats -name "*kernel_trace.csv" -delete
-find $R/gpurun_out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $R/gpurun_out/stats/kernel_stats.csv
-tail -1 $R/gpurun_out/stats/log.txt | cut -c1-200
+bash tools/collect_profiles.sh 1024 > gpurun_out/collect.log 2>&1
+cd $R
+{
+python bench.py > gpurun_out/bench_default.json
+tail -1 gpurun_out/bench_default.json | cut -c1-300
+python __graft_entry__.py --smoke 2>&1 | tail -1
+} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/run.log
