@@ -18,6 +18,8 @@
 // the other one is re-read from L2 in the transposed order; partial sums live in registers for all the
 // tiles of a wave, are reduced per workgroup in LDS and summed by a small second kernel (deterministic).
 // Backward recomputes x_mid, both LayerNorms and the hidden activations instead of storing them.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -493,18 +495,26 @@ __global__ void __launch_bounds__(256) seg_reduce_kernel(const SegArgs a) {
   }
 }
 
-int bwd_blocks(int N, int L) {
+// Workgroups per launch: whole rounds of resident waves (256 CUs x 4 SIMDs; the kernels hold 5 / 3 / 4 / 2
+// waves per SIMD by their register counts), at least `min_tiles` tiles per wave. which: 0 head fwd,
+// 1 head bwd, 2 tail fwd, 3 tail bwd. PG_BLOCK_GRID="a,b,c,d" overrides the caps (tuning).
+int grid_blocks(int which, int N, int L) {
+  static int cap[4] = {0, 0, 0, 0};
+  if (cap[0] == 0) {
+    cap[0] = 2048; cap[1] = 768; cap[2] = 2048; cap[3] = 512;  // measured: head bwd 79.8 us at 512, 68.9 at 768
+    if (const char* e = getenv("PG_BLOCK_GRID")) {
+      int v[4];
+      if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
+        for (int i = 0; i < 4; ++i) cap[i] = v[i];
+    }
+  }
+  const int min_tiles = (which & 1) ? 8 : 4;
   const long tiles = (long)N * (L / 16);
-  long b = (tiles + 4 * 8 - 1) / (4 * 8);  // >= 8 tiles per wave
-  if (b > 512) b = 512;
+  long b = (tiles + 4 * min_tiles - 1) / (4 * min_tiles);
+  if (b > cap[which]) b = cap[which];
   return b < 1 ? 1 : (int)b;
 }
-int fwd_blocks(int N, int L) {
-  const long tiles = (long)N * (L / 16);
-  long b = (tiles + 4 * 4 - 1) / (4 * 4);
-  if (b > 2048) b = 2048;
-  return b < 1 ? 1 : (int)b;
-}
+int bwd_blocks(int N, int L) { return grid_blocks(3, N, L); }
 
 int check_shape(const char* who, int N, int Cc, int L) {
   PG_REQUIRE(N > 0 && L > 0, PG_EINVAL, "%s: non-positive dimension", who);
@@ -523,11 +533,11 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 PG_EXPORT size_t pg_gpt_block_head_bwd_workspace_floats(int N, int L) {
   if (N <= 0 || L < 16) return 0;
-  return (size_t)bwd_blocks(N, L) * H_PART;
+  return (size_t)grid_blocks(1, N, L) * H_PART;
 }
 PG_EXPORT size_t pg_gpt_block_tail_bwd_workspace_floats(int N, int L) {
   if (N <= 0 || L < 16) return 0;
-  return (size_t)bwd_blocks(N, L) * T_PART;
+  return (size_t)grid_blocks(3, N, L) * T_PART;
 }
 
 PG_EXPORT int pg_gpt_block_head_fwd(const float* x, const float* ln_w, const float* ln_b, const float* wq,
@@ -539,7 +549,7 @@ PG_EXPORT int pg_gpt_block_head_fwd(const float* x, const float* ln_w, const flo
   BlockArgs a = {};
   a.x = x; a.g1 = ln_w; a.be1 = ln_b; a.wq = wq; a.bq = bq; a.wkv = wkv; a.bkv = bkv; a.qkv = qkv;
   set_geometry(a, N, L, eps);
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)fwd_blocks(N, L)), dim3(GB_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)grid_blocks(0, N, L)), dim3(GB_THREADS), 0, (hipStream_t)stream, a);
   PG_LAUNCH_CHECK("pg_gpt_block_head_fwd");
   return 0;
 }
@@ -560,7 +570,7 @@ PG_EXPORT int pg_gpt_block_head_bwd(const float* x, const float* ln_w, const flo
   a.x = x; a.g1 = ln_w; a.be1 = ln_b; a.wq = wq; a.wkv = wkv; a.dqkv = dqkv; a.gx = gx; a.dx = dx;
   a.part = workspace;
   set_geometry(a, N, L, eps);
-  const int blocks = bwd_blocks(N, L);
+  const int blocks = grid_blocks(1, N, L);
   hipStream_t st = (hipStream_t)stream;
   const size_t tr = (size_t)4 * C * TS, rd = (size_t)4 * H_PART;
   hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)blocks), dim3(GB_THREADS), (tr > rd ? tr : rd) * sizeof(float), st, a);
@@ -591,7 +601,7 @@ PG_EXPORT int pg_gpt_block_tail_fwd(const float* o, const float* x, const float*
   a.o = o; a.x = x; a.wp = wp; a.bp = bp; a.g2 = ln_w; a.be2 = ln_b; a.w1 = w1; a.b1 = b1; a.w2 = w2;
   a.b2 = b2; a.xnew = x_new;
   set_geometry(a, N, L, eps);
-  hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)fwd_blocks(N, L)), dim3(GB_THREADS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(tail_fwd_kernel, dim3((unsigned)grid_blocks(2, N, L)), dim3(GB_THREADS), 0, (hipStream_t)stream, a);
   PG_LAUNCH_CHECK("pg_gpt_block_tail_fwd");
   return 0;
 }

@@ -104,6 +104,10 @@ BASELINE_CONFIGS = {
     "image_gpt": ("ImageGPT", dict(in_channels=1, out_channels=1, in_size=28,
                                    n_transformer_blocks=8, n_attention_heads=4,
                                    n_embedding_channels=16), (2, 1, 28, 28)),
+    # not a BASELINE row: the fused block kernels at L = 1024 (16 blocks of 64 queries), 3 channels
+    "image_gpt_cifar": ("ImageGPT", dict(in_channels=3, out_channels=3, in_size=32,
+                                         n_transformer_blocks=2, n_attention_heads=4,
+                                         n_embedding_channels=16), (2, 3, 32, 32)),
     "gated_pixel_cnn": ("GatedPixelCNN", dict(in_channels=3, out_channels=3, n_gated=10,
                                               gated_channels=128, head_channels=32), (2, 3, 32, 32)),
     "pixel_snail": ("PixelSNAIL", dict(in_channels=3, out_channels=3, n_channels=64,
@@ -128,8 +132,9 @@ def test_baseline_config_vs_oracle(dev, name):
     x = (torch.bernoulli(torch.full(shape, 0.1307), generator=g) if shape[1] == 1
          else torch.randint(0, 256, shape, generator=g).float() / 255)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    kw = {"n_heads": kwargs["n_attention_heads"]} if name == "image_gpt" else {}
-    o_logits, o_loss, o_grads = otrain.loss_and_grads(omodels.FORWARDS[name], state, x, **kw)
+    kw = {"n_heads": kwargs["n_attention_heads"]} if name.startswith("image_gpt") else {}
+    fwd = omodels.FORWARDS["image_gpt" if name.startswith("image_gpt") else name]
+    o_logits, o_loss, o_grads = otrain.loss_and_grads(fwd, state, x, **kw)
 
     model = model.to(dev)
     xg = x.to(dev)
