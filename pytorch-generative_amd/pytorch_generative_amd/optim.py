@@ -20,6 +20,36 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def plan_layout(params):
+    """Offsets (in floats) of every parameter in the flat buffers, and the total length.
+
+    Every slice starts 16-byte aligned so float4 paths apply to each view — except that a parameter
+    which declares `_pg_follows = other` is placed directly behind `other` (no padding; `other` must
+    have a multiple of 4 elements): modules use this to get zero-copy merged views of weights they
+    want to run as one convolution (nn.CausalAttention: q and kv projections)."""
+    ids = {id(p) for p in params}
+    followers = {}
+    for p in params:
+        lead = getattr(p, "_pg_follows", None)
+        if lead is not None and id(lead) in ids and lead.numel() % 4 == 0 and id(lead) not in followers:
+            followers[id(lead)] = p
+    placed, off_of, total = set(), {}, 0
+    for p in params:
+        if id(p) in placed:
+            continue
+        lead = getattr(p, "_pg_follows", None)
+        if lead is not None and followers.get(id(lead)) is p and id(lead) not in placed:
+            continue  # placed right after its leader below
+        q = p
+        while q is not None and id(q) not in placed:
+            off_of[id(q)] = total
+            placed.add(id(q))
+            nxt = followers.get(id(q))
+            total += q.numel() if nxt is not None else (q.numel() + 3) // 4 * 4
+            q = nxt
+    return [off_of[id(p)] for p in params], total
+
+
 class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (betas, eps, bias correction; no weight decay / amsgrad) over a
     flattened parameter set, with the global grad-norm (clip_grad_norm_) fused in front.
@@ -49,30 +79,7 @@ class FlatAdam(torch.optim.Optimizer):
             if p.dtype != torch.float32 or p.device != dev:
                 raise TypeError("FlatAdam: all parameters must be float32 on one device")
         self._lib = _lib.load()
-        # 16-byte align every slice so float4 paths apply to each view. A parameter that declares
-        # `_pg_follows = other` is placed directly behind `other` (no padding): modules use this to
-        # get zero-copy merged views of weights they want to run as one convolution.
-        ids = {id(p) for p in self._params}
-        followers = {}
-        for p in self._params:
-            lead = getattr(p, "_pg_follows", None)
-            if lead is not None and id(lead) in ids and lead.numel() % 4 == 0 and id(lead) not in followers:
-                followers[id(lead)] = p
-        placed, off_of, total = set(), {}, 0
-        for p in self._params:
-            if id(p) in placed:
-                continue
-            lead = getattr(p, "_pg_follows", None)
-            if lead is not None and followers.get(id(lead)) is p and id(lead) not in placed:
-                continue  # placed right after its leader below
-            q = p
-            while q is not None and id(q) not in placed:
-                off_of[id(q)] = total
-                placed.add(id(q))
-                nxt = followers.get(id(q))
-                total += q.numel() if nxt is not None else (q.numel() + 3) // 4 * 4
-                q = nxt
-        offs = [off_of[id(p)] for p in self._params]
+        offs, total = plan_layout(self._params)
         self._offsets, self._numel = offs, total
         self.flat_param = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)

@@ -135,3 +135,39 @@ def test_flat_grad_allreduce_gloo_world2():
     for p in procs:
         p.join(120)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_flat_layout_places_declared_followers_back_to_back():
+    """optim.plan_layout: 16-byte aligned slices, `_pg_follows` pairs adjacent (what lets
+    nn.CausalAttention run its q and kv projections as one convolution over merged views)."""
+    import torch
+    from pytorch_generative_amd import nn as pg_nn, optim
+
+    attn = pg_nn.CausalAttention(in_channels=16, n_heads=4, embed_channels=16, out_channels=16)
+    extra = torch.nn.Parameter(torch.zeros(5))  # 5 elements: the next slice must be padded to 8
+    params = [extra] + list(attn.parameters())
+    offs, total = optim.plan_layout(params)
+    by = {id(p): o for p, o in zip(params, offs)}
+    assert by[id(extra)] == 0 and by[id(attn._q.weight)] == 8
+    assert by[id(attn._kv.weight)] == by[id(attn._q.weight)] + attn._q.weight.numel()
+    assert by[id(attn._kv.bias)] == by[id(attn._q.bias)] + attn._q.bias.numel()
+    spans = sorted((o, o + p.numel()) for p, o in zip(params, offs))
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), "slices overlap"
+    assert all(o % 4 == 0 for o in offs) and total >= spans[-1][1]
+    # a CausalAttention with extra kv inputs (PixelSNAIL) declares nothing: plain aligned layout
+    snail = pg_nn.CausalAttention(in_channels=8, embed_channels=4, out_channels=8, extra_input_channels=3)
+    assert not hasattr(snail._kv.weight, "_pg_follows")
+
+
+def test_adjacent_view_merges_only_contiguous_neighbours():
+    import torch
+    from pytorch_generative_amd import ops
+
+    flat = torch.arange(40, dtype=torch.float32)
+    a, b = flat[0:16].view(4, 4), flat[16:24].view(2, 4)
+    merged = ops._adjacent_view(a, b, (6, 4))
+    assert merged is not None and torch.equal(merged, flat[:24].view(6, 4))
+    merged[5, 3] = -1.0  # zero copy: writes land in the flat buffer
+    assert flat[23] == -1.0
+    assert ops._adjacent_view(a, flat[20:28].view(2, 4), (6, 4)) is None   # gap
+    assert ops._adjacent_view(a, torch.zeros(2, 4), (6, 4)) is None        # different storage
