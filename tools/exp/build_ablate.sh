@@ -20,7 +20,11 @@ if v in (1,4):
     s=s.replace('for (int k0 = 0; k0 < q0; k0 += 16) {','for (int k0 = 0; k0 < 0; k0 += 16) {')
     s=s.replace('for (int q0t = kb0 + 64; q0t < q_end; q0t += 16) {','for (int q0t = kb0 + 64; q0t < 0; q0t += 16) {')
 if v in (2,4):
-    s=re.sub(r'\n    (if \([^\n]*\) )?step\([^\n]*B<(true|false)>\{\}\);(?=\n)', lambda m: m.group(0) if 'for (' in m.group(0) else '', s)
+    lines=s.split('\n')
+    for i,l in enumerate(lines):
+        if 'step(' in l and 'auto step' not in l and ('B<true>{}' in l or 'I<1>{}, B<false>{}' in l):
+            lines[i]=l.replace('step(','noop(')
+    s='\n'.join(lines).replace('namespace {\n','#define noop(...) ((void)0)\nnamespace {\n',1)
 if v==3:
     s=re.sub(r'for \(int m0 = (0|r0); m0 < (rows|r1); m0 \+= 2 \* blockDim.x\) \{', lambda m: 'for (int m0 = 0; m0 < 0; m0 += 2 * blockDim.x) {', s)
 open(p,'w').write(s)
