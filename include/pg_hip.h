@@ -258,6 +258,25 @@ int pg_gpt_block_tail_bwd(const float* o, const float* x, const float* wp, const
 size_t pg_gpt_block_tail_bwd_workspace_floats(int N, int L);
 
 /* ---------------------------------------------------------------------------------------
+ * Incremental autoregressive sampling (models/base.py:97-120 runs H*W full forwards; the causal
+ * models need only position p per step). Activations of one position live as (channels, ld) matrices,
+ * column n = sample n, so the block kernels above apply with N = 1, L = ld.
+ *   pg_sample_embed: out[co*ld + n] = pixel (r, c) of Conv2d(w (already masked), b, padding k/2)
+ *                    applied to canvas (N,Cin,H,W) + pos (Cin,H,W or NULL)   (image_gpt.py:105)
+ *   pg_attn_decode:  qkv = rows [q (heads*dk) | k (heads*dk) | v (heads*dv)] x ld; appends k, v to
+ *                    the caches (N, heads*dk, L) / (N, heads*dv, L) at column p and writes
+ *                    o (heads*dv rows x ld) = softmax over positions <= p - strict   (attention.py:147-160)
+ * pos_dev (device int, or NULL): when given, the raster position p (and r = p / W, c = p % W) is read
+ * from it instead of the host arguments, so that one captured hipGraph can be replayed per pixel.
+ * ------------------------------------------------------------------------------------- */
+int pg_sample_embed(const float* canvas, const float* pos, const float* w, const float* b, float* out,
+                    int N, int Cin, int H, int W, int Cout, int KH, int KW, int r, int c, int ld,
+                    const int* pos_dev, void* stream);
+int pg_attn_decode(const float* qkv, float* k_cache, float* v_cache, float* o, int N, int heads,
+                   int L, int p, int dk, int dv, int ld, int strict, const int* pos_dev,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimiser step as timed by the reference (trainer.py:183-191): global grad L2 norm
  * (clip_grad_norm_) + torch.optim.Adam over ONE flat parameter/grad buffer.
  * state (device, 8 floats): [0]=step count, [1]=lr, [2]=sum of squares (scratch),

@@ -10,6 +10,7 @@ GELU, and the fused causal attention core.
 import torch
 from torch import nn
 
+from pytorch_generative_amd import _lib
 from pytorch_generative_amd import nn as pg_nn
 from pytorch_generative_amd import ops
 from pytorch_generative_amd.models import base
@@ -88,6 +89,103 @@ class ImageGPT(base.AutoregressiveModel):
         self._out = pg_nn.Conv2d(
             in_channels=n_embedding_channels, out_channels=out_channels, kernel_size=1
         )
+
+    # ---- incremental sampling -------------------------------------------------
+    def _incremental_ok(self, n):
+        ld = (n + 15) // 16 * 16
+        probe = torch.empty(1, self._input.weight.shape[0], 1, ld, device="meta")
+        return all(blk._fused_ok(probe) for blk in self._transformer) and self._input.bias is not None
+
+    @torch.no_grad()
+    def sample(self, n_samples=None, conditioned_on=None, *, incremental=True, return_logits=False):
+        """Same contract as the reference's AutoregressiveModel.sample (models/base.py:97-120: raster
+        order, only entries < 0 are drawn, `_sample_fn` called once per pixel on (n, c) logits) — but
+        each step evaluates ONLY the current position: the model is causal, so the activations of
+        pixel p are final once pixels < p are. One position of all samples is a (channels, batch)
+        matrix, i.e. the (C, L) plane layout of the block kernels with the batch as the pixel axis:
+        the fused head / tail kernels run unchanged, attention becomes a one-query-per-(n, head)
+        decode against per-layer K / V caches. The reference (and `incremental=False`) instead runs
+        one full forward per pixel: H*W times the work.
+
+        return_logits (extension): also returns the (H*W, n, c) logits the draws were made from."""
+        canvas = self._start_canvas(n_samples, conditioned_on)
+        n, c, h, w = canvas.shape
+        if not incremental or not self._incremental_ok(n):
+            if return_logits:
+                raise ValueError("return_logits needs the incremental sampler")
+            return super().sample(conditioned_on=canvas)
+        lib = _lib.load()
+        dev, L = canvas.device, h * w
+        canvas = canvas.contiguous()
+        ld = (n + 15) // 16 * 16
+        conv = self._input
+        emb = conv.weight.shape[0]
+        kh, kw = conv.weight.shape[2], conv.weight.shape[3]
+        ops.mul_inplace_(conv.weight.data, conv.mask)  # nn/convolution.py:42, as on every forward
+        blocks = list(self._transformer)
+        caches = []
+        for blk in blocks:
+            a = blk._attn
+            caches.append((torch.zeros(n, a._embed_channels, L, device=dev),
+                           torch.zeros(n, a._out_channels, L, device=dev)))
+        x = torch.zeros(1, emb, 1, ld, device=dev)
+        pos_dev = torch.zeros(1, dtype=torch.int32, device=dev)  # raster position, advanced on the device
+
+        def position_logits():
+            """logits (n, c) of the position in pos_dev; appends its keys / values to the caches"""
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(lib.pg_sample_embed(canvas.data_ptr(), self._pos.data_ptr(),
+                                           conv.weight.data_ptr(), conv.bias.data_ptr(), x.data_ptr(),
+                                           n, c, h, w, emb, kh, kw, 0, 0, ld, pos_dev.data_ptr(), st),
+                       "pg_sample_embed")
+            cur = x
+            for blk, (kc, vc) in zip(blocks, caches):
+                a = blk._attn
+                qkv, xs = ops.gpt_block_head(cur, blk._ln1, a._q, a._kv)
+                o = torch.empty(1, a._out_channels, 1, ld, device=dev)
+                _lib.check(lib.pg_attn_decode(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                              o.data_ptr(), n, a._n_heads, L, 0,
+                                              a._embed_channels // a._n_heads,
+                                              a._out_channels // a._n_heads, ld, int(a._mask_center),
+                                              pos_dev.data_ptr(), st), "pg_attn_decode")
+                cur = ops.gpt_block_tail(o, xs, a._proj, blk._ln2, blk._out[0], blk._out[2])
+            return self._out(self._ln(cur))[0, :, 0, :n].t().contiguous()
+
+        # One hipGraph = one position of every layer (~30 launches) + the position increment; only the
+        # draw (`_sample_fn` is user code) and the canvas update stay eager. Falls back to eager
+        # launches if the capture is refused.
+        graph, static_logits = None, None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                position_logits()  # warm-up at position 0 (rewrites cache column 0 with the same values)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                static_logits = position_logits()
+                pos_dev.add_(1)
+        except Exception:  # noqa: BLE001 — capture is an optimisation only
+            graph = None
+            torch.cuda.synchronize()
+        pos_dev.zero_()
+        all_logits = []
+        for row in range(h):
+            for col in range(w):
+                if graph is not None:
+                    graph.replay()
+                    logits = static_logits.clone() if return_logits else static_logits
+                else:
+                    logits = position_logits()
+                    pos_dev.add_(1)
+                if return_logits:
+                    all_logits.append(logits)
+                drawn = self._sample_fn(logits).view(n, c)
+                current = canvas[:, :, row, col]
+                canvas[:, :, row, col] = torch.where(current < 0, drawn, current)
+        if return_logits:
+            return canvas, torch.stack(all_logits)
+        return canvas
 
     def forward(self, x):
         x = self._input(ops.add_broadcast_batch(x, self._pos))
