@@ -131,6 +131,10 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
           for (int c = 0; c < NCIT; ++c)
 #pragma unroll
             for (int t = 0; t < NT; ++t) bv[c][t] = xl[b_base + c * 16 * a.S_x + toff[t] + p0];
+          // keep the 1 + NT*NCIT ds_reads together in front of the MFMAs: left alone, the scheduler
+          // interleaves them one by one (ds_read, s_waitcnt lgkmcnt(0), v_mfma, ...) to save registers
+          // and every MFMA eats a full LDS latency
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < NCIT; ++c)
 #pragma unroll
