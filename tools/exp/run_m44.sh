@@ -1,5 +1,6 @@
 mkdir -p gpurun_out
 {
-timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "conv" 2>&1 | tail -2
-for m in pixel_snail gated_pixel_cnn; do echo "model $m"; timeout 400 python bench.py --model $m --batch 128 --steps 10 --warmup 3 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done
+PG_ATTN_DKV_BF16=1 timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "attention or attn or block" 2>&1 | tail -3
+for v in 0 1 0 1; do echo "DKV_BF16=$v"; PG_ATTN_DKV_BF16=$v timeout 120 python tools/attn_kernels.py 1024; done
+echo "bf16 W=4"; PG_ATTN_DKV_BF16=1 PG_ATTN_WAVES=4,8,4 timeout 120 python tools/attn_kernels.py 1024
 } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/run.log
