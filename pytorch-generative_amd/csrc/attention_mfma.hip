@@ -471,24 +471,31 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
     auto step = [&](int k0, const Frag& f, auto TMIN_, auto MASK_) {
       constexpr int TMIN = decltype(TMIN_)::value;
       constexpr bool MASK = decltype(MASK_)::value;
-      f32x4 s[4], dp[4];
-      float ds[4][4];
+      // two query groups at a time (as in the dK/dV kernel: smaller live set, same chains)
 #pragma unroll
-      for (int t = TMIN; t < 4; ++t) {
-        s[t] = MFMA16B(f.ka, bq[t], zero4);
-        dp[t] = MFMA16B(f.va, bg[t], zero4);
-      }
+      for (int t0 = TMIN & ~1; t0 < 4; t0 += 2) {
+        f32x4 s[2], dp[2];
 #pragma unroll
-      for (int t = TMIN; t < 4; ++t) {
-        const bool cut = MASK && t == TMIN;
-        const int lim = cut ? qidx[t] - a.strict - (k0 + 4 * g) : 3;
+        for (int u = 0; u < 2; ++u) {
+          const int t = t0 + u;
+          if (t >= TMIN) {
+            s[u] = MFMA16B(f.ka, bq[t], zero4);
+            dp[u] = MFMA16B(f.va, bg[t], zero4);
+          }
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[t][r] = (!cut || r <= lim) ? ex2(s[t][r]) * dp[t][r] : 0.f;
-      }
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int t = TMIN; t < 4; ++t) acc[t] = MFMA4(ds[t][r], f.kq[r], acc[t]);
+          for (int u = 0; u < 2; ++u) {
+            const int t = t0 + u;
+            if (t >= TMIN) {
+              const bool cut = MASK && t == TMIN;
+              const int lim = cut ? qidx[t] - a.strict - (k0 + 4 * g) : 3;
+              const float ds = (!cut || r <= lim) ? ex2(s[u][r]) * dp[u][r] : 0.f;
+              acc[t] = MFMA4(ds, f.kq[r], acc[t]);
+            }
+          }
+        }
       }
     };
     // full tiles
