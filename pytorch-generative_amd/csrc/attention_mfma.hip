@@ -26,11 +26,13 @@
 // wave-uniform test per 4 groups).
 // dQ and dK/dV have the same shape: S and dP^T = V dO^T with -lse2 resp. -delta folded in, so
 // exp2(D) = P and D = dP - delta come straight out of the matrix pipe, then dQ += dS K, or
-// dV += P^T dO and dK += dS^T Q as 4x4x1 outer-product accumulations. (dK/dV keeps S and dP on the fp32
-// 16x16x4 tile: the bf16x3 variant measured the same, see the kernel.)
+// dV += P^T dO and dK += dS^T Q as 4x4x1 outer-product accumulations. (dK/dV uses the bf16x3 tile for S
+// only: chunks of both q and dO on its streamed side would need 96 B per query and no longer fit two
+// workgroups per CU, and resident bf16x3 operands for k and v would not fit 128 registers; dP stays on
+// the fp32 16x16x4 tile, -lse2 / -delta in the C operands.)
 // A wave works on a 64-row block = four 16-row groups at a time (one K/V fragment feeds four
 // independent MFMA/exp chains). Each wave walks a host-made longest-processing-time list of blocks;
-// workgroups have 4 (forward, dK/dV) or 8 (dQ) waves so that a CU's four SIMDs carry equal loads.
+// workgroups have 4 (forward) or 8 (dQ, dK/dV) waves so that a CU's four SIMDs carry equal loads.
 // Measured (N=1024, 4 heads, L=784): fwd 0.37 ms, dQ 0.42 ms, dK/dV 0.52 ms vs 0.62 / 0.65 / 0.69 ms
 // for the VALU row-owner kernels; ~0.1 ms of each is staging, per-block set-up and the diagonal.
 #include <stdio.h>
@@ -471,31 +473,24 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
     auto step = [&](int k0, const Frag& f, auto TMIN_, auto MASK_) {
       constexpr int TMIN = decltype(TMIN_)::value;
       constexpr bool MASK = decltype(MASK_)::value;
-      // two query groups at a time (as in the dK/dV kernel: smaller live set, same chains)
+      f32x4 s[4], dp[4];
+      float ds[4][4];
 #pragma unroll
-      for (int t0 = TMIN & ~1; t0 < 4; t0 += 2) {
-        f32x4 s[2], dp[2];
+      for (int t = TMIN; t < 4; ++t) {
+        s[t] = MFMA16B(f.ka, bq[t], zero4);
+        dp[t] = MFMA16B(f.va, bg[t], zero4);
+      }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = t0 + u;
-          if (t >= TMIN) {
-            s[u] = MFMA16B(f.ka, bq[t], zero4);
-            dp[u] = MFMA16B(f.va, bg[t], zero4);
-          }
-        }
+      for (int t = TMIN; t < 4; ++t) {
+        const bool cut = MASK && t == TMIN;
+        const int lim = cut ? qidx[t] - a.strict - (k0 + 4 * g) : 3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) ds[t][r] = (!cut || r <= lim) ? ex2(s[t][r]) * dp[t][r] : 0.f;
+      }
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int t = t0 + u;
-            if (t >= TMIN) {
-              const bool cut = MASK && t == TMIN;
-              const int lim = cut ? qidx[t] - a.strict - (k0 + 4 * g) : 3;
-              const float ds = (!cut || r <= lim) ? ex2(s[u][r]) * dp[u][r] : 0.f;
-              acc[t] = MFMA4(ds, f.kq[r], acc[t]);
-            }
-          }
-        }
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int t = TMIN; t < 4; ++t) acc[t] = MFMA4(ds[t][r], f.kq[r], acc[t]);
       }
     };
     // full tiles
@@ -525,14 +520,15 @@ __global__ void __launch_bounds__(512) attn_dq_m44_kernel(const PgAttnArgs a) {
 // ------------------------------------------------------------------------------ backward: dK, dV
 // Owner = 64-key block (four 16-key groups); the queries stream. Tile D layout: lane (key j, g),
 // VGPR r <-> query 4g+r.
-// S and dP run on the fp32 16x16x4 tile here (-lse2 / -delta in the C operands). Both were also tried on the
-// bf16x3 tile (q, dO as 24-byte chunk rows in LDS, k, v as resident bf16x3 operands, 128 registers, 8 waves
-// x 2 workgroups per CU): same 0.52 ms per launch — this kernel is bound by its 32 4x4x1 MFMAs and 16
-// v_exp per step, not by the two score tiles — so the simpler variant stayed.
-__global__ void __launch_bounds__(512, 4) attn_dkv_m44_kernel(const PgAttnArgs a) {
+// BF16S: the score tile S = Q K^T runs on the bf16x3 MFMA (q chunks streamed from LDS, +32 B per query:
+// 61 KB per workgroup, so 8 waves x 2 workgroups per CU instead of 4 x 4); dP stays on the fp32 tile.
+template <bool BF16S>
+__global__ void __launch_bounds__(512) attn_dkv_m44_kernel(const PgAttnArgs a) {
   extern __shared__ float4 lds4[];
   const int Lp = a.lp;
-  float* qt = reinterpret_cast<float*>(lds4);  // Q^T  [4][Lp]
+  bf16x8* qc0 = reinterpret_cast<bf16x8*>(lds4);  // q chunks [yh|ym], [yl|yh] (BF16S only)
+  bf16x8* qc2 = qc0 + Lp;
+  float* qt = reinterpret_cast<float*>(lds4) + (BF16S ? 8 * Lp : 0);  // Q^T  [4][Lp]
   float* gt = qt + 4 * Lp;                     // dO^T [4][Lp]
   float* nlse = gt + 4 * Lp;                   // -lse2 [Lp]   (-BIG for rows >= L: P = 0)
   float* ndel = nlse + Lp;                     // -delta [Lp]
@@ -573,6 +569,7 @@ __global__ void __launch_bounds__(512, 4) attn_dkv_m44_kernel(const PgAttnArgs a
           qt[dd * Lp + m] = qx[u][dd];
           gt[dd * Lp + m] = gx[u][dd];
         }
+        if (BF16S) put_chunks(qc0, qc2, m, qx[u]);
         nlse[m] = m < L ? -lx[u] : NEG_BIG;
         ndel[m] = m < L ? -dx[u] : 0.f;
       }
@@ -581,6 +578,9 @@ __global__ void __launch_bounds__(512, 4) attn_dkv_m44_kernel(const PgAttnArgs a
   __syncthreads();
   if (nmine == 0) return;
   const int q_end = ((L + 15) >> 4) << 4;
+  // streamed score operand of this lane: groups 0,1 -> c0[query], 2 -> c2[query]; group 3 pairs with
+  // a zero resident operand (the constants -lse2 ride in the C operand here), any chunk will do
+  const bf16x8* qbase = (g == 2 ? qc2 : qc0) + qi;
 
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -590,6 +590,7 @@ __global__ void __launch_bounds__(512, 4) attn_dkv_m44_kernel(const PgAttnArgs a
     const int ngrp = min(4, (L - kb0 + 15) >> 4);
 
     float kf[4], vf[4];
+    bf16x8 bk[4];
     f32x4 acck[4], accv[4];
     int kidx[4];
 #pragma unroll
@@ -599,16 +600,24 @@ __global__ void __launch_bounds__(512, 4) attn_dkv_m44_kernel(const PgAttnArgs a
       const int kc = ok ? kidx[t] : L - 1;
       kf[t] = ok ? kp[(size_t)g * L + kc] * a.scale2 : 0.f;
       vf[t] = ok ? vp[(size_t)g * L + kc] : 0.f;
+      if (BF16S) {
+        float k4[4];
+        load_row4(k4, kp, L, kidx[t]);
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) k4[dd] *= a.scale2;
+        bk[t] = resident_operand(k4, 0.f, g);
+      }
       acck[t] = zero4;
       accv[t] = zero4;
     }
 
     // One 16-query tile against key groups [0, TMAX]: P = exp2(S - lse), dS = P * (dP - delta),
     // dV += P^T dO, dK += dS^T Q. MASK: group TMAX is on its diagonal (per-lane causal predicate).
-    struct Frag { float qa, ga; f32x4 cl, cd, qq, gq; };
+    struct Frag { float qa, ga; bf16x8 qa8; f32x4 cl, cd, qq, gq; };
     auto frag = [&](int q0t) {
       Frag f;
-      f.qa = qt[g * Lp + q0t + qi];
+      if (BF16S) f.qa8 = qbase[q0t];
+      else f.qa = qt[g * Lp + q0t + qi];
       f.ga = gt[g * Lp + q0t + qi];
       f.cl = *reinterpret_cast<const f32x4*>(nlse + q0t + 4 * g);
       f.cd = *reinterpret_cast<const f32x4*>(ndel + q0t + 4 * g);
@@ -619,34 +628,30 @@ __global__ void __launch_bounds__(512, 4) attn_dkv_m44_kernel(const PgAttnArgs a
     auto step = [&](int q0t, const Frag& f, auto TMAX_, auto MASK_) {
       constexpr int TMAX = decltype(TMAX_)::value;
       constexpr bool MASK = decltype(MASK_)::value;
-      // two key groups at a time: their four score / dP tiles, then exp, dS and the 16 outer-product
-      // MFMAs of the pair (P and dS go straight from the tile registers into the accumulation chains)
+      f32x4 s[4], dp[4];
+      float p[4][4], ds[4][4];
 #pragma unroll
-      for (int t0 = 0; t0 <= TMAX; t0 += 2) {
-        f32x4 s[2], dp[2];
+      for (int t = 0; t <= TMAX; ++t) {
+        if (BF16S) s[t] = MFMA16B(f.qa8, bk[t], f.cl);
+        else s[t] = MFMA16(f.qa, kf[t], f.cl);
+        dp[t] = MFMA16(f.ga, vf[t], f.cd);
+      }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = t0 + u;
-          if (t <= TMAX) {
-            s[u] = MFMA16(f.qa, kf[t], f.cl);
-            dp[u] = MFMA16(f.ga, vf[t], f.cd);
-          }
-        }
+      for (int t = 0; t <= TMAX; ++t) {
+        const bool cut = MASK && t == TMAX;
+        const int lowest = cut ? kidx[t] + a.strict - (q0t + 4 * g) : 0;  // query 4g+r allowed iff r >= lowest
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          p[t][r] = (!cut || r >= lowest) ? ex2(s[t][r]) : 0.f;
+          ds[t][r] = p[t][r] * dp[t][r];
+        }
+      }
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int t = t0 + u;
-            if (t <= TMAX) {
-              const bool cut = MASK && t == TMAX;
-              // query 4g+r allowed iff r >= lowest
-              const int lowest = cut ? kb0 + 16 * t + qi + a.strict - (q0t + 4 * g) : 0;
-              const float p = (!cut || r >= lowest) ? ex2(s[u][r]) : 0.f;
-              const float ds = p * dp[u][r];
-              accv[t] = MFMA4(p, f.gq[r], accv[t]);
-              acck[t] = MFMA4(ds, f.qq[r], acck[t]);
-            }
-          }
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int t = 0; t <= TMAX; ++t) {
+          accv[t] = MFMA4(p[t][r], f.gq[r], accv[t]);
+          acck[t] = MFMA4(ds[t][r], f.qq[r], acck[t]);
         }
       }
     };
@@ -710,12 +715,16 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   a.lp = 64 * NB + 16;  // plane stride == 16 (mod 64): conflict-free b32 and b128 fragment reads
   // in 4-byte units per row — fwd: K chunks (2 x 16 B) + V^T planes; dQ: K and V chunks + K^T planes;
   // dK/dV: 10 planes; plus the ones chunk
-  const size_t planes = which == PG_ATTN_DKV ? 10 : (which == PG_ATTN_DQ ? 20 : 12);
+  // dK/dV score tile on the bf16x3 MFMA (default; PG_ATTN_DKV_BF16=0 selects the all-fp32 variant:
+  // measured 0.534-0.545 ms vs 0.515-0.521 ms per launch at batch 1024)
+  static const bool dkv_bf16 = []() { const char* e = getenv("PG_ATTN_DKV_BF16"); return !(e && e[0] == '0'); }();
+  const size_t planes = which == PG_ATTN_DKV ? (dkv_bf16 ? 18 : 10) : (which == PG_ATTN_DQ ? 20 : 12);
   const size_t shmem = planes * (size_t)a.lp * sizeof(float) + 16;
   if (shmem > 160 * 1024) return 0;
   int wcfg[3];
   attn_waves(wcfg);
   int W = wcfg[which];
+  if (which == PG_ATTN_DKV && dkv_bf16 && !getenv("PG_ATTN_WAVES")) W = 8;
   if (W > NB) W = NB;
   if ((NB + W - 1) / W > 16) return 0;  // block lists hold 16 entries per wave
   // LPT: blocks by decreasing cost (later query blocks / earlier key blocks stream more), each to
@@ -742,13 +751,16 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   dim3 block((unsigned)(64 * W));
   const void* fn = which == PG_ATTN_FWD  ? reinterpret_cast<const void*>(attn_fwd_m44_kernel)
                    : which == PG_ATTN_DQ ? reinterpret_cast<const void*>(attn_dq_m44_kernel)
-                                         : reinterpret_cast<const void*>(attn_dkv_m44_kernel);
+                   : dkv_bf16            ? reinterpret_cast<const void*>(attn_dkv_m44_kernel<true>)
+                                         : reinterpret_cast<const void*>(attn_dkv_m44_kernel<false>);
   if (shmem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (which == PG_ATTN_FWD)
     hipLaunchKernelGGL(attn_fwd_m44_kernel, grid, block, shmem, st, a);
   else if (which == PG_ATTN_DQ)
     hipLaunchKernelGGL(attn_dq_m44_kernel, grid, block, shmem, st, a);
+  else if (dkv_bf16)
+    hipLaunchKernelGGL(attn_dkv_m44_kernel<true>, grid, block, shmem, st, a);
   else
-    hipLaunchKernelGGL(attn_dkv_m44_kernel, grid, block, shmem, st, a);
+    hipLaunchKernelGGL(attn_dkv_m44_kernel<false>, grid, block, shmem, st, a);
   return 1;
 }

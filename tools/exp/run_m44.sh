@@ -1,5 +1,7 @@
 mkdir -p gpurun_out
 {
-timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "attention or attn or block" 2>&1 | tail -3
-for v in 1 2 3; do timeout 120 python tools/attn_kernels.py 1024; done
+for v in cur sonly cur sonly; do
+  lib=pytorch-generative_amd/pytorch_generative_amd/lib/libpg_hip.so; [ $v = sonly ] && lib=tools/exp/libpg_sonly.so
+  echo "lib $v"; timeout 300 python tools/exp/bench_with_lib.py $lib --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['launch_ms'])"
+done
 } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/run.log
