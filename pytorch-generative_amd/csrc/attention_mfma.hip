@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(512) attn_fwd_m44_kernel(const PgAttnArgs a) {
   float* vt = reinterpret_cast<float*>(kc2 + Lp);  // V^T [4][Lp]
   bf16x8* ones = reinterpret_cast<bf16x8*>(vt + 4 * Lp);
   const Ids d = ids();
-  const int lane = d.lane, qi = d.qi, g = d.g, jc = d.jc;
+  const int qi = d.qi, g = d.g, jc = d.jc;
   const int h = blockIdx.y, n = blockIdx.z;
   const int L = a.L;
   const int NB = (L + 63) >> 6;
