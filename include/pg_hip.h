@@ -76,6 +76,31 @@ size_t pg_packed_weight_floats(int a, int T, int b);
 /* padded extent of b the conv kernel expects */
 int pg_conv_b_pad(int b);
 
+/* ---------------------------------------------------------------------------------------
+ * The same convolution as an implicit GEMM on the fp32 matrix cores (csrc/conv_mfma.hip):
+ * M = output channels, N = output pixels, K = (input-channel group of 4, tap). Replaces the same
+ * reference call sites as pg_conv2d_taps (nn/convolution.py:41-43, gated_pixel_cnn.py:63-96,
+ * pixel_snail.py:41-55, every 1x1 convolution) once both channel counts fill MFMA tiles
+ * (pg_conv_mfma_supported != 0; otherwise call pg_conv2d_taps). `wfrag` = A fragments made by
+ * pg_pack_conv_weight_frag (transpose = 1 + negated taps: the data gradient).
+ * Epilogue order: + bias, out_act (PG_ACT_*), + res, * dact'(dact_src).
+ * ------------------------------------------------------------------------------------- */
+int pg_conv2d_mfma(const float* in, const float* wfrag, const float* bias, const float* res,
+                   float* out, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
+                   const int* tap_dr, const int* tap_dc, int in_act, const float* dact_src,
+                   int dact, int out_act, void* stream);
+/* 1 if pg_conv2d_mfma takes a (Cin -> Cout, T taps, OH x OW outputs, input rows of IW) problem */
+int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, int IW);
+/* floats pg_pack_conv_weight_frag writes for K_channels contracted into M_channels over T taps */
+size_t pg_conv_frag_floats(int K_channels, int M_channels, int T);
+/* wfrag[chunk][g*T + t][m][lane] = Wsel[64 chunk + 16 m + (lane & 15)][4 g + (lane >> 4)][t], with
+ *   transpose==0: Wsel[o][c][t] = w[o][c][tap_u[t]][tap_v[t]]  (M = Cout, K channels = Cin)
+ *   transpose==1: Wsel[o][c][t] = w[c][o][tap_u[t]][tap_v[t]]  (M = Cin,  K channels = Cout)
+ * zero filled outside; w is the torch layout (Cout, Cin, KH, KW). */
+int pg_pack_conv_weight_frag(const float* w, float* wfrag, int Cout, int Cin, int KH, int KW,
+                             int T, const int* tap_u, const int* tap_v, int transpose,
+                             void* stream);
+
 /* Weight + bias gradient (MFMA f32 16x16x4). The result is ADDED to dw/db (the caller zeroes
  * them once per step); per-workgroup partial sums go through `workspace` and a second,
  * deterministic reduction kernel (no atomics). Replaces aten::convolution_backward's weight/bias

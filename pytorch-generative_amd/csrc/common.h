@@ -35,7 +35,9 @@ __device__ __forceinline__ float pg_apply_act(float x, int act) {
     case PG_ACT_RELU:
       return x > 0.f ? x : 0.f;
     case PG_ACT_ELU:
-      return x > 0.f ? x : expm1f(x);
+      // exp(x) - 1 on the hardware exp2 path (absolute error <= 1.2e-7 next to activations of order 1;
+      // libm's expm1f is ~25 instructions per element in the staging loops that apply this)
+      return x > 0.f ? x : __expf(x) - 1.0f;
     case PG_ACT_GELU:
       return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
     default:

@@ -1,0 +1,501 @@
+// conv_mfma.hip — stride-1 convolution over an explicit tap list as an implicit GEMM on the fp32
+// matrix cores (v_mfma_f32_16x16x4_f32), gfx950.
+//
+// Same contract as conv_direct.hip (pg_conv2d_taps): replaces torch.nn.Conv2d.forward as reached
+// from CausalConv2d.forward (reference nn/convolution.py:41-43), the pad+crop convolutions of
+// gated_pixel_cnn.py:63-96 / pixel_snail.py:41-55, every 1x1 convolution — and, with the
+// transposed weight pack and negated taps, aten::convolution_backward's data gradient.
+//
+//   out[n,co,r,c] = epi( bias[co] + sum_{ci,t} W[co][ci][t] * act(in[n,ci,r+dr_t,c+dc_t]) )
+//
+// GEMM view: M = output channels, N = output pixels, K = (channel group of 4, tap): K step
+// s = g*T + t contracts input channels 4g..4g+3 at tap t.
+//   A[i = lane&15][k = lane>>4] = W[co0 + 16m + i][4g + k][t]            (pre-packed fragments)
+//   B[k = lane>>4][j = lane&15] = x_tile[4g + k][pixel j + tap offset t]  (LDS, fp32)
+//   D[(lane>>4)*4 + r][lane&15]  -> out[co0 + 16m + 4(lane>>4) + r][pixel j]
+// CDNA4 mapping
+//  * workgroup = 4 waves = up to 256 output pixels (whole rows of one image, or several whole
+//    small images) x up to 64 output channels; wave w owns NT consecutive 16-pixel groups and ALL
+//    channel tiles: MT x NT accumulator tiles (64 VGPRs at 4 x 4), 1 + MT + NT ds_read_b32 per
+//    MT*NT MFMAs (33 cycles each) — the matrix pipe, not LDS, is the bound.
+//  * x tile [ci][rows + halo][cols + halo] fp32; every thread owns up to 6 float4 'slots' of a channel
+//    chunk, loads them for chunk c+1 before the MFMA loop of chunk c and commits them (prologue
+//    activation applied once) after it, so global latency hides under the matrix pipe; channel stride == 16 (mod 32) so the two channels a
+//    32-lane half of a B fragment read touches land on disjoint bank halves.
+//  * weights arrive as ready-made A fragments (pg_pack_conv_weight_frag) and are copied to LDS with
+//    float4 loads; every lane reads its own dword (conflict free).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MF_THREADS = 256;
+constexpr int MF_CO_CHUNK = 64;
+
+struct MfArgs {
+  const float* in;
+  const float* wfrag;
+  const float* bias;
+  const float* res;
+  const float* dact_src;
+  float* out;
+  int N, Cin, IH, IW, Cout, OH, OW, T;
+  int NI, TR, tiles_per_grp, tile_h, tile_w, min_dr, min_dc, img_stride, ch_stride, CIB;
+  int KQ;  // K steps of the whole problem: ceil(Cin / 4) * T
+  int in_act, dact, out_act;
+  int w_off, b_off, dump;  // LDS float offsets
+  int Q, xslots;    // float4 staging: quads per input row, NI * CIB * tile_h * Q slots per chunk
+  int tapoff[PG_MAX_TAPS];
+};
+
+constexpr int XS = 6;  // float4 staging slots per thread per channel chunk (x tile)
+constexpr int WS = 6;  // float4 slots per thread per channel chunk (weight fragments)
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = blockIdx.x / a.tiles_per_grp;  // image group
+  const int row0 = (blockIdx.x - grp * a.tiles_per_grp) * a.TR;
+  const int n0 = grp * a.NI;
+  const int ni = min(a.NI, a.N - n0);
+  const int rows = min(a.TR, a.OH - row0);  // NI > 1 implies TR == OH
+  const int npx = ni * rows * a.OW;
+  const int co0 = blockIdx.y * MF_CO_CHUNK;
+  const int L = a.OH * a.OW;
+  const int plane = a.IH * a.IW;
+
+  float* xl = lds;
+  float* wl = lds + a.w_off;
+
+  // lane's pixel of each of its 16-pixel groups: LDS offset, validity
+  int pixoff[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int p = (wave * NT + n) * 16 + (lane & 15);
+    const int pc = p < npx ? p : 0;
+    const int q = pc / a.OW;
+    const int c = pc - q * a.OW;
+    const int img = q / rows;
+    const int r = q - img * rows;
+    pixoff[n] = img * a.img_stride + r * a.tile_w + c;
+  }
+
+  // ---- staging slots (float4 path): this thread's share of a channel chunk's x tile is the same
+  // set of (image, channel-in-chunk, tile row, quad) elements for every chunk, so global offset, LDS
+  // offset and validity are computed once; per chunk the thread issues its loads BEFORE the MFMA
+  // loop of the previous chunk and commits them to LDS after it (global latency hidden).
+  int s_goff[XS], s_meta[XS];  // meta: (LDS offset + 4) | element mask << 16 | channel-in-chunk << 20
+  int s_base = 0;              // bit k: slot k exists (in-range row of an existing image)
+  {
+#pragma unroll
+    for (int k = 0; k < XS; ++k) {
+      int e = tid + k * MF_THREADS;
+      const bool in = e < a.xslots;
+      e = in ? e : 0;
+      const int q = e % a.Q;
+      e /= a.Q;
+      const int tr = e % a.tile_h;
+      e /= a.tile_h;
+      const int ch = e % a.CIB;
+      const int img = e / a.CIB;
+      const int ir = row0 + a.min_dr + tr;
+      const bool ok = in && img < ni && ir >= 0 && ir < a.IH;
+      const int irc = ir < 0 ? 0 : (ir >= a.IH ? a.IH - 1 : ir);
+      s_goff[k] = (img * a.Cin + ch) * plane + irc * a.IW + 4 * q;
+      const int tcol = 4 * q - a.min_dc;
+      const int loff = img * a.img_stride + ch * a.ch_stride + tr * a.tile_w + tcol;
+      int mask = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (tcol + i >= 0 && tcol + i < a.tile_w) mask |= 1 << i;
+      s_meta[k] = ((loff + 4) & 0xffff) | (mask << 16) | (ch << 20);  // tcol >= -3: loff + 4 > 0
+      if (ok) s_base |= 1 << k;
+    }
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // zero the tile once: the float4 staging writes in-range elements only (the halo stays zero), and
+  // the channels that pad the last group of 4 must hold finite values (their weights are zero)
+  for (int i = tid; i < a.CIB * a.ch_stride; i += MF_THREADS) xl[i] = 0.f;
+  if (tid < MF_CO_CHUNK) {
+    const int co = co0 + tid;
+    lds[a.b_off + tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+  }
+
+  const float* in_b = a.in + (size_t)n0 * a.Cin * plane;
+  const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag + (size_t)blockIdx.y * a.KQ * (MT * 64));
+  float4 xv[XS], wv[WS];
+#pragma unroll
+  for (int k = 0; k < XS; ++k) xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < WS; ++k) wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int xok = 0;  // slots loaded for the chunk in flight
+
+#define PG_MF_ISSUE(CI0)                                                                  \
+  {                                                                                       \
+    const int cib_ = min(a.CIB, a.Cin - (CI0));                                           \
+    const int nw4_ = ((cib_ + 3) >> 2) * a.T * MT * 16;                                   \
+    const float4* ws_ = wsrc_b + (size_t)((CI0) >> 2) * a.T * (MT * 16);                  \
+    _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                      \
+      const int i = tid + k * MF_THREADS;                                                 \
+      if (i < nw4_) wv[k] = ws_[i];                                                       \
+    }                                                                                     \
+    xok = 0;                                                                              \
+    const float* src_ = in_b + (size_t)(CI0) * plane;                                     \
+    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                      \
+      const bool ok = ((s_base >> k) & 1) && (s_meta[k] >> 20) < cib_;                    \
+      if (ok) {                                                                           \
+        xv[k] = *reinterpret_cast<const float4*>(src_ + s_goff[k]);                       \
+        xok |= 1 << k;                                                                    \
+      }                                                                                   \
+    }                                                                                     \
+  }
+
+  PG_MF_ISSUE(0)
+  const int kb = lane >> 4;
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += a.CIB) {
+    const int cib = min(a.CIB, a.Cin - ci0);
+    const int ng = (cib + 3) >> 2;  // channel groups of this chunk
+    __syncthreads();                // the previous chunk's fragment reads are done
+#define PG_MF_COMMIT(ACT)                                                   \
+  _Pragma("unroll") for (int k = 0; k < XS; ++k) {                          \
+    const bool ok = (xok >> k) & 1;                                         \
+    const int loff = (s_meta[k] & 0xffff) - 4;                              \
+    const float e[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                         \
+      const bool oki = ok && ((s_meta[k] >> (16 + i)) & 1);                 \
+      xl[oki ? loff + i : a.dump] = pg_apply_act(e[i], ACT);                \
+    }                                                                       \
+  }
+    switch (a.in_act) {  // wave-uniform
+      case PG_ACT_RELU: PG_MF_COMMIT(PG_ACT_RELU) break;
+      case PG_ACT_ELU:  PG_MF_COMMIT(PG_ACT_ELU) break;
+      case PG_ACT_GELU: PG_MF_COMMIT(PG_ACT_GELU) break;
+      default:          PG_MF_COMMIT(PG_ACT_NONE) break;
+    }
+#undef PG_MF_COMMIT
+    {
+      const int nw4 = ng * a.T * MT * 16;
+      float4* wdst = reinterpret_cast<float4*>(wl);
+#pragma unroll
+      for (int k = 0; k < WS; ++k) {
+        const int i = tid + k * MF_THREADS;
+        if (i < nw4) wdst[i] = wv[k];
+      }
+    }
+    __syncthreads();
+    if (ci0 + a.CIB < a.Cin) PG_MF_ISSUE(ci0 + a.CIB)  // prefetch: lands under the MFMA loop
+    const int gstride = 4 * a.ch_stride;
+    for (int t = 0; t < a.T; ++t) {
+      const float* xb = xl + a.tapoff[t] + kb * a.ch_stride;
+      const float* wb = wl + t * (MT * 64) + lane;
+#pragma unroll 2
+      for (int g = 0; g < ng; ++g) {
+        float av[MT], bv[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = wb[(g * a.T * MT + m) * 64];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[n] = xb[g * gstride + pixoff[n]];
+        // keep the reads together in front of the MFMAs (left alone the scheduler interleaves them
+        // one by one and every MFMA waits a full LDS latency)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+#undef PG_MF_ISSUE
+
+  // ---- epilogue: + bias, out_act, + res, * act'(dact_src) (data gradient of a fused input activation).
+  // The accumulator layout (lane = 4 channels x 1 pixel) would store 64-byte segments; each wave
+  // transposes one 16-channel tile at a time through its own LDS scratch ([16 co][64 px], row stride
+  // 68: conflict-free both ways) so that a store instruction covers 64 consecutive pixels (256 B) of
+  // one channel plane. (Measured: 64-byte-segment stores cost 23-40 us of an 82 us launch.)
+  __syncthreads();  // all waves are done with the x / weight tiles
+  constexpr int EPS = 68;
+  float* ep = lds + wave * (16 * EPS);
+  const float* bl = lds + a.b_off;          // this chunk's bias values (staged at kernel start)
+  const int pw = wave * (NT * 16) + lane;   // this lane's pixel in the store phase
+  const bool sok = (lane < NT * 16) && pw < npx;
+  size_t so;
+  {
+    const int pc = sok ? pw : 0;
+    const int q = pc / a.OW;
+    const int c = pc - q * a.OW;
+    const int img = q / rows;
+    const int r = q - img * rows;
+    so = ((size_t)(n0 + img) * a.Cout + co0) * L + (size_t)((row0 + r) * a.OW + c);
+  }
+  // One 16-channel tile at a time; the residual / act' operands of tile m+1 are requested BEFORE the
+  // stores of tile m are issued, so waiting for them never waits for a store (loads and stores share
+  // vmcnt and complete in order: a load issued after a store drains it).
+  const int cvalid = a.Cout - co0;  // channels of this chunk that exist (>= 1)
+  const float* resp = a.res ? a.res + so : nullptr;
+  const float* dsp = a.dact_src ? a.dact_src + so : nullptr;
+  float* outp = a.out + so;
+  float rv[16], sv[16];
+#define PG_MF_PRELOAD(M)                                                       \
+  _Pragma("unroll") for (int c = 0; c < 16; ++c) {                             \
+    const int cc = (M) * 16 + c;                                               \
+    const size_t o = (size_t)(cc < cvalid ? cc : 0) * L;                       \
+    rv[c] = resp ? resp[o] : 0.f;                                              \
+    sv[c] = dsp ? dsp[o] : 0.f;                                                \
+  }
+  PG_MF_PRELOAD(0)
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ep[(kb * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[m][n][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = ep[c * EPS + lane] + bl[m * 16 + c];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    switch (a.out_act) {  // wave-uniform
+      case PG_ACT_RELU:
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_RELU);
+        break;
+      case PG_ACT_ELU:
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_ELU);
+        break;
+      case PG_ACT_GELU:
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_GELU);
+        break;
+      default: break;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] += rv[c];
+    switch (a.dact) {
+      case PG_ACT_RELU:
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_RELU);
+        break;
+      case PG_ACT_ELU:
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU);
+        break;
+      case PG_ACT_GELU:
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
+        break;
+      default: break;
+    }
+    if (m + 1 < MT) { PG_MF_PRELOAD(m + 1) }
+    if (sok) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int cc = m * 16 + c;
+        if (cc < cvalid) outp[(size_t)cc * L] = v[c];
+      }
+    }
+  }
+#undef PG_MF_PRELOAD
+}
+
+// ---- A-fragment weight pack ----------------------------------------------------------------
+// wfrag[chunk][s = g*T + t][m][lane] = Wsel[chunk*64 + 16m + (lane&15)][c = 4g + (lane>>4)][t]
+//   transpose==0: Wsel[o][c][t] = w[o][c][u_t][v_t]   (forward:       M = Cout, K channels = Cin)
+//   transpose==1: Wsel[o][c][t] = w[c][o][u_t][v_t]   (data gradient: M = Cin,  K channels = Cout)
+// zero outside (o >= M, c >= K channels).
+struct FragPackArgs {
+  const float* w;
+  float* wfrag;
+  int Cout, Cin, KH, KW, T, transpose;
+  int M, Kc, KQ, MT, chunks;
+  int tap_u[PG_MAX_TAPS];
+  int tap_v[PG_MAX_TAPS];
+};
+
+__global__ void pack_frag_kernel(const FragPackArgs p) {
+  const long total = (long)p.chunks * p.KQ * p.MT * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    long rest = i >> 6;
+    const int m = (int)(rest % p.MT);
+    rest /= p.MT;
+    const int kq = (int)(rest % p.KQ);
+    const int chunk = (int)(rest / p.KQ);
+    const int o = chunk * MF_CO_CHUNK + m * 16 + (lane & 15);
+    const int g = kq / p.T;
+    const int t = kq - g * p.T;
+    const int c = g * 4 + (lane >> 4);
+    float v = 0.f;
+    if (o < p.M && c < p.Kc) {
+      const int co = p.transpose ? c : o;
+      const int ci = p.transpose ? o : c;
+      v = p.w[(((size_t)co * p.Cin + ci) * p.KH + p.tap_u[t]) * p.KW + p.tap_v[t]];
+    }
+    p.wfrag[i] = v;
+  }
+}
+
+inline int mf_mt(int M) { return M >= MF_CO_CHUNK ? 4 : (M + 15) / 16; }
+inline int mf_chunks(int M) { return (M + MF_CO_CHUNK - 1) / MF_CO_CHUNK; }
+
+template <int MT>
+int mf_launch(const MfArgs& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
+  switch (nt) {
+    case 1: hipLaunchKernelGGL((conv_mfma_kernel<MT, 1>), grid, dim3(MF_THREADS), shmem, st, a); break;
+    case 2: hipLaunchKernelGGL((conv_mfma_kernel<MT, 2>), grid, dim3(MF_THREADS), shmem, st, a); break;
+    case 3: hipLaunchKernelGGL((conv_mfma_kernel<MT, 3>), grid, dim3(MF_THREADS), shmem, st, a); break;
+    default: hipLaunchKernelGGL((conv_mfma_kernel<MT, 4>), grid, dim3(MF_THREADS), shmem, st, a); break;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// The matrix-core path pays off once both channel extents fill MFMA tiles; tiny contractions
+// (the 1- / 3-channel image convolutions, 4-channel query projections) stay on conv_direct.hip.
+PG_EXPORT int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, int IW) {
+  if ((IW % 4) != 0) return 0;  // float4 staging slots
+  if (OW > 256 || T < 1 || T > PG_MAX_TAPS) return 0;
+  if (OH * OW < 64) return 0;  // tiny images (VD-VAE's 4x4 .. 1x1 levels): launch bound either way
+  return (Cin >= 8 && Cout >= 8) ? 1 : 0;
+}
+
+PG_EXPORT size_t pg_conv_frag_floats(int K_channels, int M_channels, int T) {
+  const size_t KQ = (size_t)((K_channels + 3) / 4) * T;
+  return (size_t)mf_chunks(M_channels) * KQ * mf_mt(M_channels) * 64;
+}
+
+PG_EXPORT int pg_pack_conv_weight_frag(const float* w, float* wfrag, int Cout, int Cin, int KH,
+                                       int KW, int T, const int* tap_u, const int* tap_v,
+                                       int transpose, void* stream) {
+  PG_REQUIRE(w && wfrag && tap_u && tap_v, PG_EINVAL, "pg_pack_conv_weight_frag: null pointer");
+  PG_REQUIRE(T >= 1 && T <= PG_MAX_TAPS, PG_ESHAPE, "pg_pack_conv_weight_frag: T=%d not in [1,%d]",
+             T, PG_MAX_TAPS);
+  FragPackArgs p;
+  p.w = w; p.wfrag = wfrag; p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.T = T;
+  p.transpose = transpose;
+  p.M = transpose ? Cin : Cout;
+  p.Kc = transpose ? Cout : Cin;
+  p.KQ = ((p.Kc + 3) / 4) * T;
+  p.MT = mf_mt(p.M);
+  p.chunks = mf_chunks(p.M);
+  for (int t = 0; t < T; ++t) {
+    PG_REQUIRE(tap_u[t] >= 0 && tap_u[t] < KH && tap_v[t] >= 0 && tap_v[t] < KW, PG_EINVAL,
+               "pg_pack_conv_weight_frag: tap %d (%d,%d) outside %dx%d", t, tap_u[t], tap_v[t], KH, KW);
+    p.tap_u[t] = tap_u[t];
+    p.tap_v[t] = tap_v[t];
+  }
+  const long total = (long)p.chunks * p.KQ * p.MT * 64;
+  const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  PG_LAUNCH_CHECK("pg_pack_conv_weight_frag");
+  return 0;
+}
+
+PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* bias,
+                             const float* res, float* out, int N, int Cin, int IH, int IW,
+                             int Cout, int OH, int OW, int T, const int* tap_dr,
+                             const int* tap_dc, int in_act, const float* dact_src, int dact,
+                             int out_act, void* stream) {
+  PG_REQUIRE(in && wfrag && out && tap_dr && tap_dc, PG_EINVAL, "pg_conv2d_mfma: null pointer");
+  PG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, PG_EINVAL,
+             "pg_conv2d_mfma: non-positive dimension");
+  PG_REQUIRE(T >= 1 && T <= PG_MAX_TAPS, PG_ESHAPE, "pg_conv2d_mfma: T=%d not in [1,%d]", T,
+             PG_MAX_TAPS);
+  PG_REQUIRE(OW <= 256, PG_ESHAPE, "pg_conv2d_mfma: OW=%d wider than a 256-pixel tile", OW);
+  PG_REQUIRE(in_act >= PG_ACT_NONE && in_act <= PG_ACT_GELU && out_act >= PG_ACT_NONE &&
+                 out_act <= PG_ACT_GELU, PG_EINVAL, "pg_conv2d_mfma: bad activation id");
+  PG_REQUIRE(dact >= PG_ACT_NONE && dact <= PG_ACT_GELU && ((dact == PG_ACT_NONE) == (dact_src == nullptr)),
+             PG_EINVAL, "pg_conv2d_mfma: dact_src / dact mismatch");
+  hipStream_t st = (hipStream_t)stream;
+  MfArgs a;
+  a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
+  a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW; a.T = T;
+  a.in_act = in_act; a.dact = dact; a.out_act = out_act;
+  int min_dr = tap_dr[0], max_dr = tap_dr[0], min_dc = tap_dc[0], max_dc = tap_dc[0];
+  for (int t = 1; t < T; ++t) {
+    min_dr = tap_dr[t] < min_dr ? tap_dr[t] : min_dr;
+    max_dr = tap_dr[t] > max_dr ? tap_dr[t] : max_dr;
+    min_dc = tap_dc[t] < min_dc ? tap_dc[t] : min_dc;
+    max_dc = tap_dc[t] > max_dc ? tap_dc[t] : max_dc;
+  }
+  a.min_dr = min_dr; a.min_dc = min_dc;
+  // pixel tile: whole rows of one image (TR rows), or NI whole images when an image is <= 128 px
+  const int L = OH * OW;
+  if (L <= 128) {
+    a.NI = 256 / L;
+    if (a.NI > N) a.NI = N;
+    a.TR = OH;
+  } else {
+    a.NI = 1;
+    a.TR = 256 / OW;
+    if (a.TR > OH) a.TR = OH;
+    // even out the row tiles (e.g. 28 rows: 4 tiles of 7 instead of 9,9,9,1)
+    const int nt_rows = (OH + a.TR - 1) / a.TR;
+    a.TR = (OH + nt_rows - 1) / nt_rows;
+  }
+  a.tiles_per_grp = (OH + a.TR - 1) / a.TR;
+  const int groups = (N + a.NI - 1) / a.NI;
+  a.tile_h = a.TR + (max_dr - min_dr);
+  a.tile_w = OW + (max_dc - min_dc);
+  a.img_stride = a.tile_h * a.tile_w;
+  {
+    int cs = a.NI * a.img_stride;
+    const int r = cs % 32;
+    cs += (r <= 16) ? (16 - r) : (48 - r);  // channel stride == 16 (mod 32): conflict-free B reads
+    a.ch_stride = cs;
+  }
+  PG_REQUIRE((IW % 4) == 0 && (((uintptr_t)in & 15) == 0), PG_ESHAPE,
+             "pg_conv2d_mfma: input rows must be 16-byte aligned (IW %% 4 == 0)");
+  const int MT = mf_mt(Cout);
+  a.KQ = ((Cin + 3) / 4) * T;
+  // channel chunk: x tile + weight fragments + offset table within ~40 KB (4 workgroups per CU)
+  const long budget = 40 * 1024 / 4;
+  const long per_ci = a.ch_stride + (long)T * MT * 16;
+  long CIB = (budget - 16) / per_ci;
+  CIB = (CIB / 4) * 4;
+  if (CIB < 4) CIB = 4;
+  if (CIB > Cin) CIB = ((Cin + 3) / 4) * 4;
+  a.Q = IW / 4;
+  // x slots: NI * CIB * tile_h * Q float4 per chunk over XS * 256 thread slots
+  while (CIB > 4 && (long)a.NI * CIB * a.tile_h * a.Q > (long)XS * MF_THREADS) CIB -= 4;
+  while (CIB > 4 && (CIB / 4) * (long)T * MT * 16 > (long)WS * MF_THREADS) CIB -= 4;  // weight slots
+  PG_REQUIRE((CIB / 4) * (long)T * MT * 16 <= (long)WS * MF_THREADS &&
+                 (long)a.NI * CIB * a.tile_h * a.Q <= (long)XS * MF_THREADS,
+             PG_ESHAPE, "pg_conv2d_mfma: %d taps x %d-row tile exceeds the staging slots", T, a.tile_h);
+  a.CIB = (int)CIB;
+  a.xslots = a.NI * a.CIB * a.tile_h * a.Q;
+  const long x_floats = CIB * a.ch_stride;
+  a.dump = (int)x_floats;
+  a.w_off = (int)(((x_floats + 4 + 3) / 4) * 4);
+  size_t shmem = ((size_t)a.w_off + (size_t)(CIB / 4) * T * MT * 64) * sizeof(float);
+  if (shmem < (size_t)4 * 16 * 68 * sizeof(float)) shmem = (size_t)4 * 16 * 68 * sizeof(float);
+  a.b_off = (int)(shmem / sizeof(float));
+  shmem += MF_CO_CHUNK * sizeof(float);
+  PG_REQUIRE(shmem <= 64 * 1024, PG_ESHAPE,
+             "pg_conv2d_mfma: tile %dx%d x %d taps needs %zu B of LDS (> 64 KB)", a.tile_h, a.tile_w,
+             T, shmem);
+  for (int t = 0; t < T; ++t) a.tapoff[t] = (tap_dr[t] - min_dr) * a.tile_w + (tap_dc[t] - min_dc);
+  const int npx_max = a.NI * a.TR * OW;
+  const int nt = (npx_max + 63) / 64;  // 16-pixel groups per wave
+  dim3 grid((unsigned)(groups * a.tiles_per_grp), (unsigned)mf_chunks(Cout));
+  switch (MT) {
+    case 1: mf_launch<1>(a, nt, grid, shmem, st); break;
+    case 2: mf_launch<2>(a, nt, grid, shmem, st); break;
+    case 3: mf_launch<3>(a, nt, grid, shmem, st); break;
+    default: mf_launch<4>(a, nt, grid, shmem, st); break;
+  }
+  PG_LAUNCH_CHECK("pg_conv2d_mfma");
+  return 0;
+}

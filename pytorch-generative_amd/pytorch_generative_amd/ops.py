@@ -86,6 +86,30 @@ class ConvSpec:
         return h + 2 * self.pad_h - self.kh + 1, w + 2 * self.pad_w - self.kw + 1
 
 
+# PG_CONV_MFMA=0 keeps every convolution on the VALU tap kernels (A/B measurements)
+CONV_MFMA = os.environ.get("PG_CONV_MFMA", "1") != "0"
+
+
+def _use_mfma(lib, k_channels, m_channels, spec, out_hw, in_w):
+    return CONV_MFMA and bool(
+        lib.pg_conv_mfma_supported(k_channels, m_channels, len(spec.fwd_taps), out_hw[0], out_hw[1],
+                                   in_w))
+
+
+def _pack_frag(lib, weight, spec, transpose):
+    """MFMA A-fragment pack of the active taps (csrc/conv_mfma.hip)."""
+    cout, cin, kh, kw = weight.shape
+    kc, m = (cout, cin) if transpose else (cin, cout)
+    t = len(spec.fwd_taps)
+    wfrag = torch.empty(lib.pg_conv_frag_floats(kc, m, t), device=weight.device, dtype=torch.float32)
+    _lib.check(
+        lib.pg_pack_conv_weight_frag(weight.data_ptr(), wfrag.data_ptr(), cout, cin, kh, kw, t,
+                                     spec.f_u, spec.f_v, int(transpose), _stream()),
+        "pg_pack_conv_weight_frag",
+    )
+    return wfrag
+
+
 def _pack(lib, weight, spec, transpose):
     cout, cin, kh, kw = weight.shape
     a, b = (cout, cin) if transpose else (cin, cout)
@@ -119,16 +143,27 @@ class _ConvTaps(torch.autograd.Function):
             res = _chk(res, "conv2d.res")
             if tuple(res.shape) != (n, cout, oh, ow):
                 raise ValueError("conv2d: residual shape mismatch")
-        wpk = _pack(lib, weight, spec, transpose=False)
         out = torch.empty((n, cout, oh, ow), device=x.device, dtype=torch.float32)
-        _lib.check(
-            lib.pg_conv2d_taps(
-                x.data_ptr(), wpk.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih, iw,
-                cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, 0, ACT_NONE,
-                _stream(),
-            ),
-            "pg_conv2d_taps",
-        )
+        if _use_mfma(lib, cin, cout, spec, (oh, ow), iw):
+            wfrag = _pack_frag(lib, weight, spec, transpose=False)
+            _lib.check(
+                lib.pg_conv2d_mfma(
+                    x.data_ptr(), wfrag.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih,
+                    iw, cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, 0, ACT_NONE,
+                    ACT_NONE, _stream(),
+                ),
+                "pg_conv2d_mfma",
+            )
+        else:
+            wpk = _pack(lib, weight, spec, transpose=False)
+            _lib.check(
+                lib.pg_conv2d_taps(
+                    x.data_ptr(), wpk.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih, iw,
+                    cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, 0, ACT_NONE,
+                    _stream(),
+                ),
+                "pg_conv2d_taps",
+            )
         ctx.save_for_backward(x, weight)
         ctx.spec, ctx.in_act, ctx.has_bias, ctx.has_res = spec, in_act, bias is not None, res is not None
         ctx.gw, ctx.gb = gw, gb
@@ -148,7 +183,22 @@ class _ConvTaps(torch.autograd.Function):
         n, cin, ih, iw = x.shape
         _, cout, oh, ow = dy.shape
         dx = dw = db = None
-        if need_dx:
+        if need_dx and _use_mfma(lib, cout, cin, spec, (ih, iw), ow):
+            # matrix-core data gradient; act'(x) of a fused input activation in its epilogue (one
+            # exp / erf per output element is noise next to the MFMA work of the tile)
+            wfrag_t = _pack_frag(lib, weight, spec, transpose=True)
+            dx = torch.empty_like(x)
+            fuse = ctx.in_act != ACT_NONE
+            _lib.check(
+                lib.pg_conv2d_mfma(
+                    dy.data_ptr(), wfrag_t.data_ptr(), 0, 0, dx.data_ptr(), n, cout, oh, ow, cin,
+                    ih, iw, len(spec.fwd_taps), spec.f_ndr, spec.f_ndc, ACT_NONE,
+                    x.data_ptr() if fuse else 0, ctx.in_act if fuse else ACT_NONE, ACT_NONE,
+                    _stream(),
+                ),
+                "pg_conv2d_mfma(dgrad)",
+            )
+        elif need_dx:
             wpk_t = _pack(lib, weight, spec, transpose=True)
             dx = torch.empty_like(x)
             # ReLU's derivative is applied in the dgrad kernel's epilogue; for ELU/GELU (exp/erf:
