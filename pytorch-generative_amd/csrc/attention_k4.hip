@@ -1,0 +1,451 @@
+// attention_k4.hip — causal attention core for d_k = 4, d_v = 16*DVT (PixelSNAIL: 1 head, d_k 4,
+// d_v 32, strict mask, L = 1024) on the fp32 matrix cores, gfx950.
+//
+// Replaces the body of CausalAttention.forward after the projections (reference
+// nn/attention.py:147-160: q k^T / sqrt(d_k), masked_fill, softmax, masked_fill(0), @ v) as
+// instantiated at models/autoregressive/pixel_snail.py:92-98, and its autograd.
+//
+// d_k = 4 is exactly the K extent of v_mfma_f32_16x16x4_f32, so a 16-key x 16-query score tile is
+// ONE MFMA, and with d_v = 32 the P.V / dP / dV products are full 16x16x4 tiles with no padding:
+//   S^T[key][query]   = K[16 x 4] . Q^T[4 x 16]                     1 MFMA   (C operand = -max / -lse2)
+//   O^T[dv][query]   += V^T[16 dv x 4 keys] . P^T[4 keys x 16]      2 DVT MFMAs x 4 key quads
+// The score accumulator holds, in lane (g = lane>>4, j = lane&15), keys 4g..4g+3 of query j; its
+// register r is directly the B operand of the r-th P.V MFMA (K index g <-> key 4g + r) while the A
+// operand is a float4 of a V^T row — no cross-lane movement anywhere in the main loops.
+//
+// CDNA4 mapping: no LDS and no workgroup cooperation. A wave (= workgroup of 64 lanes) owns the
+// 64- (or 32-) query block b of one (image, head) and then block NB-1-b, so every wave walks the same number
+// of key tiles of the causal triangle; K / V / dO fragments are read straight from the NCHW planes
+// (64-byte runs per channel row) and come from L2: all waves of an image are mapped to ONE XCD
+// (blockIdx % 8 selects the XCD), so an image's K/V enter that XCD's L2 once. Forward is two-pass
+// (row max with the score MFMA only, then exp / accumulate against the final max: no rescaling).
+#include "attention_args.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LSE_EMPTY = 1.0e30f;  // lse2 of a query with no allowed key: exp2(s - lse2) == 0
+
+struct K4Map {
+  int unit, b0, b1;  // (image, head) unit; the two 64-row blocks of this wave (b1 < 0: none)
+};
+
+// blockIdx -> (unit, block pair). Units are dealt round-robin to the 8 XCDs (blockIdx % 8 is the
+// XCD), 8 units per XCD at a time, heaviest pair first inside a group of units.
+__device__ __forceinline__ K4Map k4_map(int units, int NB) {
+  const int npair = (NB + 1) >> 1;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int G = 8;
+  const int grp = slot / (G * npair);
+  const int rem = slot - grp * (G * npair);
+  const int pr = rem / G;
+  const int ug = rem - pr * G;
+  K4Map m;
+  m.unit = (grp * G + ug) * 8 + xcd;
+  m.b0 = NB - 1 - pr;
+  m.b1 = (pr < NB - 1 - pr) ? pr : -1;
+  if (m.unit >= units) m.unit = -1;
+  return m;
+}
+
+__device__ __forceinline__ float xor_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xor_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int DVT, int QB>
+__global__ void __launch_bounds__(64) attn_fwd_k4_kernel(const PgAttnArgs a) {
+  const int L = a.L, NB = L / (16 * QB);
+  const K4Map mp = k4_map(a.N * a.heads, NB);
+  if (mp.unit < 0) return;
+  const int n = mp.unit / a.heads, h = mp.unit - n * a.heads;
+  const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
+  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
+  const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * (16 * DVT) * L;
+  float* op = a.o_out + (size_t)n * a.o_bs + (size_t)h * (16 * DVT) * L;
+  float* lp = a.lse2_out + ((size_t)n * a.heads + h) * L;
+  const int strict = a.strict;
+
+  for (int pass = 0; pass < 2; ++pass) {
+    const int b = pass == 0 ? mp.b0 : mp.b1;
+    if (b < 0) break;
+    const int q0 = b * (16 * QB);
+    const int nkt = (q0 + 16 * QB - strict + 15) >> 4;  // key tiles this block can see
+    float qf[QB];
+#pragma unroll
+    for (int qg = 0; qg < QB; ++qg) qf[qg] = qp[g * L + q0 + 16 * qg + j] * a.scale2;
+
+    // ---- pass 1: row maxima (score MFMA only)
+    float mx[QB];
+#pragma unroll
+    for (int qg = 0; qg < QB; ++qg) mx[qg] = NEG_BIG;
+    {
+      float kf = kp[g * L + j];
+      for (int kt = 0; kt < nkt; ++kt) {
+        const int key0 = kt << 4;
+        const float kf_n = (kt + 1 < nkt) ? kp[g * L + key0 + 16 + j] : 0.f;
+#pragma unroll
+        for (int qg = 0; qg < QB; ++qg) {
+          const int qq0 = q0 + 16 * qg;
+          if (key0 + strict > qq0 + 15) continue;  // every key of the tile is masked for this group
+          f32x4 s = MFMA4(kf, qf[qg], (f32x4{0.f, 0.f, 0.f, 0.f}));
+          if (key0 + 15 + strict > qq0) {  // diagonal tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (key0 + 4 * g + r + strict > qq0 + j) s[r] = NEG_BIG;
+          }
+          mx[qg] = fmaxf(mx[qg], fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+        }
+        kf = kf_n;
+      }
+    }
+    float negm[QB];
+#pragma unroll
+    for (int qg = 0; qg < QB; ++qg) {
+      const float m = xor_max(mx[qg]);
+      negm[qg] = m > 0.5f * NEG_BIG ? -m : 0.f;  // empty row: any finite value (every p is masked)
+    }
+
+    // ---- pass 2: p = exp2(s - m), l += p, O^T += V^T P^T
+    f32x4 O[QB][DVT];
+    float l[QB];
+#pragma unroll
+    for (int qg = 0; qg < QB; ++qg) l[qg] = 0.f;
+#pragma unroll
+    for (int qg = 0; qg < QB; ++qg)
+#pragma unroll
+      for (int t = 0; t < DVT; ++t) O[qg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      float kf = kp[g * L + j];
+      float4 vf[DVT];
+#pragma unroll
+      for (int t = 0; t < DVT; ++t)
+        vf[t] = *reinterpret_cast<const float4*>(vp + (size_t)(16 * t + j) * L + 4 * g);
+      for (int kt = 0; kt < nkt; ++kt) {
+        const int key0 = kt << 4;
+        float kf_n = 0.f;
+        float4 vf_n[DVT];
+        {
+          const int kn = (kt + 1 < nkt) ? key0 + 16 : key0;  // clamped prefetch of the next tile
+          kf_n = kp[g * L + kn + j];
+#pragma unroll
+          for (int t = 0; t < DVT; ++t)
+            vf_n[t] = *reinterpret_cast<const float4*>(vp + (size_t)(16 * t + j) * L + kn + 4 * g);
+        }
+#pragma unroll
+        for (int qg = 0; qg < QB; ++qg) {
+          const int qq0 = q0 + 16 * qg;
+          if (key0 + strict > qq0 + 15) continue;
+          f32x4 s = MFMA4(kf, qf[qg], (f32x4{negm[qg], negm[qg], negm[qg], negm[qg]}));
+          float p[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r]);
+          if (key0 + 15 + strict > qq0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (key0 + 4 * g + r + strict > qq0 + j) p[r] = 0.f;
+          }
+          l[qg] += (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+          for (int t = 0; t < DVT; ++t) {
+            O[qg][t] = MFMA4(vf[t].x, p[0], O[qg][t]);
+            O[qg][t] = MFMA4(vf[t].y, p[1], O[qg][t]);
+            O[qg][t] = MFMA4(vf[t].z, p[2], O[qg][t]);
+            O[qg][t] = MFMA4(vf[t].w, p[3], O[qg][t]);
+          }
+        }
+        kf = kf_n;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) vf[t] = vf_n[t];
+      }
+    }
+    // ---- normalise and write O^T[dv = 16t + 4g + r][query j], lse2
+#pragma unroll
+    for (int qg = 0; qg < QB; ++qg) {
+      const float lt = xor_sum(l[qg]);
+      const float inv = lt > 0.f ? 1.f / lt : 0.f;
+      const int qi = q0 + 16 * qg + j;
+#pragma unroll
+      for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[(size_t)(16 * t + 4 * g + r) * L + qi] = O[qg][t][r] * inv;
+      if (g == 0) lp[qi] = lt > 0.f ? -negm[qg] + log2f(lt) : LSE_EMPTY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ dQ (+ delta)
+template <int DVT, int QB>
+__global__ void __launch_bounds__(64) attn_dq_k4_kernel(const PgAttnArgs a) {
+  const int L = a.L, NB = L / (16 * QB);
+  const K4Map mp = k4_map(a.N * a.heads, NB);
+  if (mp.unit < 0) return;
+  const int n = mp.unit / a.heads, h = mp.unit - n * a.heads;
+  const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+  constexpr int DV = 16 * DVT, NS = 4 * DVT;  // dv K steps of 4
+  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
+  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
+  const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * DV * L;
+  const float* op = a.o + (size_t)n * a.o_bs + (size_t)h * DV * L;
+  const float* dop = a.d_o + (size_t)n * a.do_bs + (size_t)h * DV * L;
+  const float* lp = a.lse2_in + ((size_t)n * a.heads + h) * L;
+  float* dlt = a.delta + ((size_t)n * a.heads + h) * L;
+  float* dqp = a.dq + (size_t)n * a.dq_bs + (size_t)h * 4 * L;
+  const int strict = a.strict;
+
+  for (int pass = 0; pass < 2; ++pass) {
+    const int b = pass == 0 ? mp.b0 : mp.b1;
+    if (b < 0) break;
+    const int q0 = b * (16 * QB);
+    const int nkt = (q0 + 16 * QB - strict + 15) >> 4;
+    float qf[QB], nl[QB], dl[QB];
+    float dof[QB][NS];  // B[k = dv][j = query] of dP^T = V dO^T: dO^T[dv = 4s + g][query j]
+    float dq[QB][4];
+#pragma unroll
+    for (int qg = 0; qg < QB; ++qg) {
+      const int qi = q0 + 16 * qg + j;
+      qf[qg] = qp[g * L + qi] * a.scale2;
+      float acc = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        dof[qg][s] = dop[(size_t)(4 * s + g) * L + qi];
+        acc = fmaf(dof[qg][s], op[(size_t)(4 * s + g) * L + qi], acc);
+      }
+      dl[qg] = xor_sum(acc);  // delta_j = sum_dv dO O
+      if (g == 0) dlt[qi] = dl[qg];
+      nl[qg] = -lp[qi];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dq[qg][d] = 0.f;
+    }
+    float kf = kp[g * L + j];
+    float vfa[NS];  // A[i = key][k = dv] of dP^T: V^T[dv = 4s + g][key j]
+    float4 kr[4];   // K[d][keys 4g..4g+3] for the VALU dQ accumulation
+#pragma unroll
+    for (int s = 0; s < NS; ++s) vfa[s] = vp[(size_t)(4 * s + g) * L + j];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) kr[d] = *reinterpret_cast<const float4*>(kp + d * L + 4 * g);
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int key0 = kt << 4;
+      const int kn = (kt + 1 < nkt) ? key0 + 16 : key0;
+      const float kf_n = kp[g * L + kn + j];
+      float vfa_n[NS];
+      float4 kr_n[4];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) vfa_n[s] = vp[(size_t)(4 * s + g) * L + kn + j];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) kr_n[d] = *reinterpret_cast<const float4*>(kp + d * L + kn + 4 * g);
+#pragma unroll
+      for (int qg = 0; qg < QB; ++qg) {
+        const int qq0 = q0 + 16 * qg;
+        if (key0 + strict > qq0 + 15) continue;  // every key of the tile is masked for this group
+        f32x4 s4 = MFMA4(kf, qf[qg], (f32x4{nl[qg], nl[qg], nl[qg], nl[qg]}));
+        f32x4 dp = f32x4{-dl[qg], -dl[qg], -dl[qg], -dl[qg]};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) dp = MFMA4(vfa[s], dof[qg][s], dp);
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(s4[r]) * dp[r];
+        if (key0 + 15 + strict > qq0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + 4 * g + r + strict > qq0 + j) ds[r] = 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          dq[qg][d] += (ds[0] * kr[d].x + ds[1] * kr[d].y) + (ds[2] * kr[d].z + ds[3] * kr[d].w);
+      }
+      kf = kf_n;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) vfa[s] = vfa_n[s];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) kr[d] = kr_n[d];
+    }
+    // lanes (0..3, j) hold partial sums over their keys; lane (g, j) writes channel d = g
+#pragma unroll
+    for (int qg = 0; qg < QB; ++qg) {
+      float mine = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const float t = xor_sum(dq[qg][d]);
+        if (d == g) mine = t;
+      }
+      dqp[g * L + q0 + 16 * qg + j] = mine * a.scale;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ dK, dV
+template <int DVT, int QB>
+__global__ void __launch_bounds__(64) attn_dkv_k4_kernel(const PgAttnArgs a) {
+  const int L = a.L, NB = L / (16 * QB);
+  const K4Map mp = k4_map(a.N * a.heads, NB);
+  if (mp.unit < 0) return;
+  const int n = mp.unit / a.heads, h = mp.unit - n * a.heads;
+  const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+  constexpr int DV = 16 * DVT, NS = 4 * DVT;
+  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
+  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
+  const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * DV * L;
+  const float* dop = a.d_o + (size_t)n * a.do_bs + (size_t)h * DV * L;
+  const float* lp = a.lse2_in + ((size_t)n * a.heads + h) * L;
+  const float* dlt = a.delta + ((size_t)n * a.heads + h) * L;
+  float* dkp = a.dk + (size_t)n * a.dk_bs + (size_t)h * 4 * L;
+  float* dvp = a.dv + (size_t)n * a.dv_bs + (size_t)h * DV * L;
+  const int strict = a.strict;
+  const int nqt = L >> 4;
+
+  for (int pass = 0; pass < 2; ++pass) {
+    // key-owner: block 0 streams the most queries, so the pair is (NB-1-b0, NB-1-b1) mirrored
+    const int bb = pass == 0 ? mp.b0 : mp.b1;
+    if (bb < 0) break;
+    const int k0 = (NB - 1 - bb) * (16 * QB);
+    float kfb[QB];     // B[k = d][j = key] of S = Q K^T, per 16-key group
+    float vfb[QB][NS]; // B[k = dv][j = key] of dP = dO V^T
+    f32x4 dV[QB][DVT];
+    float dk[QB][4];
+#pragma unroll
+    for (int kg = 0; kg < QB; ++kg) {
+      const int ki = k0 + 16 * kg + j;
+      kfb[kg] = kp[g * L + ki] * a.scale2;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) vfb[kg][s] = vp[(size_t)(4 * s + g) * L + ki];
+#pragma unroll
+      for (int t = 0; t < DVT; ++t) dV[kg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dk[kg][d] = 0.f;
+    }
+    const int qt0 = (k0 + strict) >> 4;  // first query tile that sees a key of this block
+
+#define K4_LOAD(QQ, QFA, DOFA, DOFT, QR, NL, ND)                                                   \
+  {                                                                                                 \
+    QFA = qp[g * L + (QQ) + j];                                                                     \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) DOFA[s] = dop[(size_t)(4 * s + g) * L + (QQ) + j]; \
+    _Pragma("unroll") for (int t = 0; t < DVT; ++t)                                                 \
+        DOFT[t] = *reinterpret_cast<const float4*>(dop + (size_t)(16 * t + j) * L + (QQ) + 4 * g);   \
+    _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                   \
+        QR[d] = *reinterpret_cast<const float4*>(qp + d * L + (QQ) + 4 * g);                         \
+    NL = *reinterpret_cast<const float4*>(lp + (QQ) + 4 * g);                                        \
+    ND = *reinterpret_cast<const float4*>(dlt + (QQ) + 4 * g);                                       \
+  }
+    float qfa, dofa[NS];
+    float4 doft[DVT], qr[4], nl4, nd4;
+    K4_LOAD(min(qt0, nqt - 1) << 4, qfa, dofa, doft, qr, nl4, nd4)
+    for (int qt = qt0; qt < nqt; ++qt) {
+      const int qq0 = qt << 4;
+      const int qn = (qt + 1 < nqt) ? qq0 + 16 : qq0;
+      float qfa_n, dofa_n[NS];
+      float4 doft_n[DVT], qr_n[4], nl4_n, nd4_n;
+      K4_LOAD(qn, qfa_n, dofa_n, doft_n, qr_n, nl4_n, nd4_n)
+#pragma unroll
+      for (int kg = 0; kg < QB; ++kg) {
+        const int kk0 = k0 + 16 * kg;
+        if (kk0 + strict > qq0 + 15) continue;  // no query of the tile sees a key of this group
+        // S[query 4g + r][key j] - lse2[query]
+        f32x4 s4 = MFMA4(qfa, kfb[kg], (f32x4{-nl4.x, -nl4.y, -nl4.z, -nl4.w}));
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s4[r]);
+        if (kk0 + 15 + strict > qq0) {  // diagonal tile
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kk0 + j + strict > qq0 + 4 * g + r) p[r] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) {  // dV^T[dv][key] += dO^T[dv][query] P[query][key]
+          dV[kg][t] = MFMA4(doft[t].x, p[0], dV[kg][t]);
+          dV[kg][t] = MFMA4(doft[t].y, p[1], dV[kg][t]);
+          dV[kg][t] = MFMA4(doft[t].z, p[2], dV[kg][t]);
+          dV[kg][t] = MFMA4(doft[t].w, p[3], dV[kg][t]);
+        }
+        f32x4 dp = f32x4{-nd4.x, -nd4.y, -nd4.z, -nd4.w};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) dp = MFMA4(dofa[s], vfb[kg][s], dp);
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = p[r] * dp[r];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          dk[kg][d] += (ds[0] * qr[d].x + ds[1] * qr[d].y) + (ds[2] * qr[d].z + ds[3] * qr[d].w);
+      }
+      qfa = qfa_n; nl4 = nl4_n; nd4 = nd4_n;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) dofa[s] = dofa_n[s];
+#pragma unroll
+      for (int t = 0; t < DVT; ++t) doft[t] = doft_n[t];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) qr[d] = qr_n[d];
+    }
+#undef K4_LOAD
+#pragma unroll
+    for (int kg = 0; kg < QB; ++kg) {
+      const int ki = k0 + 16 * kg + j;
+      float mine = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const float t = xor_sum(dk[kg][d]);
+        if (d == g) mine = t;
+      }
+      dkp[g * L + ki] = mine * a.scale;
+#pragma unroll
+      for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dvp[(size_t)(16 * t + 4 * g + r) * L + ki] = dV[kg][t][r];
+    }
+  }
+}
+
+template <int DVT, int QB>
+void k4_launch(int which, const PgAttnArgs& a, dim3 grid, hipStream_t st) {
+  if (which == PG_ATTN_FWD)
+    hipLaunchKernelGGL((attn_fwd_k4_kernel<DVT, QB>), grid, dim3(64), 0, st, a);
+  else if (which == PG_ATTN_DQ)
+    hipLaunchKernelGGL((attn_dq_k4_kernel<DVT, QB>), grid, dim3(64), 0, st, a);
+  else
+    hipLaunchKernelGGL((attn_dkv_k4_kernel<DVT, QB>), grid, dim3(64), 0, st, a);
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// Returns 1 if these kernels took the launch (d_k == 4, d_v in {16, 32}, L % 64 == 0, 16-byte
+// aligned planes), else 0.
+int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st) {
+  if (a.dk_dim != 4 || (a.dv_dim != 16 && a.dv_dim != 32) || (a.L % 64) != 0) return 0;
+  if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) % 4 != 0) return 0;
+  if (!al16(a.k) || !al16(a.v) || !al16(a.q)) return 0;
+  if (which != PG_ATTN_FWD) {
+    if ((a.do_bs | a.dq_bs | a.dk_bs | a.dv_bs) % 4 != 0) return 0;
+    if (!al16(a.d_o) || !al16(a.lse2_in) || !al16(a.delta)) return 0;
+  }
+  const int units = a.N * a.heads;
+  // A lone wave keeps its SIMD's matrix pipe ~50 % busy (score -> exp -> P.V is one dependent chain
+  // per 16-query group), so below ~3 waves per SIMD the blocks are halved to 32 rows: twice the
+  // waves, each half as long (measured at batch 128: 1 wave per SIMD ran 2x over the MFMA bound).
+  static const int force_qb = []() { const char* e = getenv("PG_ATTN_K4_QB"); return e ? atoi(e) : 0; }();
+  int qb = ((long)units * ((a.L / 64 + 1) / 2) >= 3 * 1024) ? 4 : 2;
+  if (force_qb == 2 || force_qb == 4) qb = force_qb;
+  const int NB = a.L / (16 * qb);
+  const int npair = (NB + 1) / 2;
+  // units in groups of 64 (8 per XCD); every group has 8 * 8 * npair workgroups
+  const int groups = (units + 63) / 64;
+  dim3 grid((unsigned)(groups * 64 * npair));
+  if (a.dv_dim == 32) {
+    if (qb == 4) k4_launch<2, 4>(which, a, grid, st); else k4_launch<2, 2>(which, a, grid, st);
+  } else {
+    if (qb == 4) k4_launch<1, 4>(which, a, grid, st); else k4_launch<1, 2>(which, a, grid, st);
+  }
+  return 1;
+}

@@ -708,7 +708,10 @@ static void attn_waves(int* w) {
   w[0] = cfg[0]; w[1] = cfg[1]; w[2] = cfg[2];
 }
 
+int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st);  // attention_k4.hip
+
 int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
+  if (a0.dk_dim == 4 && a0.dv_dim != 4) return pg_attn_k4_launch(which, a0, st);
   if (a0.dk_dim != 4 || a0.dv_dim != 4) return 0;
   PgAttnArgs a = a0;
   const int NB = (a.L + 63) / 64;
