@@ -37,6 +37,9 @@ extern "C" {
 #define PG_ACT_RELU 1 /* nn.ReLU: models/autoregressive/pixel_cnn.py:33-50 */
 #define PG_ACT_ELU 2  /* F.elu alpha=1: models/autoregressive/pixel_snail.py:27-28 */
 #define PG_ACT_GELU 3 /* nn.GELU() exact erf: models/autoregressive/image_gpt.py:44 */
+/* only as the `dact` of pg_conv2d_mfma: dact_src holds ELU's OUTPUT y, derivative = y > 0 ? 1 : y + 1
+ * (a producer convolution fused F.elu into its epilogue, pixel_snail.py:54) */
+#define PG_ACT_ELU_OUT 4
 
 /* gate kinds for pg_gated_* (nn/convolution.py:46-66) */
 #define PG_GATE_TANH 0     /* tanh(a)*sigmoid(b): gated_pixel_cnn.py:57 */
@@ -186,6 +189,15 @@ int pg_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, vo
 int pg_gated_fwd(const float* x, float* y, int N, int C, int L, int gate, void* stream);
 int pg_gated_bwd(const float* x, const float* dy, float* dx, int N, int C, int L, int gate,
                  void* stream);
+/* y = res + gate(x): GatedActivation followed by the block's residual add in one pass
+ * (pixel_snail.py:55-56 `x + self._activation(out)`); L % 4 == 0, 16-byte aligned tensors. */
+int pg_gated_fwd_res(const float* x, const float* res, float* y, int N, int C, int L, int gate,
+                     void* stream);
+/* dx = dy * act'(pre) with the derivative recovered from the activation's OUTPUT v = y - res
+ * (res may be NULL): backward of the fused convolution epilogue y = act(conv + bias) + res
+ * (pixel_snail.py:27-28,113-119). act = PG_ACT_ELU (v > 0 ? 1 : v + 1) or PG_ACT_RELU. */
+int pg_act_bwd_from_out(const float* y, const float* res, const float* dy, float* dx, size_t n,
+                        int act, void* stream);
 /* out = a + b */
 int pg_add(const float* a, const float* b, float* out, size_t n, void* stream);
 /* y[n,i] = x[n,i] + p[i] (learned positional map, image_gpt.py:86,106); i < per */

@@ -57,6 +57,20 @@ __device__ __forceinline__ float pg_act_grad(float x, int act) {
       const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
       return cdf + x * pdf;
     }
+    case PG_ACT_ELU_OUT:  // x is ELU's OUTPUT: elu'(pre) = y > 0 ? 1 : y + 1
+      return x > 0.f ? 1.f : x + 1.f;
+    default:
+      return 1.f;
+  }
+}
+
+// d act / d pre-activation expressed through the activation's output y (ReLU, ELU only)
+__device__ __forceinline__ float pg_act_grad_out(float y, int act) {
+  switch (act) {
+    case PG_ACT_RELU:
+      return y > 0.f ? 1.f : 0.f;
+    case PG_ACT_ELU:
+      return y > 0.f ? 1.f : y + 1.f;
     default:
       return 1.f;
   }

@@ -294,6 +294,10 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
         break;
+      case PG_ACT_ELU_OUT:
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU_OUT);
+        break;
       default: break;
     }
     if (m + 1 < MT) { PG_MF_PRELOAD(m + 1) }
@@ -416,7 +420,7 @@ PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* b
   PG_REQUIRE(OW <= 256, PG_ESHAPE, "pg_conv2d_mfma: OW=%d wider than a 256-pixel tile", OW);
   PG_REQUIRE(in_act >= PG_ACT_NONE && in_act <= PG_ACT_GELU && out_act >= PG_ACT_NONE &&
                  out_act <= PG_ACT_GELU, PG_EINVAL, "pg_conv2d_mfma: bad activation id");
-  PG_REQUIRE(dact >= PG_ACT_NONE && dact <= PG_ACT_GELU && ((dact == PG_ACT_NONE) == (dact_src == nullptr)),
+  PG_REQUIRE(dact >= PG_ACT_NONE && dact <= PG_ACT_ELU_OUT && ((dact == PG_ACT_NONE) == (dact_src == nullptr)),
              PG_EINVAL, "pg_conv2d_mfma: dact_src / dact mismatch");
   hipStream_t st = (hipStream_t)stream;
   MfArgs a;

@@ -223,6 +223,81 @@ __global__ void bce_bwd_kernel(const float* __restrict__ z, const float* __restr
     dz[i] = g * (sigmoidf_(z[i]) - x[i]);
 }
 
+// dx = dy * act'(v), v = y - res: the activation's derivative recovered from its OUTPUT
+// (ELU: v > 0 ? 1 : v + 1; ReLU: v > 0) — backward of a convolution epilogue `y = act(conv) + res`
+template <int ACT>
+__global__ void act_bwd_out_kernel(const float* __restrict__ y, const float* __restrict__ res,
+                                   const float* __restrict__ dy, float* __restrict__ dx, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(y)[i];
+    if (res) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      v.x -= r.x; v.y -= r.y; v.z -= r.z; v.w -= r.w;
+    }
+    float4 g = reinterpret_cast<const float4*>(dy)[i];
+    g.x *= pg_act_grad_out(v.x, ACT); g.y *= pg_act_grad_out(v.y, ACT);
+    g.z *= pg_act_grad_out(v.z, ACT); g.w *= pg_act_grad_out(v.w, ACT);
+    reinterpret_cast<float4*>(dx)[i] = g;
+  }
+}
+
+// float4 gate kernels (L % 4 == 0): item = (n, c, quad of pixels)
+__global__ void gated_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                  float* __restrict__ y, size_t CL4, size_t total4, int gate) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const size_t n = i / CL4;
+    const size_t r = i - n * CL4;
+    const float4 a = reinterpret_cast<const float4*>(x)[n * 2 * CL4 + r];
+    const float4 b = reinterpret_cast<const float4*>(x)[n * 2 * CL4 + CL4 + r];
+    float4 o;
+    if (gate == PG_GATE_TANH) {
+      o.x = tanhf(a.x) * sigmoidf_(b.x); o.y = tanhf(a.y) * sigmoidf_(b.y);
+      o.z = tanhf(a.z) * sigmoidf_(b.z); o.w = tanhf(a.w) * sigmoidf_(b.w);
+    } else {
+      o.x = a.x * sigmoidf_(b.x); o.y = a.y * sigmoidf_(b.y);
+      o.z = a.z * sigmoidf_(b.z); o.w = a.w * sigmoidf_(b.w);
+    }
+    if (res) {
+      const float4 rv = reinterpret_cast<const float4*>(res)[i];
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+__device__ __forceinline__ void gate_grad(float a, float b, float g, int gate, float& da, float& db) {
+  const float sg = sigmoidf_(b);
+  if (gate == PG_GATE_TANH) {
+    const float t = tanhf(a);
+    da = g * sg * (1.f - t * t);
+    db = g * t * sg * (1.f - sg);
+  } else {
+    da = g * sg;
+    db = g * a * sg * (1.f - sg);
+  }
+}
+
+__global__ void gated_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                  float* __restrict__ dx, size_t CL4, size_t total4, int gate) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const size_t n = i / CL4;
+    const size_t r = i - n * CL4;
+    const float4 a = reinterpret_cast<const float4*>(x)[n * 2 * CL4 + r];
+    const float4 b = reinterpret_cast<const float4*>(x)[n * 2 * CL4 + CL4 + r];
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    float4 da, db;
+    gate_grad(a.x, b.x, g.x, gate, da.x, db.x);
+    gate_grad(a.y, b.y, g.y, gate, da.y, db.y);
+    gate_grad(a.z, b.z, g.z, gate, da.z, db.z);
+    gate_grad(a.w, b.w, g.w, gate, da.w, db.w);
+    reinterpret_cast<float4*>(dx)[n * 2 * CL4 + r] = da;
+    reinterpret_cast<float4*>(dx)[n * 2 * CL4 + CL4 + r] = db;
+  }
+}
+
 }  // namespace
 
 #define EW_STREAM ((hipStream_t)stream)
@@ -258,14 +333,49 @@ PG_EXPORT int pg_act_bwd(const float* x, const float* dy, float* dx, size_t n, i
   return 0;
 }
 
-PG_EXPORT int pg_gated_fwd(const float* x, float* y, int N, int C, int L, int gate, void* stream) {
-  PG_REQUIRE(x && y, PG_EINVAL, "pg_gated_fwd: null pointer");
-  PG_REQUIRE(N > 0 && C > 0 && L > 0, PG_EINVAL, "pg_gated_fwd: bad dims");
-  PG_REQUIRE(gate == PG_GATE_TANH || gate == PG_GATE_IDENTITY, PG_EINVAL, "pg_gated_fwd: bad gate");
+namespace {
+int gated_fwd_impl(const char* who, const float* x, const float* res, float* y, int N, int C, int L,
+                   int gate, void* stream) {
+  PG_REQUIRE(x && y, PG_EINVAL, "%s: null pointer", who);
+  PG_REQUIRE(N > 0 && C > 0 && L > 0, PG_EINVAL, "%s: bad dims", who);
+  PG_REQUIRE(gate == PG_GATE_TANH || gate == PG_GATE_IDENTITY, PG_EINVAL, "%s: bad gate", who);
   const size_t CL = (size_t)C * L, total = (size_t)N * CL;
-  hipLaunchKernelGGL(gated_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, EW_STREAM, x, y,
-                     C, CL, total, gate);
-  PG_LAUNCH_CHECK("pg_gated_fwd");
+  if ((L % 4) == 0 && aligned16(x) && aligned16(y) && (!res || aligned16(res))) {
+    hipLaunchKernelGGL(gated_fwd4_kernel, dim3(ew_blocks(total / 4)), dim3(EW_THREADS), 0, EW_STREAM,
+                       x, res, y, CL / 4, total / 4, gate);
+  } else {
+    PG_REQUIRE(res == nullptr, PG_ESHAPE, "%s: the fused residual needs L %% 4 == 0 and aligned tensors", who);
+    hipLaunchKernelGGL(gated_fwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, EW_STREAM, x, y,
+                       C, CL, total, gate);
+  }
+  PG_LAUNCH_CHECK(who);
+  return 0;
+}
+}  // namespace
+
+PG_EXPORT int pg_gated_fwd(const float* x, float* y, int N, int C, int L, int gate, void* stream) {
+  return gated_fwd_impl("pg_gated_fwd", x, nullptr, y, N, C, L, gate, stream);
+}
+
+PG_EXPORT int pg_gated_fwd_res(const float* x, const float* res, float* y, int N, int C, int L,
+                               int gate, void* stream) {
+  PG_REQUIRE(res, PG_EINVAL, "pg_gated_fwd_res: null residual");
+  return gated_fwd_impl("pg_gated_fwd_res", x, res, y, N, C, L, gate, stream);
+}
+
+PG_EXPORT int pg_act_bwd_from_out(const float* y, const float* res, const float* dy, float* dx,
+                                  size_t n, int act, void* stream) {
+  PG_REQUIRE(y && dy && dx, PG_EINVAL, "pg_act_bwd_from_out: null pointer");
+  PG_REQUIRE((n % 4) == 0 && aligned16(y) && aligned16(dy) && aligned16(dx) && (!res || aligned16(res)),
+             PG_ESHAPE, "pg_act_bwd_from_out: needs n %% 4 == 0 and 16-byte aligned tensors");
+  if (n == 0) return 0;
+  const int blocks = ew_blocks(n / 4);
+  switch (act) {
+    case PG_ACT_RELU: hipLaunchKernelGGL(act_bwd_out_kernel<PG_ACT_RELU>, dim3(blocks), dim3(EW_THREADS), 0, EW_STREAM, y, res, dy, dx, n / 4); break;
+    case PG_ACT_ELU:  hipLaunchKernelGGL(act_bwd_out_kernel<PG_ACT_ELU>,  dim3(blocks), dim3(EW_THREADS), 0, EW_STREAM, y, res, dy, dx, n / 4); break;
+    default: PG_REQUIRE(false, PG_EINVAL, "pg_act_bwd_from_out: act %d has no derivative in terms of its output", act);
+  }
+  PG_LAUNCH_CHECK("pg_act_bwd_from_out");
   return 0;
 }
 
@@ -275,6 +385,10 @@ PG_EXPORT int pg_gated_bwd(const float* x, const float* dy, float* dx, int N, in
   PG_REQUIRE(N > 0 && C > 0 && L > 0, PG_EINVAL, "pg_gated_bwd: bad dims");
   PG_REQUIRE(gate == PG_GATE_TANH || gate == PG_GATE_IDENTITY, PG_EINVAL, "pg_gated_bwd: bad gate");
   const size_t CL = (size_t)C * L, total = (size_t)N * CL;
+  if ((L % 4) == 0 && aligned16(x) && aligned16(dy) && aligned16(dx))
+    hipLaunchKernelGGL(gated_bwd4_kernel, dim3(ew_blocks(total / 4)), dim3(EW_THREADS), 0, EW_STREAM, x,
+                       dy, dx, CL / 4, total / 4, gate);
+  else
   hipLaunchKernelGGL(gated_bwd_kernel, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, EW_STREAM, x, dy,
                      dx, C, CL, total, gate);
   PG_LAUNCH_CHECK("pg_gated_bwd");

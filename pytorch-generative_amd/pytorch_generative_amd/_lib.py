@@ -90,6 +90,8 @@ SIGNATURES = {
     "pg_act_bwd": (c_i, [c_f, c_f, c_f, c_z, c_i, c_s]),
     "pg_gated_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_s]),
     "pg_gated_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_s]),
+    "pg_gated_fwd_res": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_s]),
+    "pg_act_bwd_from_out": (c_i, [c_f, c_f, c_f, c_f, c_z, c_i, c_s]),
     "pg_add": (c_i, [c_f, c_f, c_f, c_z, c_s]),
     "pg_add_bcast_fwd": (c_i, [c_f, c_f, c_f, c_i, c_z, c_s]),
     "pg_add_bcast_bwd": (c_i, [c_f, c_f, c_i, c_z, c_s]),

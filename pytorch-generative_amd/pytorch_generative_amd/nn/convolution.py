@@ -27,6 +27,9 @@ class Conv2d(nn.Conv2d):
               pixel_snail.py:54-55).
       in_act: "relu" | "elu" | "gelu" applied to the input on load.
       res:    tensor added to the output (fused residual).
+      out_act: "relu" | "elu" applied to conv + bias BEFORE `res` is added (epilogue fusion).
+      out_pre_scaled / in_post: the producer / consumer halves of a fused activation between two
+              convolutions (see ops.conv2d_taps); only valid when both report mfma_ok().
     """
 
     def __init__(self, *args, **kwargs):
@@ -56,12 +59,27 @@ class Conv2d(nn.Conv2d):
             self._spec = ops.ConvSpec(kh, kw, ph, pw, active=self._active_taps(), wgrad_all=True)
         return self._spec
 
-    def forward(self, x, *, crop=None, in_act=None, res=None):
+    def mfma_ok(self, x, crop=None):
+        """True when this convolution and its data gradient run on the matrix-core kernels (then
+        out_act / out_pre_scaled / in_post are available)."""
+        return (not self._down2) and ops.conv_mfma_ok(x, self.weight, self._conv_spec(), crop)
+
+    def forward(self, x, *, crop=None, in_act=None, res=None, out_act=None, out_pre_scaled=False,
+                in_post=None):
         if self._down2:
+            if out_act is not None or in_post is not None:
+                raise ValueError("Conv2d: fused output activations are not available for stride 2")
             return self._forward_down2(x, in_act, res)
+        if out_act is not None and not out_pre_scaled and not self.mfma_ok(x, crop):
+            # shapes the matrix-core path does not take: same result from separate kernels
+            y = ops.conv2d_taps(x, self.weight, self.bias, self._conv_spec(), out_hw=crop,
+                                in_act=_ACTS[in_act], weight_param=self.weight, bias_param=self.bias)
+            y = ops._Act.apply(y, _ACTS[out_act])
+            return y if res is None else ops.add(y, res)
         return ops.conv2d_taps(
             x, self.weight, self.bias, self._conv_spec(), out_hw=crop, in_act=_ACTS[in_act],
-            res=res, weight_param=self.weight, bias_param=self.bias,
+            res=res, weight_param=self.weight, bias_param=self.bias, out_act=_ACTS[out_act],
+            out_pre_scaled=out_pre_scaled, in_post=_ACTS[in_post],
         )
 
     def _forward_down2(self, x, in_act, res):
@@ -137,9 +155,9 @@ class CausalConv2d(Conv2d):
         m = self.mask[0, 0].detach().to("cpu")
         return [(u, v) for u in range(m.shape[0]) for v in range(m.shape[1]) if m[u, v] != 0]
 
-    def forward(self, x, *, crop=None, in_act=None, res=None):
+    def forward(self, x, *, crop=None, in_act=None, res=None, **kw):
         ops.mul_inplace_(self.weight.data, self.mask)
-        return super().forward(x, crop=crop, in_act=in_act, res=res)
+        return super().forward(x, crop=crop, in_act=in_act, res=res, **kw)
 
 
 class GatedActivation(nn.Module):
@@ -161,10 +179,11 @@ class GatedActivation(nn.Module):
                 "GatedActivation on the HIP path supports torch.tanh and nn.Identity() only"
             )
 
-    def forward(self, x):
+    def forward(self, x, *, res=None):
+        """res (extension): tensor added to the gated output in the same kernel."""
         _, c, _, _ = x.shape
         assert c % 2 == 0, "x must have an even number of channels."
-        return ops.gated_activation(x, self._gate)
+        return ops.gated_activation(x, self._gate, res)
 
 
 class NCHWLayerNorm(nn.LayerNorm):

@@ -20,6 +20,7 @@ import torch
 from pytorch_generative_amd import _lib
 
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_GELU = 0, 1, 2, 3
+ACT_ELU_OUT = 4  # dgrad epilogue only: derivative of ELU from its output (include/pg_hip.h)
 GATE_TANH, GATE_IDENTITY = 0, 1
 _ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "elu": ACT_ELU, "gelu": ACT_GELU}
 
@@ -128,7 +129,8 @@ def _pack(lib, weight, spec, transpose):
 
 class _ConvTaps(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, res, spec, out_hw, in_act, gw, gb):
+    def forward(ctx, x, weight, bias, res, spec, out_hw, in_act, gw, gb, out_act=ACT_NONE,
+                out_pre_scaled=False, in_post=ACT_NONE):
         lib = _lib.load()
         x = _chk(x, "conv2d.x")
         weight = _chk(weight, "conv2d.weight")
@@ -144,13 +146,17 @@ class _ConvTaps(torch.autograd.Function):
             if tuple(res.shape) != (n, cout, oh, ow):
                 raise ValueError("conv2d: residual shape mismatch")
         out = torch.empty((n, cout, oh, ow), device=x.device, dtype=torch.float32)
-        if _use_mfma(lib, cin, cout, spec, (oh, ow), iw):
+        mfma = _use_mfma(lib, cin, cout, spec, (oh, ow), iw)
+        if (out_act != ACT_NONE or in_post != ACT_NONE) and not mfma:
+            raise ValueError("conv2d: fused output activations need the matrix-core path "
+                             "(check ops.conv_mfma_ok first)")
+        if mfma:
             wfrag = _pack_frag(lib, weight, spec, transpose=False)
             _lib.check(
                 lib.pg_conv2d_mfma(
                     x.data_ptr(), wfrag.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih,
                     iw, cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, 0, ACT_NONE,
-                    ACT_NONE, _stream(),
+                    out_act, _stream(),
                 ),
                 "pg_conv2d_mfma",
             )
@@ -164,22 +170,37 @@ class _ConvTaps(torch.autograd.Function):
                 ),
                 "pg_conv2d_taps",
             )
-        ctx.save_for_backward(x, weight)
+        if out_act != ACT_NONE and not out_pre_scaled:
+            # backward recovers act' from the output: v = out - res
+            ctx.save_for_backward(x, weight, out, res) if res is not None else ctx.save_for_backward(x, weight, out)
+        else:
+            ctx.save_for_backward(x, weight)
         ctx.spec, ctx.in_act, ctx.has_bias, ctx.has_res = spec, in_act, bias is not None, res is not None
         ctx.gw, ctx.gb = gw, gb
+        ctx.out_act, ctx.out_pre_scaled, ctx.in_post = out_act, out_pre_scaled, in_post
         return out
 
     @staticmethod
     def backward(ctx, dy):
         need = ctx.needs_input_grad
-        return _ConvTaps.backward_impl(ctx, dy, need[0], need[1], ctx.has_bias and need[2])
+        return _ConvTaps.backward_impl(ctx, dy, need[0], need[1], ctx.has_bias and need[2]) + (None, None, None)
 
     @staticmethod
     def backward_impl(ctx, dy, need_dx, need_w, need_b):
         lib = _lib.load()
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
         spec = ctx.spec
         dy = _chk(dy, "conv2d.dy")
+        dres = dy if ctx.has_res else None
+        out_act = getattr(ctx, "out_act", ACT_NONE)
+        in_post = getattr(ctx, "in_post", ACT_NONE)
+        if out_act != ACT_NONE and not ctx.out_pre_scaled:
+            out = ctx.saved_tensors[2]
+            res = ctx.saved_tensors[3] if ctx.has_res else None
+            g = torch.empty_like(dy)
+            _lib.check(lib.pg_act_bwd_from_out(out.data_ptr(), _p(res), dy.data_ptr(), g.data_ptr(),
+                                               dy.numel(), out_act, _stream()), "pg_act_bwd_from_out")
+            dy = g
         n, cin, ih, iw = x.shape
         _, cout, oh, ow = dy.shape
         dx = dw = db = None
@@ -188,13 +209,13 @@ class _ConvTaps(torch.autograd.Function):
             # exp / erf per output element is noise next to the MFMA work of the tile)
             wfrag_t = _pack_frag(lib, weight, spec, transpose=True)
             dx = torch.empty_like(x)
-            fuse = ctx.in_act != ACT_NONE
+            dact = ctx.in_act if ctx.in_act != ACT_NONE else (ACT_ELU_OUT if in_post == ACT_ELU else ACT_NONE)
+            fuse = dact != ACT_NONE
             _lib.check(
                 lib.pg_conv2d_mfma(
                     dy.data_ptr(), wfrag_t.data_ptr(), 0, 0, dx.data_ptr(), n, cout, oh, ow, cin,
                     ih, iw, len(spec.fwd_taps), spec.f_ndr, spec.f_ndc, ACT_NONE,
-                    x.data_ptr() if fuse else 0, ctx.in_act if fuse else ACT_NONE, ACT_NONE,
-                    _stream(),
+                    x.data_ptr() if fuse else 0, dact, ACT_NONE, _stream(),
                 ),
                 "pg_conv2d_mfma(dgrad)",
             )
@@ -244,7 +265,6 @@ class _ConvTaps(torch.autograd.Function):
                 ),
                 "pg_conv2d_wgrad",
             )
-        dres = dy if ctx.has_res else None
         return dx, dw, db, dres, None, None, None, None, None
 
 
@@ -303,7 +323,7 @@ class _ConvPair(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         need = ctx.needs_input_grad
-        dx, _, _, _, *_ = _ConvTaps.backward_impl(ctx, dy, need[0], need[1] or need[3], need[2] or need[4])
+        dx = _ConvTaps.backward_impl(ctx, dy, need[0], need[1] or need[3], need[2] or need[4])[0]
         return dx, None, None, None, None, None, None, None
 
 
@@ -314,9 +334,26 @@ def conv2d_pair(x, conv_a, conv_b, views, spec, out_hw=None):
                            tuple(out_hw))
 
 
+def conv_mfma_ok(x, weight, spec, out_hw=None):
+    """True if this convolution AND its data gradient run on the matrix-core kernels (the fused
+    output-activation / post-activation-input protocols of conv2d_taps need both)."""
+    if out_hw is None:
+        out_hw = spec.full_out(x.shape[2], x.shape[3])
+    lib = _lib.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    return (x.is_cuda and _use_mfma(lib, cin, cout, spec, out_hw, x.shape[3])
+            and _use_mfma(lib, cout, cin, spec, (x.shape[2], x.shape[3]), out_hw[1]))
+
+
 def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
-                weight_param=None, bias_param=None):
-    """y = conv(act(x)) + bias (+ res), cropped to out_hw (defaults to the full extent)."""
+                weight_param=None, bias_param=None, out_act=ACT_NONE, out_pre_scaled=False,
+                in_post=ACT_NONE):
+    """y = out_act(conv(in_act(x)) + bias) (+ res), cropped to out_hw (defaults to the full extent).
+
+    out_act (matrix-core path only): activation fused into the epilogue; its backward recovers act'
+    from the output (ELU / ReLU). out_pre_scaled=True declares that the ONLY consumer of y hands back
+    a gradient already multiplied by act'(y) — the consumer is a convolution called with
+    in_post=<that activation>, which applies the factor in its data-gradient epilogue."""
     if out_hw is None:
         out_hw = spec.full_out(x.shape[2], x.shape[3])
     # outputs beyond the "full" extent read only zero padding; allow up to one kernel's worth
@@ -325,7 +362,8 @@ def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
     if out_hw[0] > full[0] + spec.kh or out_hw[1] > full[1] + spec.kw or min(out_hw) < 1:
         raise ValueError(f"conv2d: requested output {out_hw} exceeds the full extent {full}")
     return _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act,
-                           _sink(weight_param), _sink(bias_param))
+                           _sink(weight_param), _sink(bias_param), out_act, bool(out_pre_scaled),
+                           in_post)
 
 
 # --------------------------------------------------------------------------------------------
@@ -769,16 +807,23 @@ def gelu(x):
 
 class _Gated(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gate):
+    def forward(ctx, x, gate, res=None):
         lib = _lib.load()
         x = _chk(x, "gated.x")
         n, c2, h, w = x.shape
         assert c2 % 2 == 0, "x must have an even number of channels."
         y = torch.empty((n, c2 // 2, h, w), device=x.device, dtype=torch.float32)
-        _lib.check(lib.pg_gated_fwd(x.data_ptr(), y.data_ptr(), n, c2 // 2, h * w, gate, _stream()),
-                   "pg_gated_fwd")
+        if res is None:
+            _lib.check(lib.pg_gated_fwd(x.data_ptr(), y.data_ptr(), n, c2 // 2, h * w, gate, _stream()),
+                       "pg_gated_fwd")
+        else:
+            res = _chk(res, "gated.res")
+            if res.shape != y.shape:
+                raise ValueError("gated_activation: residual shape mismatch")
+            _lib.check(lib.pg_gated_fwd_res(x.data_ptr(), res.data_ptr(), y.data_ptr(), n, c2 // 2,
+                                            h * w, gate, _stream()), "pg_gated_fwd_res")
         ctx.save_for_backward(x)
-        ctx.gate = gate
+        ctx.gate, ctx.has_res = gate, res is not None
         return y
 
     @staticmethod
@@ -790,11 +835,15 @@ class _Gated(torch.autograd.Function):
         dx = torch.empty_like(x)
         _lib.check(lib.pg_gated_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, c2 // 2, h * w,
                                     ctx.gate, _stream()), "pg_gated_bwd")
-        return dx, None
+        return dx, None, (dy if ctx.has_res else None)
 
 
-def gated_activation(x, gate):
-    return _Gated.apply(x, gate)
+def gated_activation(x, gate, res=None):
+    """act(x[:, :C]) * sigmoid(x[:, C:]) (+ res): GatedActivation, optionally fused with the
+    residual add that follows it in PixelSNAIL's ResidualBlock (pixel_snail.py:55-56)."""
+    if res is not None and ((x.shape[2] * x.shape[3]) % 4 != 0):
+        return add(res, _Gated.apply(x, gate))
+    return _Gated.apply(x, gate, res)
 
 
 class _Add(torch.autograd.Function):
