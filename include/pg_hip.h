@@ -103,6 +103,11 @@ size_t pg_conv_frag_floats(int K_channels, int M_channels, int T);
 int pg_pack_conv_weight_frag(const float* w, float* wfrag, int Cout, int Cin, int KH, int KW,
                              int T, const int* tap_u, const int* tap_v, int transpose,
                              void* stream);
+/* both orientations of one weight in ONE launch (either output may be NULL): the forward pass packs
+ * the data-gradient fragments it will need in backward at the same time */
+int pg_pack_conv_weight_frag2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout,
+                              int Cin, int KH, int KW, int T, const int* tap_u, const int* tap_v,
+                              void* stream);
 
 /* Weight + bias gradient (MFMA f32 16x16x4). The result is ADDED to dw/db (the caller zeroes
  * them once per step); per-workgroup partial sums go through `workspace` and a second,

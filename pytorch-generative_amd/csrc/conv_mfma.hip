@@ -25,6 +25,7 @@
 //  * weights arrive as ready-made A fragments (pg_pack_conv_weight_frag) and are copied to LDS with
 //    float4 loads; every lane reads its own dword (conflict free).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -317,36 +318,43 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
 //   transpose==0: Wsel[o][c][t] = w[o][c][u_t][v_t]   (forward:       M = Cout, K channels = Cin)
 //   transpose==1: Wsel[o][c][t] = w[c][o][u_t][v_t]   (data gradient: M = Cin,  K channels = Cout)
 // zero outside (o >= M, c >= K channels).
+struct FragPackJob {
+  float* wfrag;
+  int transpose, M, Kc, KQ, MT, chunks;
+  long total;
+};
 struct FragPackArgs {
   const float* w;
-  float* wfrag;
-  int Cout, Cin, KH, KW, T, transpose;
-  int M, Kc, KQ, MT, chunks;
+  int Cout, Cin, KH, KW, T, njobs;
+  FragPackJob job[2];  // forward and / or data-gradient fragments of the same weight in one launch
   int tap_u[PG_MAX_TAPS];
   int tap_v[PG_MAX_TAPS];
 };
 
 __global__ void pack_frag_kernel(const FragPackArgs p) {
-  const long total = (long)p.chunks * p.KQ * p.MT * 64;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
+  const long total = p.job[0].total + (p.njobs > 1 ? p.job[1].total : 0);
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total;
+       i0 += (long)gridDim.x * blockDim.x) {
+    const bool second = i0 >= p.job[0].total;
+    const FragPackJob& jb = p.job[second ? 1 : 0];
+    const long i = second ? i0 - p.job[0].total : i0;
     const int lane = (int)(i & 63);
     long rest = i >> 6;
-    const int m = (int)(rest % p.MT);
-    rest /= p.MT;
-    const int kq = (int)(rest % p.KQ);
-    const int chunk = (int)(rest / p.KQ);
+    const int m = (int)(rest % jb.MT);
+    rest /= jb.MT;
+    const int kq = (int)(rest % jb.KQ);
+    const int chunk = (int)(rest / jb.KQ);
     const int o = chunk * MF_CO_CHUNK + m * 16 + (lane & 15);
     const int g = kq / p.T;
     const int t = kq - g * p.T;
     const int c = g * 4 + (lane >> 4);
     float v = 0.f;
-    if (o < p.M && c < p.Kc) {
-      const int co = p.transpose ? c : o;
-      const int ci = p.transpose ? o : c;
+    if (o < jb.M && c < jb.Kc) {
+      const int co = jb.transpose ? c : o;
+      const int ci = jb.transpose ? o : c;
       v = p.w[(((size_t)co * p.Cin + ci) * p.KH + p.tap_u[t]) * p.KW + p.tap_v[t]];
     }
-    p.wfrag[i] = v;
+    jb.wfrag[i] = v;
   }
 }
 
@@ -362,6 +370,17 @@ int mf_launch(const MfArgs& a, int nt, dim3 grid, size_t shmem, hipStream_t st) 
     default: hipLaunchKernelGGL((conv_mfma_kernel<MT, 4>), grid, dim3(MF_THREADS), shmem, st, a); break;
   }
   return 0;
+}
+
+static void mf_pack_job(FragPackJob& j, float* wfrag, int Cout, int Cin, int T, int transpose) {
+  j.wfrag = wfrag;
+  j.transpose = transpose;
+  j.M = transpose ? Cin : Cout;
+  j.Kc = transpose ? Cout : Cin;
+  j.KQ = ((j.Kc + 3) / 4) * T;
+  j.MT = mf_mt(j.M);
+  j.chunks = mf_chunks(j.M);
+  j.total = (long)j.chunks * j.KQ * j.MT * 64;
 }
 
 }  // namespace
@@ -380,31 +399,38 @@ PG_EXPORT size_t pg_conv_frag_floats(int K_channels, int M_channels, int T) {
   return (size_t)mf_chunks(M_channels) * KQ * mf_mt(M_channels) * 64;
 }
 
-PG_EXPORT int pg_pack_conv_weight_frag(const float* w, float* wfrag, int Cout, int Cin, int KH,
-                                       int KW, int T, const int* tap_u, const int* tap_v,
-                                       int transpose, void* stream) {
-  PG_REQUIRE(w && wfrag && tap_u && tap_v, PG_EINVAL, "pg_pack_conv_weight_frag: null pointer");
+
+PG_EXPORT int pg_pack_conv_weight_frag2(const float* w, float* wfrag_fwd, float* wfrag_dgrad,
+                                        int Cout, int Cin, int KH, int KW, int T, const int* tap_u,
+                                        const int* tap_v, void* stream) {
+  PG_REQUIRE(w && (wfrag_fwd || wfrag_dgrad) && tap_u && tap_v, PG_EINVAL,
+             "pg_pack_conv_weight_frag: null pointer");
   PG_REQUIRE(T >= 1 && T <= PG_MAX_TAPS, PG_ESHAPE, "pg_pack_conv_weight_frag: T=%d not in [1,%d]",
              T, PG_MAX_TAPS);
   FragPackArgs p;
-  p.w = w; p.wfrag = wfrag; p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.T = T;
-  p.transpose = transpose;
-  p.M = transpose ? Cin : Cout;
-  p.Kc = transpose ? Cout : Cin;
-  p.KQ = ((p.Kc + 3) / 4) * T;
-  p.MT = mf_mt(p.M);
-  p.chunks = mf_chunks(p.M);
+  p.w = w; p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.T = T;
+  p.njobs = 0;
+  if (wfrag_fwd) mf_pack_job(p.job[p.njobs++], wfrag_fwd, Cout, Cin, T, 0);
+  if (wfrag_dgrad) mf_pack_job(p.job[p.njobs++], wfrag_dgrad, Cout, Cin, T, 1);
+  if (p.njobs == 1) p.job[1] = p.job[0];
   for (int t = 0; t < T; ++t) {
     PG_REQUIRE(tap_u[t] >= 0 && tap_u[t] < KH && tap_v[t] >= 0 && tap_v[t] < KW, PG_EINVAL,
                "pg_pack_conv_weight_frag: tap %d (%d,%d) outside %dx%d", t, tap_u[t], tap_v[t], KH, KW);
     p.tap_u[t] = tap_u[t];
     p.tap_v[t] = tap_v[t];
   }
-  const long total = (long)p.chunks * p.KQ * p.MT * 64;
+  const long total = p.job[0].total + (p.njobs > 1 ? p.job[1].total : 0);
   const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
   hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   PG_LAUNCH_CHECK("pg_pack_conv_weight_frag");
   return 0;
+}
+
+PG_EXPORT int pg_pack_conv_weight_frag(const float* w, float* wfrag, int Cout, int Cin, int KH,
+                                       int KW, int T, const int* tap_u, const int* tap_v,
+                                       int transpose, void* stream) {
+  return pg_pack_conv_weight_frag2(w, transpose ? nullptr : wfrag, transpose ? wfrag : nullptr, Cout,
+                                   Cin, KH, KW, T, tap_u, tap_v, stream);
 }
 
 PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* bias,
@@ -437,13 +463,15 @@ PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* b
   a.min_dr = min_dr; a.min_dc = min_dc;
   // pixel tile: whole rows of one image (TR rows), or NI whole images when an image is <= 128 px
   const int L = OH * OW;
+  static const int px_cap = []() { const char* e = getenv("PG_MF_PX"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 192) ? v : 256; }();
   if (L <= 128) {
     a.NI = 256 / L;
     if (a.NI > N) a.NI = N;
     a.TR = OH;
   } else {
     a.NI = 1;
-    a.TR = 256 / OW;
+    a.TR = px_cap / OW;
+    if (a.TR < 1) a.TR = 1;
     if (a.TR > OH) a.TR = OH;
     // even out the row tiles (e.g. 28 rows: 4 tiles of 7 instead of 9,9,9,1)
     const int nt_rows = (OH + a.TR - 1) / a.TR;

@@ -19,6 +19,7 @@
 // so both fragment reads are bank-conflict free. Each workgroup walks many pixel tiles and
 // flushes once with fp32 atomics (caller zeroes dw/db once per step).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,6 +28,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WG_THREADS = 256;
 constexpr int CO_CHUNK = 64;  // dy channels staged per block
 constexpr int CI_CHUNK = 32;  // x channels staged per block (2 MFMA column tiles)
+constexpr int DS = 4;    // float4 staging slots per thread per tile: dy
+constexpr int XSW = 6;   // ... and x
 constexpr int LDS_BUDGET_FLOATS = 18000;  // ~72 KB -> two workgroups per CU: one stages while the other runs MFMAs (measured best of 36k/18k/9.5k)
 
 struct WgArgs {
@@ -40,13 +43,15 @@ struct WgArgs {
   int dump;                 // LDS float index of the dump word (past every tile / scratch area)
   int vec_dy, vec_x, qshift_dy, qshift_x;  // float4 staging when rows are 16-byte aligned
   float inv_TR, inv_xh;
+  int prefetch;             // float4 slot staging with register prefetch (both tensors 16-byte aligned rows)
+  int Qd, Qx, dslots, xslots;  // quads per row and slots per tile (dy / x)
   int tapoff[PG_MAX_TAPS];
   int tap_u[PG_MAX_TAPS];
   int tap_v[PG_MAX_TAPS];
 };
 
-template <int NT, int NCIT>
-__global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) {
+template <int NT, int NCIT, bool PF>
+__global__ void __launch_bounds__(WG_THREADS, NT <= 4 ? 2 : 1) conv_wgrad_kernel(const WgArgs a) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,6 +87,131 @@ __global__ void __launch_bounds__(WG_THREADS) conv_wgrad_kernel(const WgArgs a) 
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (PF) {
+      // ---- slot staging: this thread's float4 share of a (dy, x) tile pair is the same set of
+      // (channel, tile row, quad) elements for every tile; the loads of tile i+1 are issued before the
+      // MFMA loop of tile i and committed to LDS after it (global latency under the matrix pipe)
+      int d_goff[DS], d_meta[DS], x_goff[XSW], x_meta[XSW];  // meta: LDS offset | mask << 16 | row << 20
+#pragma unroll
+      for (int k = 0; k < DS; ++k) {
+        int e = tid + k * WG_THREADS;
+        const bool in = e < a.dslots;
+        e = in ? e : 0;
+        const int q = e % a.Qd; e /= a.Qd;
+        const int tr = e % a.TR;
+        const int ch = e / a.TR;
+        d_goff[k] = in && ch < nco ? (ch * a.OH + tr) * a.OW + 4 * q : -1;
+        d_meta[k] = (ch * a.S_dy + tr * a.SW + 4 * q) | (0xf << 16) | (tr << 20);
+      }
+#pragma unroll
+      for (int k = 0; k < XSW; ++k) {
+        int e = tid + k * WG_THREADS;
+        const bool in = e < a.xslots;
+        e = in ? e : 0;
+        const int q = e % a.Qx; e /= a.Qx;
+        const int tr = e % a.xh;
+        const int ch = e / a.xh;
+        const int tcol = 4 * q - a.min_dc;
+        int mask = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (tcol + i >= 0 && tcol + i < a.SW) mask |= 1 << i;
+        x_goff[k] = in && ch < nci ? (ch * a.IH + tr) * a.IW + 4 * q : -1;
+        x_meta[k] = (ch * a.S_x + tr * a.SW + tcol + 4) | (mask << 16) | (tr << 20);
+      }
+      float4 dv[DS], xv[XSW];
+#pragma unroll
+      for (int k = 0; k < DS; ++k) dv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < XSW; ++k) xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      int dok = 0, xok = 0;
+#define PG_WG_ISSUE(TILE)                                                                     \
+  {                                                                                           \
+    const int n_ = (TILE) / a.tiles_per_img;                                                  \
+    const int row0_ = ((TILE) - n_ * a.tiles_per_img) * a.TR;                                 \
+    const float* dyb_ = a.dy + (((size_t)n_ * a.Cout + co0) * a.OH + row0_) * a.OW;           \
+    const float* xb_ = a.x + (((size_t)n_ * a.Cin + ci0) * a.IH + (row0_ + a.min_dr)) * a.IW; \
+    dok = 0; xok = 0;                                                                         \
+    _Pragma("unroll") for (int k = 0; k < DS; ++k) {                                          \
+      const int tr = d_meta[k] >> 20;                                                         \
+      if (d_goff[k] >= 0 && row0_ + tr < a.OH) {                                              \
+        dv[k] = *reinterpret_cast<const float4*>(dyb_ + d_goff[k]);                           \
+        dok |= 1 << k;                                                                        \
+      }                                                                                       \
+    }                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < XSW; ++k) {                                         \
+      const int ir = row0_ + a.min_dr + (x_meta[k] >> 20);                                    \
+      if (x_goff[k] >= 0 && ir >= 0 && ir < a.IH) {                                           \
+        xv[k] = *reinterpret_cast<const float4*>(xb_ + x_goff[k]);                            \
+        xok |= 1 << k;                                                                        \
+      }                                                                                       \
+    }                                                                                         \
+  }
+#define PG_WG_COMMIT_X(ACT)                                                      \
+  _Pragma("unroll") for (int k = 0; k < XSW; ++k) {                              \
+    const bool ld = (xok >> k) & 1;                                              \
+    const int loff = (x_meta[k] & 0xffff) - 4;                                   \
+    const float e[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                              \
+      const bool wr = x_goff[k] >= 0 && ((x_meta[k] >> (16 + i)) & 1);           \
+      xl[wr ? loff + i : xdump] = ld ? pg_apply_act(e[i], ACT) : 0.f;            \
+    }                                                                            \
+  }
+      const int xdump = a.dump - (int)(xl - lds);
+      int tile = blockIdx.x;
+      if (tile < a.total_tiles) PG_WG_ISSUE(tile)
+      for (; tile < a.total_tiles; tile += gridDim.x) {
+        __syncthreads();  // the previous tile's fragment reads are done
+#pragma unroll
+        for (int k = 0; k < DS; ++k) {  // rows past the image (last tile) are written as zeros
+          if (d_goff[k] >= 0) {  // (channel strides are == 2 mod 32: dword stores)
+            const bool ld = (dok >> k) & 1;
+            float* d = dyl + (d_meta[k] & 0xffff);
+            d[0] = ld ? dv[k].x : 0.f; d[1] = ld ? dv[k].y : 0.f;
+            d[2] = ld ? dv[k].z : 0.f; d[3] = ld ? dv[k].w : 0.f;
+          }
+        }
+        switch (a.in_act) {  // wave-uniform
+          case PG_ACT_RELU: PG_WG_COMMIT_X(PG_ACT_RELU) break;
+          case PG_ACT_ELU:  PG_WG_COMMIT_X(PG_ACT_ELU) break;
+          case PG_ACT_GELU: PG_WG_COMMIT_X(PG_ACT_GELU) break;
+          default:          PG_WG_COMMIT_X(PG_ACT_NONE) break;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.total_tiles) PG_WG_ISSUE(tile + (int)gridDim.x)
+      // ---- MFMA over the tile's positions
+        if (cot < ncot_real) {
+          // tap offsets hoisted out of the K loop (a kernarg s_load per tap per step shares
+          // lgkmcnt with the ds_reads), and the step body is branch-free: 1 + NT*NCIT ds_reads are
+          // issued back to back, then the MFMAs.
+          int toff[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) toff[t] = a.tapoff[t0 + (t < tcount ? t : 0)];
+          const bool bias_pass = do_bias && t0 == 0;
+#pragma unroll 2
+          for (int p0 = kpart * 4; p0 < a.npos; p0 += 4 * ks) {
+            const float av = dyl[a_base + p0];
+            float bv[NCIT][NT];
+#pragma unroll
+            for (int c = 0; c < NCIT; ++c)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) bv[c][t] = xl[b_base + c * 16 * a.S_x + toff[t] + p0];
+            // keep the 1 + NT*NCIT ds_reads together in front of the MFMAs: left alone, the scheduler
+            // interleaves them one by one (ds_read, s_waitcnt lgkmcnt(0), v_mfma, ...) to save registers
+            // and every MFMA eats a full LDS latency
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NCIT; ++c)
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+                acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[c][t], acc[c][t], 0, 0, 0);
+            if (bias_pass) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.0f, accb, 0, 0, 0);
+          }
+        }
+      }
+#undef PG_WG_ISSUE
+#undef PG_WG_COMMIT_X
+    } else
     for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
       const int n = tile / a.tiles_per_img;
       const int row0 = (tile - n * a.tiles_per_img) * a.TR;
@@ -358,36 +488,35 @@ struct RedArgs {
   int tap_v[PG_MAX_TAPS];
 };
 
-// block = 8 consecutive slots x 32 row groups: the G-row sum is split 32 ways (short dependent
-// chains: this kernel is pure latency) and finished through LDS.
+// block = 64 consecutive slots x 4 row groups: every load instruction covers 256 contiguous bytes of
+// one partial row (the first version read 32-byte pieces of 32 rows: 8.3 us per call on PixelSNAIL's
+// 16 K-slot gradients); each thread sums G/4 rows with 8 loads in flight, the groups meet in LDS.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedArgs a) {
-  __shared__ float red[32][9];
-  const int sl = threadIdx.x & 7, rg = threadIdx.x >> 3;
-  const long s = (long)blockIdx.x * 8 + sl;
+  __shared__ float red[4][64];
+  const int sl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const long s = (long)blockIdx.x * 64 + sl;
   const long nw = (long)a.Cout * a.Cin * a.T;
   const long total = nw + (a.db ? a.Cout : 0);
-  float acc0 = 0.f, acc1 = 0.f;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (s < total) {
     const float* p = a.part + s;
     int g = rg;
-    for (; g + 32 < a.G; g += 64) {
-      acc0 += p[(size_t)g * a.part_stride];
-      acc1 += p[(size_t)(g + 32) * a.part_stride];
+    for (; g + 28 < a.G; g += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += p[(size_t)(g + 4 * u) * a.part_stride];
     }
-    if (g < a.G) acc0 += p[(size_t)g * a.part_stride];
+    for (; g < a.G; g += 4) acc[0] += p[(size_t)g * a.part_stride];
   }
-  red[rg][sl] = acc0 + acc1;
+  red[rg][sl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
   if (rg != 0 || s >= total) return;
-  float acc = 0.f;
-#pragma unroll
-  for (int r = 0; r < 32; ++r) acc += red[r][sl];
+  const float sum = (red[0][sl] + red[1][sl]) + (red[2][sl] + red[3][sl]);
   if (s < nw) {
     const int t = (int)(s % a.T);
     const long cc = s / a.T;  // co*Cin + ci
-    a.dw[(cc * a.KH + a.tap_u[t]) * a.KW + a.tap_v[t]] += acc;
+    a.dw[(cc * a.KH + a.tap_u[t]) * a.KW + a.tap_v[t]] += sum;
   } else {
-    a.db[s - nw] += acc;
+    a.db[s - nw] += sum;
   }
 }
 
@@ -398,7 +527,7 @@ int launch_reduce(const float* part, long stride, int G, float* dw, float* db, i
   r.Cout = Cout; r.Cin = Cin; r.KH = KH; r.KW = KW; r.T = T;
   for (int t = 0; t < T; ++t) { r.tap_u[t] = tap_u[t]; r.tap_v[t] = tap_v[t]; }
   const long total = (long)Cout * Cin * T + (db ? Cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 7) / 8)), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, r);
   return 0;
 }
 
@@ -484,6 +613,19 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   int TR = (LDS_BUDGET_FLOATS - fixed) / ((nco_alloc + nci) * a.SW);
   PG_REQUIRE(TR >= 1, PG_ESHAPE, "pg_conv2d_wgrad: row of %d (+%d halo) too wide for LDS", OW, hc);
   if (TR > OH) TR = OH;
+  // register-prefetch staging: rows of both tensors 16-byte aligned in global memory
+  static const bool pf_on = []() { const char* e = getenv("PG_WGRAD_PREFETCH"); return !(e && e[0] == '0'); }();
+  a.prefetch = pf_on && (OW % 4 == 0) && (IW % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
+  a.Qd = OW / 4;
+  a.Qx = IW / 4;
+  if (a.prefetch) {
+    while (TR > 1 && ((long)nco * TR * a.Qd > (long)DS * WG_THREADS ||
+                      (long)nci * (TR + hr) * a.Qx > (long)XSW * WG_THREADS))
+      --TR;
+    if ((long)nco * TR * a.Qd > (long)DS * WG_THREADS ||
+        (long)nci * (TR + hr) * a.Qx > (long)XSW * WG_THREADS || TR + hr >= 2048)
+      a.prefetch = 0;
+  }
   a.TR = TR;
   a.xh = TR + hr;
   a.tiles_per_img = (OH + TR - 1) / TR;
@@ -491,6 +633,8 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   const int kq = 16;  // npos multiple of 4*ks for every ks in {1,2,4}
   a.npos = ((TR * a.SW + kq - 1) / kq) * kq;
   a.S_dy = pad_stride(a.npos);
+  a.dslots = nco * a.TR * a.Qd;
+  a.xslots = nci * a.xh * a.Qx;
   a.S_x = pad_stride(a.npos + hr * a.SW + hc + 4);
   for (int t = 0; t < T; ++t) {
     a.tapoff[t] = (tap_dr[t] - min_dr) * a.SW + (tap_dc[t] - min_dc);
@@ -523,7 +667,11 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   shmem += 16;
   PG_REQUIRE(shmem <= 160 * 1024, PG_ESHAPE, "pg_conv2d_wgrad: LDS %zu B over budget", shmem);
   dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
-#define PG_WG(NT, NC) hipLaunchKernelGGL((conv_wgrad_kernel<NT, NC>), grid, dim3(WG_THREADS), shmem, st, a)
+#define PG_WG(NT, NC)                                                                              \
+  {                                                                                               \
+    if (a.prefetch) hipLaunchKernelGGL((conv_wgrad_kernel<NT, NC, true>), grid, dim3(WG_THREADS), shmem, st, a);  \
+    else hipLaunchKernelGGL((conv_wgrad_kernel<NT, NC, false>), grid, dim3(WG_THREADS), shmem, st, a);            \
+  }
   if (ncit_h <= 1) {
     switch (NTsel) { case 1: PG_WG(1, 1); break; case 2: PG_WG(2, 1); break; case 3: PG_WG(3, 1); break;
                      case 4: PG_WG(4, 1); break; default: PG_WG(9, 1); break; }

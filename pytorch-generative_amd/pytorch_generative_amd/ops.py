@@ -111,6 +111,20 @@ def _pack_frag(lib, weight, spec, transpose):
     return wfrag
 
 
+def _pack_frag_both(lib, weight, spec):
+    """Forward and data-gradient fragments in one launch."""
+    cout, cin, kh, kw = weight.shape
+    t = len(spec.fwd_taps)
+    wf = torch.empty(lib.pg_conv_frag_floats(cin, cout, t), device=weight.device, dtype=torch.float32)
+    wt = torch.empty(lib.pg_conv_frag_floats(cout, cin, t), device=weight.device, dtype=torch.float32)
+    _lib.check(
+        lib.pg_pack_conv_weight_frag2(weight.data_ptr(), wf.data_ptr(), wt.data_ptr(), cout, cin, kh,
+                                      kw, t, spec.f_u, spec.f_v, _stream()),
+        "pg_pack_conv_weight_frag2",
+    )
+    return wf, wt
+
+
 def _pack(lib, weight, spec, transpose):
     cout, cin, kh, kw = weight.shape
     a, b = (cout, cin) if transpose else (cin, cout)
@@ -150,8 +164,12 @@ class _ConvTaps(torch.autograd.Function):
         if (out_act != ACT_NONE or in_post != ACT_NONE) and not mfma:
             raise ValueError("conv2d: fused output activations need the matrix-core path "
                              "(check ops.conv_mfma_ok first)")
+        ctx.wfrag_t = None
         if mfma:
-            wfrag = _pack_frag(lib, weight, spec, transpose=False)
+            if ctx.needs_input_grad[0] and _use_mfma(lib, cout, cin, spec, (ih, iw), ow):
+                wfrag, ctx.wfrag_t = _pack_frag_both(lib, weight, spec)  # backward's fragments too
+            else:
+                wfrag = _pack_frag(lib, weight, spec, transpose=False)
             _lib.check(
                 lib.pg_conv2d_mfma(
                     x.data_ptr(), wfrag.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih,
@@ -207,7 +225,9 @@ class _ConvTaps(torch.autograd.Function):
         if need_dx and _use_mfma(lib, cout, cin, spec, (ih, iw), ow):
             # matrix-core data gradient; act'(x) of a fused input activation in its epilogue (one
             # exp / erf per output element is noise next to the MFMA work of the tile)
-            wfrag_t = _pack_frag(lib, weight, spec, transpose=True)
+            wfrag_t = getattr(ctx, "wfrag_t", None)
+            if wfrag_t is None:
+                wfrag_t = _pack_frag(lib, weight, spec, transpose=True)
             dx = torch.empty_like(x)
             dact = ctx.in_act if ctx.in_act != ACT_NONE else (ACT_ELU_OUT if in_post == ACT_ELU else ACT_NONE)
             fuse = dact != ACT_NONE
