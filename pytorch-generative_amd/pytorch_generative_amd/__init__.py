@@ -1,7 +1,8 @@
 """pytorch_generative_amd — MI355X-native drop-in for pytorch_generative's masked-convolution +
-causal-attention training path (nn.* operators, models.* constructors, Trainer)."""
+causal-attention training path: the nn.* operators, the models.* constructors (with each module's
+reproduce() recipe) and the Trainer, on hand-written gfx950 kernels behind a C-ABI."""
 
-from pytorch_generative_amd import _lib, models, nn, ops  # noqa: F401
+from pytorch_generative_amd import _lib, datasets, models, nn, ops, trainer  # noqa: F401
 
-__all__ = ["models", "nn", "ops"]
-__version__ = "0.1.0"
+__all__ = ["datasets", "models", "nn", "ops", "trainer"]
+__version__ = "0.2.0"

@@ -16,20 +16,34 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, loss_fn, example_x, reducer=None, warmup_iters=2):
+    def __init__(self, model, optimizer, loss_fn, example_x, reducer=None, warmup_iters=2,
+                 example_y=None, forward_fn=None, preserve_state=False):
         """Args:
             model: a pytorch_generative_amd model on the GPU, in train mode.
             optimizer: optim.FlatAdam over model.parameters().
-            loss_fn: fn(x, preds) -> scalar loss tensor (HIP op, e.g. ops.bce_with_logits_sum_mean).
-            example_x: a batch with the static shape to capture.
+            loss_fn: fn(x, preds) -> scalar loss tensor (HIP op, e.g. ops.bce_with_logits_sum_mean);
+                ignored when `forward_fn` is given.
+            example_x / example_y: a batch with the static shapes to capture (y may be None).
             reducer: parallel.FlatGradAllReduce or None (single GPU).
-        NOTE: warm-up iterations run real optimisation steps on `example_x`.
+            forward_fn: fn(x, y) -> loss tensor or {"loss": ..., other metrics}: the forward + loss
+                part of the step (the Trainer passes its overridable train_one_batch hook).
+            preserve_state: the warm-up iterations (needed before capture: allocator warm-up, lazy
+                module state) are real steps on the example batch; True rolls parameters, Adam
+                moments and the step / lr counters back afterwards so the first replay is step 1.
         """
-        self.model, self.opt, self.loss_fn, self.reducer = model, optimizer, loss_fn, reducer
+        self.model, self.opt, self.reducer = model, optimizer, reducer
+        if forward_fn is None:
+            forward_fn = lambda x, y: loss_fn(x, model(x))  # noqa: E731
+        self.forward_fn = forward_fn
         self.split = reducer is not None and reducer.world > 1
         self.static_x = example_x.clone()
-        self.static_loss = None
+        self.static_y = None if example_y is None else example_y.clone()
+        self.static_out = None
 
+        saved = None
+        if preserve_state:
+            saved = [t.clone() for t in (optimizer.flat_param, optimizer.exp_avg, optimizer.exp_avg_sq,
+                                         optimizer.state_block)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -40,12 +54,16 @@ class GraphedTrainStep:
                 self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if saved is not None:
+            for dst, src in zip((optimizer.flat_param, optimizer.exp_avg, optimizer.exp_avg_sq,
+                                 optimizer.state_block), saved):
+                dst.copy_(src)
 
         # thread_local: RCCL's watchdog thread may touch the HIP runtime while we capture
         mode = dict(capture_error_mode="thread_local")
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a, **mode):
-            self.static_loss = self._fwd_bwd()
+            self.static_out = self._fwd_bwd()
             if not self.split:
                 self.opt.step()
         self.graph_b = None
@@ -56,16 +74,22 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
-        loss = self.loss_fn(self.static_x, self.model(self.static_x))
+        out = self.forward_fn(self.static_x, self.static_y)
+        loss = out["loss"] if isinstance(out, dict) else out
         loss.backward()
+        if isinstance(out, dict):
+            return {k: v.detach() for k, v in out.items()}
         return loss.detach()
 
-    def __call__(self, x=None):
-        """Runs one step on batch `x` (None: reuse the resident batch). Returns the device loss."""
+    def __call__(self, x=None, y=None):
+        """Runs one step on batch `x` (None: reuse the resident batch). Returns the device loss
+        (or the metrics dict of `forward_fn`) — static tensors, overwritten by the next call."""
         if x is not None:
             self.static_x.copy_(x, non_blocking=True)
+        if y is not None and self.static_y is not None:
+            self.static_y.copy_(y, non_blocking=True)
         self.graph_a.replay()
         if self.split:
             self.reducer.all_reduce()
             self.graph_b.replay()
-        return self.static_loss
+        return self.static_out

@@ -1,0 +1,8 @@
+"""Autoregressive image models of the hot path (layout of pytorch_generative.models.autoregressive)."""
+
+from pytorch_generative_amd.models.autoregressive import (  # noqa: F401
+    gated_pixel_cnn,
+    image_gpt,
+    pixel_cnn,
+    pixel_snail,
+)

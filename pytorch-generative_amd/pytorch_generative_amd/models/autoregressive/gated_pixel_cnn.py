@@ -107,3 +107,17 @@ class GatedPixelCNN(base.AutoregressiveModel):
             vstack, hstack, skip = gated_layer(vstack, hstack)
             skip_connections = ops.add(skip_connections, skip)
         return self._head[3](self._head[1](skip_connections, in_act="relu"), in_act="relu")
+
+
+def reproduce(n_epochs=457, batch_size=128, log_dir="/tmp/run", n_gpus=1, device_id=0,
+              debug_loader=None):
+    """The reference's training recipe for this model (gated_pixel_cnn.py:193-250: same model
+    hyper-parameters, Adam lr 1e-3, per-batch lr decay 0.9999) on the MI355X path. Arguments as the reference;
+    `debug_loader` replaces both loaders (any iterable of (x, y) batches). Returns the Trainer."""
+    from pytorch_generative_amd import recipes
+
+    return recipes.run(
+        lambda: GatedPixelCNN(in_channels=1, out_channels=1, n_gated=10, gated_channels=128, head_channels=32),
+        loaders=recipes.binarized_mnist, loss_fn=recipes.bce_loss, lr=1e-3, lr_decay=0.9999,
+        n_epochs=n_epochs, batch_size=batch_size, log_dir=log_dir, n_gpus=n_gpus,
+        device_id=device_id, debug_loader=debug_loader)

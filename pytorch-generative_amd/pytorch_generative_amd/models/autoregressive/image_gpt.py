@@ -192,3 +192,18 @@ class ImageGPT(base.AutoregressiveModel):
         for block in self._transformer:
             x = block.forward_plus_input(x)
         return self._out(self._ln(x))
+
+
+def reproduce(n_epochs=457, batch_size=64, log_dir="/tmp/run", n_gpus=1, device_id=0,
+              debug_loader=None):
+    """The reference's training recipe for this model (image_gpt.py:112-175: same model
+    hyper-parameters, Adam lr 5e-3, per-batch lr decay 0.999977) on the MI355X path. Arguments as the reference;
+    `debug_loader` replaces both loaders (any iterable of (x, y) batches). Returns the Trainer."""
+    from pytorch_generative_amd import recipes
+
+    return recipes.run(
+        lambda: ImageGPT(in_channels=1, out_channels=1, in_size=28, n_transformer_blocks=8,
+                         n_attention_heads=2, n_embedding_channels=64),
+        loaders=recipes.binarized_mnist, loss_fn=recipes.bce_loss, lr=5e-3, lr_decay=0.999977,
+        n_epochs=n_epochs, batch_size=batch_size, log_dir=log_dir, n_gpus=n_gpus,
+        device_id=device_id, debug_loader=debug_loader)

@@ -71,3 +71,17 @@ class PixelCNN(base.AutoregressiveModel):
         for layer in self._causal_layers:
             x = ops.add(x, layer(x))
         return self._head[3](self._head[1](x, in_act="relu"), in_act="relu")
+
+
+def reproduce(n_epochs=457, batch_size=256, log_dir="/tmp/run", n_gpus=1, device_id=0,
+              debug_loader=None):
+    """The reference's training recipe for this model (pixel_cnn.py:113-174: same model
+    hyper-parameters, Adam lr 1e-3, per-batch lr decay 0.999977) on the MI355X path. Arguments as the reference;
+    `debug_loader` replaces both loaders (any iterable of (x, y) batches). Returns the Trainer."""
+    from pytorch_generative_amd import recipes
+
+    return recipes.run(
+        lambda: PixelCNN(in_channels=1, out_channels=1, n_residual=15, residual_channels=16, head_channels=32),
+        loaders=recipes.binarized_mnist, loss_fn=recipes.bce_loss, lr=1e-3, lr_decay=0.999977,
+        n_epochs=n_epochs, batch_size=batch_size, log_dir=log_dir, n_gpus=n_gpus,
+        device_id=device_id, debug_loader=debug_loader)

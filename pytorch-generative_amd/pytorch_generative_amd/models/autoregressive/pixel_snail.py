@@ -128,3 +128,18 @@ class PixelSNAIL(base.AutoregressiveModel):
         for block in self._pixel_snail_blocks:
             x = block(x, input_img, add_input=True)
         return self._output[1](self._output[0](x))
+
+
+def reproduce(n_epochs=457, batch_size=128, log_dir="/tmp/run", n_gpus=1, device_id=0,
+              debug_loader=None):
+    """The reference's training recipe for this model (pixel_snail.py:190-254: same model
+    hyper-parameters, Adam lr 1e-3, per-batch lr decay 0.999977) on the MI355X path. Arguments as the reference;
+    `debug_loader` replaces both loaders (any iterable of (x, y) batches). Returns the Trainer."""
+    from pytorch_generative_amd import recipes
+
+    return recipes.run(
+        lambda: PixelSNAIL(in_channels=1, out_channels=1, n_channels=64, n_pixel_snail_blocks=8, n_residual_blocks=2,
+                           attention_value_channels=32, attention_key_channels=4),
+        loaders=recipes.binarized_mnist, loss_fn=recipes.bce_loss, lr=1e-3, lr_decay=0.999977,
+        n_epochs=n_epochs, batch_size=batch_size, log_dir=log_dir, n_gpus=n_gpus,
+        device_id=device_id, debug_loader=debug_loader)

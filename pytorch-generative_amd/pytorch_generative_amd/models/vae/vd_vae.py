@@ -17,7 +17,7 @@ from torch import nn
 
 from pytorch_generative_amd import nn as pg_nn
 from pytorch_generative_amd import ops
-from pytorch_generative_amd.models import vaes
+from pytorch_generative_amd.models.vae import vaes
 
 
 @dataclass
@@ -190,3 +190,20 @@ class VeryDeepVAE(vaes.VariationalAutoEncoder):
             x = ops.add_broadcast_batch(x, bias)
             x, _ = stack(x)
         return self._output(x)
+
+
+def reproduce(n_epochs=500, batch_size=128, log_dir="/tmp/run", n_gpus=1, device_id=0,
+              debug_loader=None):
+    """The reference's training recipe for this model (vd_vae.py:415-494: six stacks
+    (3,5)(3,5)(2,4)(2,3)(2,2)(1,1) on 32x32, Adam lr 5e-4) on the MI355X path. Arguments as the
+    reference; `debug_loader` replaces both loaders. Returns the Trainer."""
+    from pytorch_generative_amd import recipes
+
+    stacks = [StackConfig(3, 5), StackConfig(3, 5), StackConfig(2, 4), StackConfig(2, 3),
+              StackConfig(2, 2), StackConfig(1, 1)]
+    return recipes.run(
+        lambda: VeryDeepVAE(in_channels=1, out_channels=1, input_resolution=32, stack_configs=stacks,
+                            latent_channels=16, hidden_channels=64, bottleneck_channels=32),
+        loaders=recipes.binarized_mnist_32, loss_fn=recipes.elbo_loss, lr=5e-4,
+        n_epochs=n_epochs, batch_size=batch_size, log_dir=log_dir, n_gpus=n_gpus,
+        device_id=device_id, debug_loader=debug_loader)

@@ -37,6 +37,11 @@ def _chk(t, name):
         )
     if t.dtype != torch.float32:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        # kernels are enqueued on the CURRENT device's stream with raw pointers: a tensor of another
+        # GPU would be dereferenced from the wrong device (Trainer / recipes call set_device)
+        raise RuntimeError(f"{name}: tensor lives on {t.device} but the current device is "
+                           f"cuda:{torch.cuda.current_device()}; call torch.cuda.set_device first")
     return t if t.is_contiguous() else t.contiguous()
 
 

@@ -16,6 +16,12 @@ from pytorch_generative_amd import _lib
 _STEP, _LR, _SUMSQ, _NORM, _COEF, _LRMUL, _MAXNORM, _PRESCALE = range(8)
 
 
+# the keys torch.optim.Adam expects in a param_group besides lr / betas / eps (none is implemented
+# here beyond its default: load_state_dict rejects anything else)
+_ADAM_GROUP_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                            differentiable=False, fused=None, decoupled_weight_decay=False)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -99,18 +105,38 @@ class FlatAdam(torch.optim.Optimizer):
         st[_PRESCALE] = 1.0
         self.state_block = st.to(dev)
         self._host_lr = lr
+        self._lr_decay = float(lr_decay)
 
     # ---- helpers -------------------------------------------------------------------------
     def set_grad_prescale(self, s):
         """Gradients are multiplied by `s` before the norm/update (1/world after an all-reduce sum)."""
         self.state_block[_PRESCALE] = float(s)
 
+    def set_max_norm(self, max_norm):
+        """Clip threshold of the fused global grad-norm (None: compute the norm, never scale)."""
+        self.state_block[_MAXNORM] = float("inf") if max_norm is None else float(max_norm)
+
     def sync_lr_from_groups(self):
-        """Eager-mode hook: push param_groups[0]['lr'] (as set by an lr_scheduler) to the device."""
+        """Pushes param_groups[0]['lr'] (as set by a torch lr_scheduler or by hand) to the device
+        state block when it changed. Host-side compare; called by step() in eager mode and by the
+        Trainer after lr_scheduler.step() (a hipGraph replay does not run Python)."""
         lr = float(self.param_groups[0]["lr"])
         if lr != self._host_lr:
+            if self._lr_decay != 1.0:
+                raise ValueError("FlatAdam: lr_decay (device-side MultiplicativeLR) cannot be combined "
+                                 "with a host lr_scheduler that also changes param_groups['lr']")
             self.state_block[_LR] = lr
             self._host_lr = lr
+
+    def current_lr(self):
+        """The learning rate the next step will use (read back from the device: with lr_decay the
+        host-side param_groups value is only the initial one)."""
+        return float(self.state_block[_LR].item())
+
+    def measure_grad_norm(self):
+        """Global L2 norm of the (pre-scaled) flat gradient as a device scalar, without stepping."""
+        scale = self.state_block[_PRESCALE]
+        return self.flat_grad.norm() * scale
 
     def grad_norm(self):
         """Device scalar: the global L2 norm computed by the last step()."""
@@ -126,6 +152,10 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise ValueError("FlatAdam does not support closures")
+        if not all(p.requires_grad for p in self._params):
+            raise RuntimeError("FlatAdam: a parameter was frozen after the optimizer was built; the flat "
+                               "update covers every slice — rebuild FlatAdam over the trainable set")
+        self.sync_lr_from_groups()
         lib, s = self._lib, _stream()
         b1, b2 = self.param_groups[0]["betas"]
         eps = self.param_groups[0]["eps"]
@@ -141,34 +171,45 @@ class FlatAdam(torch.optim.Optimizer):
 
     # ---- checkpoint compatibility with torch.optim.Adam's state_dict layout ---------------
     def state_dict(self):
+        """torch.optim.Adam's layout (state keyed by the parameter's index in the group, full
+        param_group keys) so that the dict loads into torch.optim.Adam and back."""
         step = float(self.state_block[_STEP].item())
+        slot = {id(p): (o, p) for p, o in zip(self._params, self._offsets)}
         state = {}
-        for i, (p, o) in enumerate(zip(self._params, self._offsets)):
-            n = p.numel()
+        all_params = self.param_groups[0]["params"]
+        for i, p in enumerate(all_params):
+            if id(p) not in slot:
+                continue
+            o, n = slot[id(p)][0], p.numel()
             state[i] = {
                 "step": torch.tensor(step),
                 "exp_avg": self.exp_avg[o : o + n].view(p.shape).clone(),
                 "exp_avg_sq": self.exp_avg_sq[o : o + n].view(p.shape).clone(),
             }
         group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
-        group["lr"] = float(self.state_block[_LR].item())
-        group["params"] = list(range(len(self._params)))
+        group.update(_ADAM_GROUP_DEFAULTS)
+        group["lr"] = self.current_lr()
+        group["params"] = list(range(len(all_params)))
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         group = sd["param_groups"][0]
+        if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
+            raise ValueError("FlatAdam implements plain Adam: weight_decay / amsgrad / maximize in the "
+                             "checkpoint are not supported")
         for k, v in group.items():
             if k != "params":
                 self.param_groups[0][k] = v
         self.state_block[_LR] = float(group["lr"])
         self._host_lr = float(group["lr"])
+        slot = {id(p): o for p, o in zip(self._params, self._offsets)}
         step = 0.0
         with torch.no_grad():
-            for i, (p, o) in enumerate(zip(self._params, self._offsets)):
+            for i, p in enumerate(self.param_groups[0]["params"]):
                 st = sd["state"].get(i)
-                if st is None:
+                if st is None or id(p) not in slot:
                     continue
-                n = p.numel()
+                o, n = slot[id(p)], p.numel()
                 self.exp_avg[o : o + n].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[o : o + n].copy_(st["exp_avg_sq"].reshape(-1))
                 step = max(step, float(st["step"]))

@@ -1,52 +1,89 @@
-"""Training loop for the MI355X operator path.
+"""Trainer for the MI355X operator path.
 
-Keeps the reference Trainer's constructor, step semantics and checkpoint layout
-(pytorch_generative/trainer.py:15-287): per batch `zero_grad -> model(x) -> loss_fn(x, y, preds)
--> backward -> global grad-norm (clip / skip) -> optimizer.step -> lr_scheduler.step`, metrics
-returned as Python floats, `trainer_state_{epoch}.ckpt` holding model / optimizer / step / epoch /
-examples_processed / time_taken (/ lr_scheduler), written by device 0 only.
+Contract kept from the reference (pytorch_generative/trainer.py): the constructor signature
+(:23-38), what one training step means (:173-193 — zero_grad, model(x), loss_fn(x, y, preds),
+backward, global grad norm with optional clip / skip, optimizer.step, lr_scheduler.step), the
+overridable `train_one_batch` / `eval_one_batch` hooks, example-weighted evaluation averages, and
+the on-disk checkpoint `trainer_state_{epoch}.ckpt` with keys model / optimizer / step / epoch /
+examples_processed / time_taken (/ lr_scheduler), written by rank 0 only (:98-148) — reference
+checkpoints restore here and vice versa.
 
-Differences that make it MI355X-native:
-  * `optimizer` may be a `pytorch_generative_amd.optim.FlatAdam`; the grad norm, clipping and the
-    Adam update then run as one fused device-side chain (no per-tensor kernels, no host sync
-    besides the final metric read), and gradients are accumulated by the backward kernels
-    directly into its flat buffer.
-  * data parallelism is one process per GPU with ONE flat RCCL all-reduce per step
-    (parallel.FlatGradAllReduce) instead of DistributedDataParallel's bucket hooks.
-A stock torch optimizer still works (then `torch.nn.utils.clip_grad_norm_` is used).
+How a step runs here:
+  * with `optim.FlatAdam` the whole step (zero_grad .. Adam, incl. the clip) is captured into a
+    hipGraph per input shape (graph.GraphedTrainStep) and replayed: one launch instead of
+    hundreds; only the final metric read-back touches the host (every `metrics_every` steps);
+  * `skip_grad_norm` needs the norm on the host before the update, and stock torch optimizers have
+    no flat buffer: both run as eager kernel launches;
+  * `n_gpus > 1`: one process per GPU (launched by train.py / torchrun), this process pinned to
+    `device_id`, ONE flat RCCL all-reduce per step between the two halves of the graph.
+TensorBoard is used when it is importable; otherwise metrics are only returned to the caller.
 """
 
-import collections
 import glob
 import os
 import re
 import tempfile
 import time
+import warnings
 
 import torch
 import torch.distributed as dist
 
+from pytorch_generative_amd import graph as pg_graph
 from pytorch_generative_amd import optim as pg_optim
 from pytorch_generative_amd import parallel
 
+_CKPT_RE = re.compile(r"trainer_state_(\d+)\.ckpt$")
 
-class _NullWriter:
-    def add_scalar(self, *a, **k):
-        pass
 
-    add_scalars = add_images = add_scalar
+def _ckpt_name(epoch):
+    return f"trainer_state_{epoch}.ckpt"
+
+
+class _Scalars:
+    """TensorBoard sink if the package is installed, else a no-op with the same three calls."""
+
+    def __init__(self, log_dir, purge_step=None):
+        self._w = None
+        try:
+            from torch.utils import tensorboard
+
+            kw = {} if purge_step is None else {"purge_step": purge_step}
+            self._w = tensorboard.SummaryWriter(log_dir, max_queue=100, **kw)
+        except Exception:  # not installed in this image
+            pass
+
+    @property
+    def active(self):
+        return self._w is not None
+
+    def group(self, tag, values, step):
+        if self._w is not None:
+            self._w.add_scalars(tag, values, step)
+
+    def scalar(self, tag, value, step):
+        if self._w is not None:
+            self._w.add_scalar(tag, value, step)
+
+    def images(self, tag, tensor, step):
+        if self._w is not None:
+            self._w.add_images(tag, tensor, step)
 
     def close(self):
-        pass
+        if self._w is not None:
+            self._w.close()
 
 
-def _make_writer(log_dir, **kwargs):
-    try:
-        from torch.utils import tensorboard
+def _split_batch(batch):
+    if isinstance(batch, (tuple, list)):
+        return (batch[0], batch[1]) if len(batch) > 1 else (batch[0], None)
+    return batch, None
 
-        return tensorboard.SummaryWriter(log_dir, max_queue=100, **kwargs)
-    except Exception:  # tensorboard not installed: metrics are still returned to the caller
-        return _NullWriter()
+
+def _as_metrics(out):
+    metrics = out if isinstance(out, dict) else {"loss": out}
+    assert "loss" in metrics, 'Metrics dictionary does not contain "loss" key.'
+    return metrics
 
 
 class Trainer:
@@ -65,34 +102,30 @@ class Trainer:
         save_checkpoint_epochs=1,
         n_gpus=0,
         device_id=None,
+        *,
+        graph=True,
+        metrics_every=1,
     ):
+        """Arguments as the reference Trainer (trainer.py:40-76). Extensions (keyword only):
+        graph: capture FlatAdam steps into hipGraphs (default); metrics_every: read the step
+        metrics back to the host every N steps (1 = the reference's per-step logging)."""
         self.loss_fn = loss_fn
-        self.train_loader = train_loader
-        self.eval_loader = eval_loader
-        self.clip_grad_norm = clip_grad_norm
-        self.skip_grad_norm = skip_grad_norm
+        self.train_loader, self.eval_loader = train_loader, eval_loader
+        self.clip_grad_norm, self.skip_grad_norm = clip_grad_norm, skip_grad_norm
         self.log_dir = log_dir or tempfile.mkdtemp()
-        self.save_checkpoint_epochs = save_checkpoint_epochs
-        self.sample_epochs = sample_epochs
+        self.sample_epochs, self.save_checkpoint_epochs = sample_epochs, save_checkpoint_epochs
 
-        if n_gpus < 1:
-            raise RuntimeError(
-                "pytorch_generative_amd.Trainer runs on MI355X GPUs only (n_gpus >= 1); the HIP "
-                "operator path has no CPU fallback"
-            )
-        self.device_id = 0 if device_id is None and n_gpus == 1 else device_id
-        if n_gpus > 1:
-            assert device_id is not None, "'device_id' must be provided if n_gpus > 1."
-        self.device = torch.device("cuda", self.device_id if n_gpus > 1 else torch.cuda.current_device())
-        if next(model.parameters()).device != self.device:
-            if isinstance(optimizer, pg_optim.FlatAdam):
-                raise RuntimeError("move the model to the GPU before building FlatAdam")
-            model = model.to(self.device)
-
-        self.model = model
-        self.optimizer = optimizer
-        self.lr_scheduler = lr_scheduler
+        self.device = self._resolve_device(model, n_gpus, device_id)
+        self.device_id = self.device.index if n_gpus > 1 else 0
+        # every raw kernel launch of this process goes to the CURRENT device's streams: pin it
+        torch.cuda.set_device(self.device)
         self._flat = isinstance(optimizer, pg_optim.FlatAdam)
+        if next(model.parameters()).device != self.device:
+            if self._flat:
+                raise RuntimeError("move the model to its GPU before building FlatAdam")
+            model = model.to(self.device)
+        self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
+
         self._reducer = None
         if n_gpus > 1:
             if not self._flat:
@@ -102,182 +135,214 @@ class Trainer:
             self._reducer = parallel.FlatGradAllReduce(optimizer)
             self._reducer.broadcast_parameters(src=0)
         if self._flat:
-            max_norm = clip_grad_norm or skip_grad_norm
-            optimizer.state_block[pg_optim._MAXNORM] = float("inf") if max_norm is None else float(max_norm)
+            optimizer.set_max_norm(clip_grad_norm or skip_grad_norm)
+        self._use_graph = bool(graph) and self._flat and not skip_grad_norm
+        self._graphs = {}
+        self._metrics_every = max(1, int(metrics_every))
 
-        self._step = 0
-        self._epoch = 0
-        self._examples_processed = 0
-        self._time_taken = 0
-        self._summary_writer = _make_writer(self.log_dir)
+        self._step = self._epoch = self._examples_processed = 0
+        self._time_taken = 0.0
+        self._log = _Scalars(self.log_dir)
+
+    @staticmethod
+    def _resolve_device(model, n_gpus, device_id):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pytorch_generative_amd.Trainer needs an MI355X: the HIP operator "
+                               "path has no CPU fallback")
+        if n_gpus > 1:
+            assert device_id is not None, "'device_id' must be provided if n_gpus > 1."
+            return torch.device("cuda", device_id)
+        where = next(model.parameters()).device
+        if n_gpus == 0:
+            # the reference trains on the CPU here (trainer.py:77); this path has no CPU arithmetic
+            warnings.warn("n_gpus=0 requested, but the HIP operator path only runs on the GPU: "
+                          "training on " + (str(where) if where.type == "cuda" else "cuda:0"))
+        if where.type == "cuda":
+            return where
+        return torch.device("cuda", device_id if device_id is not None else torch.cuda.current_device())
 
     # ------------------------------------------------------------------ checkpoints
-    def _path(self, file_name):
-        return os.path.join(self.log_dir, file_name)
+    def _path(self, name):
+        return os.path.join(self.log_dir, name)
 
     def _save_checkpoint(self):
-        if self.device_id != 0 or self._epoch % self.save_checkpoint_epochs != 0:
+        if self.device_id != 0 or self._epoch % self.save_checkpoint_epochs:
             return
-        checkpoint = {
-            "model": self.model.state_dict(),
-            "optimizer": self.optimizer.state_dict(),
-            "step": self._step,
-            "epoch": self._epoch,
-            "examples_processed": self._examples_processed,
-            "time_taken": self._time_taken,
-        }
+        payload = dict(
+            model=self.model.state_dict(),
+            optimizer=self.optimizer.state_dict(),
+            step=self._step,
+            epoch=self._epoch,
+            examples_processed=self._examples_processed,
+            time_taken=self._time_taken,
+        )
         if self.lr_scheduler is not None:
-            checkpoint["lr_scheduler"] = self.lr_scheduler.state_dict()
-        torch.save(checkpoint, self._path(f"trainer_state_{self._epoch}.ckpt"))
+            payload["lr_scheduler"] = self.lr_scheduler.state_dict()
+        torch.save(payload, self._path(_ckpt_name(self._epoch)))
 
-    def _find_latest_epoch(self):
-        files = glob.glob(self._path("trainer_state_[0-9]*.ckpt"))
-        epochs = sorted(int(re.findall(r"trainer_state_(\d+)\.ckpt", f)[0]) for f in files)
-        if not epochs:
+    def _latest_epoch(self):
+        found = [int(m.group(1)) for m in map(_CKPT_RE.search, glob.glob(self._path("trainer_state_*.ckpt"))) if m]
+        if not found:
             raise FileNotFoundError(f"No checkpoints found in {self.log_dir}.")
-        print(f"Found {len(epochs)} saved checkpoints.")
-        return epochs[-1]
+        print(f"Found {len(found)} saved checkpoints.")
+        return max(found)
 
     def restore_checkpoint(self, epoch=None):
-        epoch = epoch or self._find_latest_epoch()
-        name = f"trainer_state_{epoch}.ckpt"
-        print(f"Restoring trainer state from checkpoint {name}.")
-        checkpoint = torch.load(self._path(name), map_location=self.device, weights_only=False)
-        self.model.load_state_dict(checkpoint["model"])
-        self.optimizer.load_state_dict(checkpoint["optimizer"])
-        self._step = checkpoint["step"]
-        self._epoch = checkpoint["epoch"]
-        self._examples_processed = checkpoint["examples_processed"]
-        self._time_taken = checkpoint["time_taken"]
+        """Restores model / optimizer / counters from `epoch` (default: the newest checkpoint)."""
+        epoch = epoch or self._latest_epoch()
+        print(f"Restoring trainer state from checkpoint {_ckpt_name(epoch)}.")
+        state = torch.load(self._path(_ckpt_name(epoch)), map_location=self.device, weights_only=False)
+        self.model.load_state_dict(state["model"])
+        self.optimizer.load_state_dict(state["optimizer"])
         if self.lr_scheduler is not None:
-            self.lr_scheduler.load_state_dict(checkpoint["lr_scheduler"])
-        self._summary_writer.close()
-        self._summary_writer = _make_writer(self.log_dir, purge_step=self._step)
+            self.lr_scheduler.load_state_dict(state["lr_scheduler"])
+        self._step, self._epoch = state["step"], state["epoch"]
+        self._examples_processed, self._time_taken = state["examples_processed"], state["time_taken"]
+        self._log.close()
+        self._log = _Scalars(self.log_dir, purge_step=self._step)
 
-    # ------------------------------------------------------------------ one batch
-    def _get_metrics_dict(self, loss_or_metrics):
-        metrics = loss_or_metrics
-        if not isinstance(metrics, dict):
-            metrics = {"loss": metrics}
-        assert "loss" in metrics, 'Metrics dictionary does not contain "loss" key.'
-        return metrics
-
-    def _log_metrics(self, metrics, training):
-        for key, metric in metrics.items():
-            self._summary_writer.add_scalars(
-                f"metrics/{key}", {"train" if training else "eval": metric}, self._step
-            )
-
+    # ------------------------------------------------------------------ hooks (overridable)
     def train_one_batch(self, x, y):
-        """Override for custom training steps."""
-        preds = self.model(x)
-        return self.loss_fn(x, y, preds)
+        """Forward + loss for one training batch; override for custom steps."""
+        return self.loss_fn(x, y, self.model(x))
 
-    def _train_one_batch(self, x, y):
-        self.model.train()
+    def eval_one_batch(self, x, y):
+        return self.loss_fn(x, y, self.model(x))
+
+    # ------------------------------------------------------------------ one step
+    def _to_device(self, x, y):
         x = x.to(self.device, non_blocking=True)
         if y is not None:
             y = y.to(self.device, non_blocking=True)
-        self.optimizer.zero_grad()
-        metrics = self._get_metrics_dict(self.train_one_batch(x, y))
-        metrics["loss"].backward()
+        return x, y
 
-        if self._flat:
-            if self._reducer is not None:
-                self._reducer.all_reduce()
-            if self.skip_grad_norm:
-                # the decision needs the norm on the host, as in the reference (trainer.py:188)
-                norm = self._flat_grad_norm()
-                metrics["grad_norm"] = norm
-                if norm.item() <= self.skip_grad_norm:
-                    self._optimizer_step()
-            else:
-                self._optimizer_step()
-                metrics["grad_norm"] = self.optimizer.grad_norm().clone()
+    def _graphed(self, x, y):
+        key = (tuple(x.shape), None if y is None else (tuple(y.shape), y.dtype))
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 4:  # e.g. ragged batch sizes: do not hoard graphs
+                return None
+            g = pg_graph.GraphedTrainStep(
+                self.model, self.optimizer, None, x, reducer=self._reducer, example_y=y,
+                forward_fn=lambda xx, yy: _as_metrics(self.train_one_batch(xx, yy)),
+                preserve_state=True,
+            )
+            self._graphs[key] = g
+        return g
+
+    def _train_one_batch(self, x, y, want_metrics=True):
+        """One optimisation step; returns the step's metrics as Python floats (or None when
+        `want_metrics` is False: nothing is read back, the host does not wait for the GPU)."""
+        self.model.train()
+        x, y = self._to_device(x, y)
+        g = self._graphed(x, y) if self._use_graph else None
+        if g is not None:
+            metrics = dict(g(x, y))
+            metrics["grad_norm"] = self.optimizer.grad_norm()
+            stepped = True
         else:
-            max_norm = self.clip_grad_norm or self.skip_grad_norm or 1e50
-            norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm)
-            metrics["grad_norm"] = norm
-            if not self.skip_grad_norm or norm.item() <= self.skip_grad_norm:
-                self._optimizer_step()
-        return {k: v.item() for k, v in metrics.items()}
-
-    def _flat_grad_norm(self):
-        scale = float(self.optimizer.state_block[pg_optim._PRESCALE].item())
-        return self.optimizer.flat_grad.norm() * scale
-
-    def _optimizer_step(self):
-        self.optimizer.step()
-        if self.lr_scheduler is not None:
+            metrics, stepped = self._eager_step(x, y)
+        if stepped and self.lr_scheduler is not None:
             self.lr_scheduler.step()
             if self._flat:
                 self.optimizer.sync_lr_from_groups()
+        if not want_metrics:
+            return None
+        return {k: float(v) for k, v in metrics.items()}
 
-    def eval_one_batch(self, x, y):
-        preds = self.model(x)
-        return self.loss_fn(x, y, preds)
+    def _eager_step(self, x, y):
+        opt = self.optimizer
+        opt.zero_grad()
+        metrics = dict(_as_metrics(self.train_one_batch(x, y)))
+        metrics["loss"].backward()
+        if self._flat:
+            if self._reducer is not None:
+                self._reducer.all_reduce()
+            if self.skip_grad_norm:  # the decision needs the norm on the host (reference :188)
+                norm = opt.measure_grad_norm()
+                metrics["grad_norm"] = norm
+                if float(norm) > self.skip_grad_norm:
+                    return metrics, False
+            opt.step()
+            metrics.setdefault("grad_norm", opt.grad_norm().clone())
+            return metrics, True
+        limit = self.clip_grad_norm or self.skip_grad_norm or 1e50
+        norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), limit)
+        metrics["grad_norm"] = norm
+        if self.skip_grad_norm and float(norm) > self.skip_grad_norm:
+            return metrics, False
+        opt.step()
+        return metrics, True
 
     @torch.no_grad()
     def _eval_one_batch(self, x, y):
         self.model.eval()
-        x = x.to(self.device)
-        if y is not None:
-            y = y.to(self.device)
-        metrics = self._get_metrics_dict(self.eval_one_batch(x, y))
-        return {k: v.item() for k, v in metrics.items()}
+        x, y = self._to_device(x, y)
+        return {k: float(v) for k, v in _as_metrics(self.eval_one_batch(x, y)).items()}
 
     @torch.no_grad()
     def sample_one_batch(self):
         self.model.eval()
         try:
-            tensor = self.model.sample(n_samples=16)
-            self._summary_writer.add_images("sample", tensor, self._step)
-        except Exception as e:  # same policy as the reference (trainer.py:215-220)
+            self._log.images("sample", self.model.sample(n_samples=16), self._step)
+        except Exception as e:  # sampling is best effort, as in the reference (trainer.py:215-220)
             print(f"Failed to sample from the model: {e}")
 
     # ------------------------------------------------------------------ epochs
+    def _current_lrs(self):
+        if self._flat:
+            return {"group_0": self.optimizer.current_lr()}
+        return {f"group_{i}": g["lr"] for i, g in enumerate(self.optimizer.param_groups)}
+
+    def _train_epoch(self):
+        tick = time.time()
+        for batch in self.train_loader:
+            x, y = _split_batch(batch)
+            self._examples_processed += x.shape[0]
+            report = self._step % self._metrics_every == 0
+            if report and self._log.active:
+                self._log.group("metrics/lr", self._current_lrs(), self._step)
+            metrics = self._train_one_batch(x, y, want_metrics=report)
+            now = time.time()
+            self._time_taken += now - tick
+            tick = now
+            if report:
+                for key, value in metrics.items():
+                    self._log.group(f"metrics/{key}", {"train": value}, self._step)
+                rate = self._examples_processed / max(self._time_taken, 1e-9)
+                self._log.scalar("speed/examples_per_sec", rate, self._step)
+                self._log.scalar("speed/millis_per_example", 1000.0 / rate, self._step)
+                self._log.scalar("speed/epoch", self._epoch, self._step)
+                self._log.scalar("speed/step", self._step, self._step)
+            self._step += 1
+
+    def _eval_epoch(self):
+        """Example-weighted means of every metric over the evaluation set."""
+        seen, totals = 0, {}
+        for batch in self.eval_loader:
+            x, y = _split_batch(batch)
+            n = x.shape[0]
+            seen += n
+            for key, value in self._eval_one_batch(x, y).items():
+                totals[key] = totals.get(key, 0.0) + value * n
+        means = {k: v / max(seen, 1) for k, v in totals.items()}
+        for key, value in means.items():
+            self._log.group(f"metrics/{key}", {"eval": value}, self._step)
+        return means
+
     def interleaved_train_and_eval(self, max_epochs, restore=True):
+        """Trains until `max_epochs` epochs are done (counting restored ones), evaluating,
+        checkpointing and sampling after each epoch as configured."""
         if restore:
             try:
                 self.restore_checkpoint()
             except FileNotFoundError:
                 print(f"No checkpoint found in {self.log_dir}. Training from scratch.")
-
-        for _ in range(max_epochs - self._epoch):
-            start_time = time.time()
-            for batch in self.train_loader:
-                x, y = batch if isinstance(batch, (tuple, list)) else (batch, None)
-                self._examples_processed += x.shape[0]
-                lrs = {f"group_{i}": g["lr"] for i, g in enumerate(self.optimizer.param_groups)}
-                self._summary_writer.add_scalars("metrics/lr", lrs, self._step)
-                metrics = self._train_one_batch(x, y)
-                self._log_metrics(metrics, training=True)
-
-                self._time_taken += time.time() - start_time
-                start_time = time.time()
-                self._summary_writer.add_scalar(
-                    "speed/examples_per_sec", self._examples_processed / self._time_taken, self._step
-                )
-                self._summary_writer.add_scalar(
-                    "speed/millis_per_example",
-                    self._time_taken / self._examples_processed * 1000,
-                    self._step,
-                )
-                self._summary_writer.add_scalar("speed/epoch", self._epoch, self._step)
-                self._summary_writer.add_scalar("speed/step", self._step, self._step)
-                self._step += 1
-
-            n_examples, sums = 0, collections.defaultdict(float)
-            for batch in self.eval_loader:
-                x, y = batch if isinstance(batch, (tuple, list)) else (batch, None)
-                n_examples += x.shape[0]
-                for key, metric in self._eval_one_batch(x, y).items():
-                    sums[key] += metric * x.shape[0]
-            self._log_metrics({k: v / n_examples for k, v in sums.items()}, training=False)
-
+        while self._epoch < max_epochs:
+            self._train_epoch()
+            self.last_eval_metrics = self._eval_epoch()
             self._epoch += 1
             self._save_checkpoint()
             if self._epoch % self.sample_epochs == 0:
                 self.sample_one_batch()
-
-        self._summary_writer.close()
+        self._log.close()

@@ -220,7 +220,7 @@ def test_vae_golden_step(dev, name):
     with the reference's noise replayed through the model's noise hook."""
     import pytorch_generative_amd as pg
     from pytorch_generative_amd import ops, optim
-    from pytorch_generative_amd.models import vaes
+    from pytorch_generative_amd.models.vae import vaes
 
     g = _util.load_golden(name)
     model = getattr(pg.models, g["ctor"])(**g["kwargs"])

@@ -369,7 +369,7 @@ def test_fused_gpt_block_matches_operator_composition(dev, n, hw):
     """forward_plus_input (head / attention / tail kernels of gpt_block.hip) against the same block
     evaluated operator by operator: output, input gradient and all 16 parameter gradients."""
     from pytorch_generative_amd import ops
-    from pytorch_generative_amd.models import image_gpt
+    from pytorch_generative_amd.models.autoregressive import image_gpt
 
     torch.manual_seed(0)
     blk = image_gpt.TransformerBlock(16, 4).to(dev)
