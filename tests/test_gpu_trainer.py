@@ -134,3 +134,72 @@ def test_conditional_sampling_keeps_given_pixels(dev, ctor, kw):
     cond[:, :, :2, :] = 0.25
     out = model.sample(conditioned_on=cond)
     assert torch.equal(out[:, :, :2, :], cond[:, :, :2, :]) and bool((out[:, :, 2:, :] >= 0).all())
+
+
+def test_trainer_restores_a_checkpoint_written_by_the_reference_trainer(dev, tmp_path):
+    """tests/golden/ref_trainer/trainer_state_2.ckpt was written by the reference's own Trainer
+    (make_ckpt_golden.py). Restoring it here must reproduce the counters, parameters, Adam moments
+    and the scheduled lr — and the NEXT training batch must give the reference's metrics and
+    parameters (the fixture records what the reference did next)."""
+    import shutil
+
+    import pytorch_generative_amd as pg
+    from pytorch_generative_amd import optim, trainer
+
+    src = os.path.join(_util.GOLDEN_DIR, "ref_trainer")
+    shutil.copy(os.path.join(src, "trainer_state_2.ckpt"), tmp_path)
+    nxt = torch.load(os.path.join(src, "next_step.pt"), map_location="cpu", weights_only=False)
+    ref = torch.load(os.path.join(src, "trainer_state_2.ckpt"), map_location="cpu", weights_only=False)
+
+    model = pg.models.PixelCNN(**nxt["model_kwargs"]).to(dev)
+    opt = optim.FlatAdam(model.parameters(), lr=nxt["lr"])
+    sched = torch.optim.lr_scheduler.MultiplicativeLR(opt, lr_lambda=lambda _: nxt["decay"])
+    loader = [(b, None) for b in nxt["train_batches"]]
+    t = trainer.Trainer(model, _loss_fn, opt, loader, loader, lr_scheduler=sched, log_dir=str(tmp_path),
+                        n_gpus=1)
+    t.restore_checkpoint()
+    assert (t._step, t._epoch, t._examples_processed) == (ref["step"], ref["epoch"], ref["examples_processed"])
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), ref["model"][k]), k
+    assert abs(opt.current_lr() - ref["optimizer"]["param_groups"][0]["lr"]) < 1e-10
+    for i, p in enumerate(model.parameters()):
+        o = opt._offsets[i]
+        assert torch.equal(opt.exp_avg[o:o + p.numel()].view(p.shape).cpu(), ref["optimizer"]["state"][i]["exp_avg"])
+    assert float(opt.state_block[0]) == float(ref["optimizer"]["state"][0]["step"])
+    # ... and it continues exactly like the reference did
+    m = t._train_one_batch(nxt["next_x"], None)
+    assert abs(m["loss"] - nxt["next_metrics"]["loss"]) <= 1e-4 * abs(nxt["next_metrics"]["loss"])
+    assert abs(m["grad_norm"] - nxt["next_metrics"]["grad_norm"]) <= 1e-4 * nxt["next_metrics"]["grad_norm"]
+    for k, v in model.state_dict().items():
+        _util.assert_close(v, nxt["state_after_next"][k], 1e-4, f"{k} after the next step")
+    assert abs(opt.current_lr() - nxt["lr_after_next"]) < 1e-10
+
+
+def test_flat_adam_state_dict_round_trips_through_torch_adam(dev):
+    """FlatAdam.state_dict() is a complete torch.optim.Adam state_dict: it loads into torch's Adam,
+    which can step, and torch's state loads back."""
+    from pytorch_generative_amd import ops
+
+    model, opt = _make(dev)
+    x = _Loader((4, 1, 8, 8)).batches[0].to(dev)
+    for _ in range(2):
+        opt.zero_grad()
+        ops.bce_with_logits_sum_mean(model(x), x).backward()
+        opt.step()
+    sd = opt.state_dict()
+    clones = [p.detach().clone().requires_grad_(True) for p in model.parameters()]
+    adam = torch.optim.Adam(clones, lr=1e-3)
+    adam.load_state_dict(sd)
+    for c, p in zip(clones, model.parameters()):
+        c.grad = p.grad.clone()
+    adam.step()  # raises KeyError if a param_group key is missing
+    opt.step()
+    for c, p in zip(clones, model.parameters()):
+        _util.assert_close(p, c, 1e-5, "FlatAdam vs torch.optim.Adam continuing from the same state")
+    model2, opt2 = _make(dev)
+    opt2.load_state_dict(adam.state_dict())
+    assert float(opt2.state_block[0]) == 3.0
+    bad = adam.state_dict()
+    bad["param_groups"][0]["weight_decay"] = 0.1
+    with pytest.raises(ValueError, match="weight_decay"):
+        opt2.load_state_dict(bad)
