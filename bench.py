@@ -6,10 +6,19 @@
 
 One "step" = the reference's Trainer._train_one_batch (trainer.py:173-193): zero_grad, forward,
 BCE-with-logits loss, backward, global grad norm, Adam, lr decay — on one resident batch of
-synthetic binarised-MNIST-shaped images, replayed from a hipGraph. Workload: BASELINE.json
-configs[1], ImageGPT 8 blocks / 4 heads / 16 embedding channels on 28x28x1 (fp32: the reference
-is fp32 end to end and parity is gated at 1e-4; see DESIGN.md for the bf16 note).
-Rank 0 prints ONE JSON line.
+synthetic images, replayed from a hipGraph (two graphs with one flat RCCL all-reduce between them
+when data parallel). Rank 0 prints ONE JSON line:
+
+  * headline (`value`, `config.workload`): BASELINE.json configs[1], ImageGPT 8 blocks / 4 heads /
+    16 embedding channels on 28x28x1 at the saturating per-GPU batch 1024, fp32 (the reference is
+    fp32 end to end and parity is gated at 1e-4; DESIGN.md has the bf16 note);
+  * `imagegpt_b64`: the same model at the reference's default batch 64 (image_gpt.py:114);
+  * `pixel_snail`: the other half of BASELINE.json's metric — configs[3] PixelSNAIL(3, 3, 64, 8, 2,
+    4, 32) on 32x32x3 — at a saturating batch and at the reference default 128, with its own
+    dominant-kernel roofline;
+  * `roofline`: the headline's dominant kernel timed live with HIP events; `cpu_baseline`: the
+    oracle's restatement of the same step on the host cores.
+`python bench.py --model <name>` benches one workload only (profiling helper; not the driver line).
 """
 
 import argparse
@@ -26,33 +35,60 @@ for _p in (ROOT, os.path.join(ROOT, "pytorch-generative_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-MODEL_KW = dict(in_channels=1, out_channels=1, in_size=28, n_transformer_blocks=8,
-                n_attention_heads=4, n_embedding_channels=16)
-LR, LR_DECAY = 5e-3, 0.999977  # reference reproduce(): image_gpt.py:155-156
-# secondary workloads (same step definition; selected with --model, reported under the same
-# contract but NOT the default bench line): BASELINE.json configs[0], [2], [3]
-OTHER_MODELS = {
-    "pixel_snail": ("PixelSNAIL", dict(in_channels=3, out_channels=3, n_channels=64,
-                                       n_pixel_snail_blocks=8, n_residual_blocks=2,
-                                       attention_key_channels=4, attention_value_channels=32),
-                    (3, 32, 32), 1e-3, 0.999977, 7.97e9, 110.5e6),
-    "gated_pixel_cnn": ("GatedPixelCNN", dict(in_channels=3, out_channels=3, n_gated=10,
-                                              gated_channels=128, head_channels=32),
-                        (3, 32, 32), 1e-3, 0.9999, 21.23e9, 266e6),
-    "pixel_cnn": ("PixelCNN", dict(in_channels=1, out_channels=1, n_residual=15,
-                                   residual_channels=32, head_channels=32),
-                  (1, 28, 28), 1e-3, 0.999977, 0.964e9, 31.6e6),
-    # BASELINE.json configs[4]: VAE conv stacks + KL on 64x64x3 (ELBO loss, vae.py:149-159)
-    "beta_vae": ("BetaVAE", dict(in_channels=3, out_channels=3, beta=4.0, latent_channels=16,
-                                 strides=[2, 2, 2, 2], hidden_channels=64, residual_channels=32),
-                 (3, 64, 64), 1e-3, 1.0, 1.57e9, 17.6e6),
-    "vd_vae": ("VeryDeepVAE", dict(in_channels=3, out_channels=3, input_resolution=64,
-                                   stack_configs=[(3, 5), (3, 5), (2, 4), (2, 3), (2, 2), (1, 1)],
-                                   latent_channels=16, hidden_channels=64, bottleneck_channels=32),
-               (3, 64, 64), 5e-4, 1.0, 10.96e9, 354e6),
-}
-HEADS, DK, DV, L = 4, 4, 4, 784
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix == vector peak (no TF32 on gfx950)
+LN2 = 0.6931471805599453
+
+
+def _attn_flops_per_pair(dk, dv):
+    """Algorithmic FLOPs per allowed (query, key) pair of the three attention kernels:
+    fwd QK^T + PV; dQ recomputes QK^T, dP = dO V^T, dQ = dS K; dK/dV recomputes QK^T, dP, dV = P^T dO,
+    dK = dS^T Q."""
+    return {"fwd": 2 * dk + 2 * dv, "dq": 4 * dk + 2 * dv, "dkv": 4 * dk + 4 * dv}
+
+
+def _causal_gflop_per_img(dense_total, dense_attn, heads, L, dk, dv, blocks, strict):
+    """SURVEY.md §8(d) counts attention as dense L^2 at 3.5x forward; the kernels only touch the
+    allowed pairs (and recompute more in backward). Returns the per-image training GFLOP with the
+    attention core counted on the causal triangle."""
+    pairs = heads * (L * (L - 1) / 2 if strict else L * (L + 1) / 2)
+    attn = blocks * pairs * sum(_attn_flops_per_pair(dk, dv).values()) / 1e9
+    return dense_total - dense_attn + attn
+
+
+# name -> constructor, kwargs, (C, H, W), lr, per-batch lr decay, SURVEY §8(d) GFLOP / MB per image
+WORKLOADS = {
+    "image_gpt": dict(ctor="ImageGPT", kw=dict(in_channels=1, out_channels=1, in_size=28, n_transformer_blocks=8,
+                                               n_attention_heads=4, n_embedding_channels=16),
+                      chw=(1, 28, 28), lr=5e-3, decay=0.999977, gflop=1.223, mbytes=26.2,
+                      gflop_causal=_causal_gflop_per_img(1.223, 1.10, 4, 784, 4, 4, 8, False)),
+    "pixel_snail": dict(ctor="PixelSNAIL", kw=dict(in_channels=3, out_channels=3, n_channels=64,
+                                                   n_pixel_snail_blocks=8, n_residual_blocks=2,
+                                                   attention_key_channels=4, attention_value_channels=32),
+                        chw=(3, 32, 32), lr=1e-3, decay=0.999977, gflop=7.97, mbytes=110.5,
+                        gflop_causal=_causal_gflop_per_img(7.97, 2.114, 1, 1024, 4, 32, 8, True)),
+    "gated_pixel_cnn": dict(ctor="GatedPixelCNN", kw=dict(in_channels=3, out_channels=3, n_gated=10,
+                                                          gated_channels=128, head_channels=32),
+                            chw=(3, 32, 32), lr=1e-3, decay=0.9999, gflop=21.23, mbytes=266.0),
+    "pixel_cnn": dict(ctor="PixelCNN", kw=dict(in_channels=1, out_channels=1, n_residual=15,
+                                               residual_channels=32, head_channels=32),
+                      chw=(1, 28, 28), lr=1e-3, decay=0.999977, gflop=0.964, mbytes=31.6),
+    # BASELINE.json configs[4]: VAE conv stacks + KL on 64x64x3 (ELBO loss, vae.py:149-159)
+    "beta_vae": dict(ctor="BetaVAE", kw=dict(in_channels=3, out_channels=3, beta=4.0, latent_channels=16,
+                                             strides=[2, 2, 2, 2], hidden_channels=64, residual_channels=32),
+                     chw=(3, 64, 64), lr=1e-3, decay=1.0, gflop=1.57, mbytes=17.6),
+    "vd_vae": dict(ctor="VeryDeepVAE", kw=dict(in_channels=3, out_channels=3, input_resolution=64,
+                                               stack_configs=[(3, 5), (3, 5), (2, 4), (2, 3), (2, 2), (1, 1)],
+                                               latent_channels=16, hidden_channels=64, bottleneck_channels=32),
+                   chw=(3, 64, 64), lr=5e-4, decay=1.0, gflop=10.96, mbytes=354.0),
+}
+WORKLOAD_TEXT = {
+    "image_gpt": "BASELINE.json configs[1]: ImageGPT 8 blocks / 4 heads / 16 embed on 28x28x1 "
+                 "binarised-MNIST-shaped synthetic",
+    "pixel_snail": "BASELINE.json configs[3]: PixelSNAIL(3, 3, n_channels=64, 8 blocks, 2 residual "
+                   "blocks, key 4 / value 32 channels) on 32x32x3 CIFAR-shaped synthetic",
+}
+STEP_TEXT = ("one step = zero_grad + fwd + BCE + bwd + global grad-norm + Adam + lr decay "
+             "(reference trainer.py:173-193)")
 
 
 def synthetic_batch(batch, rank, chw=(1, 28, 28)):
@@ -62,156 +98,54 @@ def synthetic_batch(batch, rank, chw=(1, 28, 28)):
     return torch.randint(0, 256, (batch, *chw), generator=g).float() / 255  # CIFAR-shaped
 
 
-def attention_kernel_roofline(batch, device, iters=10):
-    """Times the three causal-attention kernels live with HIP events on the stream they are
-    launched on, through the C-ABI, at the bench's exact shapes and on random data. The dominant
-    kernel of the step is attn_dkv_m44_kernel (pg_causal_attn_bwd_dkv; matrix-core path, d_k = d_v = 4).
-    Algorithmic FLOPs (DESIGN.md §4): pairs = N*heads*L*(L+1)/2 allowed (query, key) pairs;
-      fwd   2*dk + 2*dv          (QK^T, PV)
-      dQ    2*dk + 2*dv + 2*dk   (QK^T recompute, dP = dO V^T, dQ = dS K)
-      dK/dV 2*dk + 2*dv + 2*dv + 2*dk (QK^T recompute, dP, dV = P^T dO, dK = dS^T Q)."""
-    from pytorch_generative_amd import _lib
+class Env:
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+            args.gpus = self.world
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        # debugging hooks (1-GPU dev box): PG_FORCE_DEVICE pins every rank to one GPU and
+        # PG_DIST_BACKEND=gloo replaces RCCL so the multi-process code path can be exercised there
+        local_rank = int(os.environ.get("PG_FORCE_DEVICE", local_rank))
+        backend = os.environ.get("PG_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world,
+                                        device_id=self.device)
+            else:
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
 
-    lib = _lib.load()
-    e = HEADS * DK
-    g = torch.Generator().manual_seed(7)
-    mk = lambda c: torch.randn(batch, c, 28, 28, generator=g).to(device)  # noqa: E731
-    q, kv, d_o = mk(e), mk(2 * e), mk(e)
-    o, dq, dkv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(kv)
-    lse = torch.empty(batch, HEADS, L, device=device)
-    delta = torch.empty_like(lse)
-    stream = torch.cuda.current_stream()
-    st = stream.cuda_stream
-    kvs = 2 * e * L
-
-    def fwd():
-        _lib.check(lib.pg_causal_attn_fwd(q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * e * L,
-                                          o.data_ptr(), lse.data_ptr(), batch, HEADS, L, DK, DV,
-                                          e * L, kvs, kvs, e * L, 0, st), "fwd")
-
-    def bwd(fn):
-        _lib.check(fn(q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * e * L, o.data_ptr(),
-                      d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(),
-                      dkv.data_ptr(), dkv.data_ptr() + 4 * e * L, batch, HEADS, L, DK, DV, e * L,
-                      kvs, kvs, e * L, e * L, e * L, kvs, kvs, 0, st), "bwd")
-
-    def timed(fn):
-        fn()
+    def barrier(self):
         torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-               for _ in range(iters)]
-        for a, b in evs:
-            a.record(stream)
-            fn()
-            b.record(stream)
+        if self.world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in evs) / iters
-
-    t_fwd = timed(fwd)
-    t_dq = timed(lambda: bwd(lib.pg_causal_attn_bwd_dq))
-    t_dkv = timed(lambda: bwd(lib.pg_causal_attn_bwd_dkv))
-    pairs = batch * HEADS * L * (L + 1) / 2
-    fl = {"fwd": pairs * (2 * DK + 2 * DV), "dq": pairs * (4 * DK + 2 * DV),
-          "dkv": pairs * (4 * DK + 4 * DV)}
-    ms = {"fwd": t_fwd, "dq": t_dq, "dkv": t_dkv}
-    return {k: {"launch_ms": ms[k], "flop_per_launch": fl[k], "tflops": fl[k] / ms[k] / 1e9}
-            for k in ms}
 
 
-def measured_traffic(batch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile (collected in
-    separate rocprofv3 --pmc passes, see profiles/README.md); None when no profile matches."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("per_gpu_batch") == batch:
-            return t.get("attn_bwd_dkv_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
-    return None
-
-
-def cpu_baseline(batch=16, steps=2):
-    """The oracle's restatement of the same training step on the host cores (kind 'port': the
-    reference is Python and cannot travel to the GPU box; the oracle dispatches the same torch
-    CPU primitives). Bounded sample: 1 warm-up + `steps` timed steps at a reduced batch."""
-    from oracle import models as omodels
-    from oracle import train as otrain
-
-    import pytorch_generative_amd as pg
-
-    torch.manual_seed(0)
-    model = pg.models.ImageGPT(**MODEL_KW)
-    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    x = synthetic_batch(batch, 0)
-    opt_state = otrain.new_opt_state()
-    times = []
-    for i in range(steps + 1):
-        t0 = time.perf_counter()
-        _, loss, grads = otrain.loss_and_grads(omodels.image_gpt, state, x, n_heads=HEADS)
-        otrain.adam_step_(state, grads, opt_state, lr=LR)
-        times.append(time.perf_counter() - t0)
-    dt = sum(times[1:]) / steps
-    return {
-        "value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"oracle train step (torch-CPU fp32), batch {batch}, {steps} timed steps after 1 warm-up, "
-                  f"{dt * 1e3:.0f} ms/step",
-    }
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024,
-                    help="per-GPU batch (weak scaling); 1024 = the saturating batch SURVEY.md §8(d) names for 28x28 models")
-    ap.add_argument("--model", default="image_gpt", choices=["image_gpt", *OTHER_MODELS])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-        args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    # debugging hooks (1-GPU dev box): PG_FORCE_DEVICE pins every rank to one GPU and
-    # PG_DIST_BACKEND=gloo replaces RCCL so the multi-process code path can be exercised there
-    local_rank = int(os.environ.get("PG_FORCE_DEVICE", local_rank))
-    backend = os.environ.get("PG_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-
+def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=False):
+    """Builds the model, captures the step and times EXACTLY `steps` steps between barriers
+    (max over ranks). Returns the record of this workload at this per-GPU batch."""
     import pytorch_generative_amd as pg
     from pytorch_generative_amd import graph, ops, optim, parallel
 
+    w = WORKLOADS[name]
     torch.manual_seed(0)  # identical initial weights on every rank (then broadcast anyway)
-    chw, gflop_img, bytes_img = (1, 28, 28), 1.223e9, 26.2e6  # SURVEY.md §8(d), per image
-    if args.model == "image_gpt":
-        model = pg.models.ImageGPT(**MODEL_KW).to(device)
-        lr, lr_decay = LR, LR_DECAY
-    else:
-        ctor, kw, chw, lr, lr_decay, gflop_img, bytes_img = OTHER_MODELS[args.model]
-        model = getattr(pg.models, ctor)(**kw).to(device)
+    model = getattr(pg.models, w["ctor"])(**w["kw"]).to(env.device)
     model.train()
-    opt = optim.FlatAdam(model.parameters(), lr=lr, lr_decay=lr_decay)
+    opt = optim.FlatAdam(model.parameters(), lr=w["lr"], lr_decay=w["decay"])
     reducer = None
-    if world > 1:
+    if env.world > 1:
         reducer = parallel.FlatGradAllReduce(opt)
         reducer.broadcast_parameters(src=0)
-    x = synthetic_batch(args.batch, rank, chw).to(device)
-    if args.model in ("beta_vae", "vd_vae"):
+    x = synthetic_batch(batch, env.rank, w["chw"]).to(env.device)
+    if name in ("beta_vae", "vd_vae"):
         def loss_fn(xx, preds):  # ELBO: recon.mean() + kl.mean()
             recon, klm = ops.elbo_terms(preds[0], xx, preds[1])
             return recon + klm
@@ -227,82 +161,306 @@ def main():
         opt.step()
         return loss.detach()
 
-    launch = "eager"
-    step = eager_step
-    if not args.no_graph:
+    launch, fallback, step = "eager", None, eager_step
+    if use_graph:
         try:
             gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
             step = lambda: gstep()  # noqa: E731
             launch = "hipGraph replay"
-        except Exception as e:  # keep the bench alive (e.g. capture refused next to a live RCCL comm)
-            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); "
-                  "falling back to eager launches", file=sys.stderr, flush=True)
+        except Exception as e:  # e.g. capture refused next to a live RCCL communicator
+            fallback = f"{type(e).__name__}: {e}"
+            print(f"[bench] WARNING rank {env.rank}: hipGraph capture of {name} FAILED ({fallback}); "
+                  "the numbers below are EAGER launches", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
-    if world > 1:  # every rank must take the same path (graphs imply a different collective order)
-        flag = torch.tensor([1 if launch == "eager" else 0], device=device)
+            if require_graph:
+                raise SystemExit(f"--require-graph: capture failed on rank {env.rank}: {fallback}")
+    if env.world > 1:  # every rank must take the same path (graphs imply a different collective order)
+        flag = torch.tensor([1 if launch == "eager" else 0], device=env.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) == 1 and launch != "eager":
-            step, launch = eager_step, "eager"
+            if require_graph:
+                raise SystemExit("--require-graph: another rank fell back to eager launches")
+            step, launch, fallback = eager_step, "eager", "another rank failed to capture"
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    env.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    env.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    t = torch.tensor([elapsed], device=env.device, dtype=torch.float64)
+    if env.world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     loss_val = float(loss.item())
+    value = batch * env.world * steps / elapsed
+    dims = w["chw"][0] * w["chw"][1] * w["chw"][2]
+    rec = {
+        "images_per_s": value, "ms_per_step": elapsed / steps * 1e3, "per_gpu_batch": batch,
+        "global_batch": batch * env.world, "launch": launch, "graph_fallback": fallback,
+        "loss_nats_per_image": loss_val, "bits_per_dim": loss_val / (dims * LN2),
+        # whole step against the per-image algorithmic work of SURVEY.md §8(d)
+        "step_hbm_gbps_algorithmic": value * w["mbytes"] * 1e6 / 1e9,
+        "step_tflops_dense_attention_count": value * w["gflop"] / 1e3,
+    }
+    if "gflop_causal" in w:  # attention counted on the allowed pairs only (what the kernels execute)
+        rec["step_tflops"] = value * w["gflop_causal"] / 1e3
+        rec["step_frac_of_fp32_peak"] = rec["step_tflops"] / env.world / FP32_PEAK_TFLOPS
+    del model, opt, step
+    torch.cuda.empty_cache()
+    return rec
 
-    if rank == 0:
-        global_batch = args.batch * world
-        value = global_batch * args.steps / elapsed
+
+def _event_time(fn, stream, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(stream)
+        fn()
+        b.record(stream)
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs) / iters
+
+
+def attention_kernel_roofline(batch, device, heads, dk, dv, hw, strict):
+    """Times the three causal-attention kernels live with HIP events on the stream they are
+    launched on, through the C-ABI, at the bench's exact shapes and on random data."""
+    from pytorch_generative_amd import _lib
+
+    lib = _lib.load()
+    e, vd, L = heads * dk, heads * dv, hw * hw
+    g = torch.Generator().manual_seed(7)
+    mk = lambda c: torch.randn(batch, c, hw, hw, generator=g).to(device)  # noqa: E731
+    q, kv, d_o = mk(e), mk(e + vd), mk(vd)
+    o, dq, dkv = torch.empty_like(d_o), torch.empty_like(q), torch.empty_like(kv)
+    lse = torch.empty(batch, heads, L, device=device)
+    delta = torch.empty_like(lse)
+    stream = torch.cuda.current_stream()
+    st = stream.cuda_stream
+    kvs = (e + vd) * L
+
+    def fwd():
+        _lib.check(lib.pg_causal_attn_fwd(q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * e * L,
+                                          o.data_ptr(), lse.data_ptr(), batch, heads, L, dk, dv,
+                                          e * L, kvs, kvs, vd * L, int(strict), st), "fwd")
+
+    def bwd(fn):
+        _lib.check(fn(q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * e * L, o.data_ptr(),
+                      d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(),
+                      dkv.data_ptr(), dkv.data_ptr() + 4 * e * L, batch, heads, L, dk, dv, e * L,
+                      kvs, kvs, vd * L, vd * L, e * L, kvs, kvs, int(strict), st), "bwd")
+
+    ms = {"fwd": _event_time(fwd, stream),
+          "dq": _event_time(lambda: bwd(lib.pg_causal_attn_bwd_dq), stream),
+          "dkv": _event_time(lambda: bwd(lib.pg_causal_attn_bwd_dkv), stream)}
+    pairs = batch * heads * (L * (L - 1) / 2 if strict else L * (L + 1) / 2)
+    per = _attn_flops_per_pair(dk, dv)
+    return {k: {"launch_ms": ms[k], "flop_per_launch": pairs * per[k],
+                "tflops": pairs * per[k] / ms[k] / 1e9} for k in ms}
+
+
+def conv_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
+    """PixelSNAIL's dominant kernel: conv_mfma_kernel<4, 4> on its most frequent problem — the 2x2
+    (pad 1, cropped) 64 -> 64 convolution of ResidualBlock with the fused ELU prologue
+    (pixel_snail.py:41-55), forward launch, timed through the C-ABI with HIP events."""
+    from pytorch_generative_amd import _lib, ops
+
+    lib = _lib.load()
+    spec = ops.ConvSpec(2, 2, 1, 1)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(batch, cin, hw, hw, generator=g).to(device)
+    wt = (torch.randn(cout, cin, 2, 2, generator=g) * 0.05).to(device)
+    bias = torch.zeros(cout, device=device)
+    out = torch.empty(batch, cout, hw, hw, device=device)
+    wfrag = ops._pack_frag(lib, wt, spec, transpose=False)
+    stream = torch.cuda.current_stream()
+    T = len(spec.fwd_taps)
+
+    def run():
+        _lib.check(lib.pg_conv2d_mfma(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), 0, out.data_ptr(),
+                                      batch, cin, hw, hw, cout, hw, hw, T, spec.f_dr, spec.f_dc,
+                                      ops.ACT_ELU, 0, ops.ACT_NONE, ops.ACT_NONE, stream.cuda_stream),
+                   "pg_conv2d_mfma")
+
+    ms = _event_time(run, stream)
+    flop = 2.0 * batch * hw * hw * cin * cout * T
+    return {"launch_ms": ms, "flop_per_launch": flop, "tflops": flop / ms / 1e9}
+
+
+def measured_traffic(batch):
+    """HBM bytes per launch of the headline's dominant kernel from the committed PMC profile
+    (collected in separate rocprofv3 --pmc passes, see profiles/README.md); None when no profile
+    matches this batch."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            if t.get("per_gpu_batch") == batch:
+                return t.get("attn_bwd_dkv_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+    return None
+
+
+def _physical_cores():
+    try:
+        seen = set()
+        with open("/proc/cpuinfo") as f:
+            phys = core = None
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline(batch=32, budget_s=30.0):
+    """The oracle's restatement of the same ImageGPT training step on the host cores (kind 'port':
+    the reference is Python and cannot travel to the GPU box; the oracle dispatches the same torch
+    CPU primitives — oneDNN / MKL — in the same order). Bounded sample: a thread sweep over
+    {physical cores, 32, 16} (1 warm-up + 2 timed steps each), then 5 timed steps at the best
+    setting, at batch 32 (the survey's probe batch; the reference default 64 gives the same
+    images/s within noise but doubles the sample's wall time)."""
+    from oracle import models as omodels
+    from oracle import train as otrain
+
+    import pytorch_generative_amd as pg
+
+    w = WORKLOADS["image_gpt"]
+    torch.manual_seed(0)
+    model = pg.models.ImageGPT(**w["kw"])
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = synthetic_batch(batch, 0)
+    logical, physical = os.cpu_count(), _physical_cores()
+    default_threads = torch.get_num_threads()
+
+    def timed(threads, n_steps):
+        torch.set_num_threads(threads)
+        state = {k: v.clone() for k, v in state0.items()}
+        opt_state = otrain.new_opt_state()
+        ts = []
+        for _ in range(n_steps + 1):
+            t0 = time.perf_counter()
+            _, loss, grads = otrain.loss_and_grads(omodels.image_gpt, state, x, n_heads=4)
+            otrain.adam_step_(state, grads, opt_state, lr=w["lr"])
+            ts.append(time.perf_counter() - t0)
+        return sum(ts[1:]) / n_steps, float(loss)
+
+    t_start = time.perf_counter()
+    sweep = {}
+    # small thread counts first: at this model size (16 channels) the per-op work is tiny and 128
+    # threads measured SLOWER than 16 (oversubscription); the sweep stops when its time budget is spent
+    for threads in sorted({t for t in (16, 32, physical or logical) if t and t <= logical}):
+        if sweep and time.perf_counter() - t_start > budget_s * 0.5:
+            break
+        sweep[threads] = timed(threads, 2)[0]
+    best = min(sweep, key=sweep.get)
+    dt, loss = timed(best, 5)
+    torch.set_num_threads(default_threads)
+    return {
+        "value": batch / dt, "unit": "images/s", "cores": best, "cores_logical": logical,
+        "cores_physical": physical, "kind": "port", "torch": torch.__version__,
+        "ms_per_step": dt * 1e3, "loss_after": loss,
+        "thread_sweep_ms_per_step": {str(k): v * 1e3 for k, v in sweep.items()},
+        "sample": f"oracle train step (torch-CPU fp32, ImageGPT 8/4/16), batch {batch}, 5 timed steps after "
+                  f"1 warm-up at {best} threads (best of a sweep over {sorted(sweep)})",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024,
+                    help="per-GPU batch of the headline (weak scaling); 1024 = the saturating batch "
+                         "SURVEY.md §8(d) names for 28x28 models")
+    ap.add_argument("--snail-batch", type=int, default=512, help="per-GPU batch of the PixelSNAIL record")
+    ap.add_argument("--model", default=None, choices=sorted(WORKLOADS),
+                    help="bench this one workload only (profiling helper)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (no batch-64 / PixelSNAIL records)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--require-graph", action="store_true",
+                    help="exit non-zero if hipGraph capture fails on any rank instead of falling back to eager")
+    args = ap.parse_args()
+    env = Env(args)
+    graph_on = not args.no_graph
+
+    def run(name, batch, steps=None):
+        return run_workload(env, name, batch, steps or args.steps, args.warmup, graph_on, args.require_graph)
+
+    if args.model is not None:  # single-workload helper line
+        w = WORKLOADS[args.model]
+        rec = run(args.model, args.batch)
+        if env.rank == 0:
+            print(json.dumps({
+                "metric": f"training images/sec ({w['ctor']}, {w['chw'][1]}x{w['chw'][2]}x{w['chw'][0]})",
+                "value": rec["images_per_s"], "unit": "images/s", "n_gpus": env.world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{w['ctor']}({w['kw']}) on synthetic {w['chw']}; {STEP_TEXT} "
+                                       "(secondary workload, not the driver line)",
+                           "per_gpu_batch": args.batch, "global_batch": args.batch * env.world,
+                           "parallelism": f"dp{env.world}", "launch": rec["launch"],
+                           "graph_fallback": rec["graph_fallback"]},
+                "record": rec}), flush=True)
+        if env.world > 1:
+            dist.destroy_process_group()
+        return
+
+    head = run("image_gpt", args.batch)
+    extras = {}
+    if not args.no_extras:
+        extras["imagegpt_b64"] = run("image_gpt", 64)
+        snail = run("pixel_snail", args.snail_batch, steps=max(10, args.steps // 2))
+        snail["reference_default_batch_128"] = run("pixel_snail", 128)
+        extras["pixel_snail"] = snail
+
+    if env.rank == 0:
         out = {
             "metric": "training images/sec (ImageGPT 8-block/4-head/16-embed, 28x28x1)",
-            "value": value,
+            "value": head["images_per_s"],
             "unit": "images/s",
-            "n_gpus": world,
+            "n_gpus": env.world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[1]: ImageGPT 8 blocks / 4 heads / 16 embed on "
-                            "28x28x1 binarised-MNIST-shaped synthetic; one step = zero_grad + fwd + "
-                            "BCE + bwd + global grad-norm + Adam + lr decay (reference trainer.py:173-193)",
+                "workload": WORKLOAD_TEXT["image_gpt"] + "; " + STEP_TEXT,
                 "per_gpu_batch": args.batch,
-                "global_batch": global_batch,
-                "parallelism": f"dp{world}",
-                "launch": launch,
+                "global_batch": args.batch * env.world,
+                "parallelism": f"dp{env.world}",
+                "launch": head["launch"],
+                "graph_fallback": head["graph_fallback"],
             },
-            "loss_nats_per_image": loss_val,
-            "bits_per_dim": loss_val / (784 * 0.6931471805599453),
+            "loss_nats_per_image": head["loss_nats_per_image"],
+            "bits_per_dim": head["bits_per_dim"],
         }
-        if args.model != "image_gpt":
-            ctor, kw = OTHER_MODELS[args.model][:2]
-            out["metric"] = f"training images/sec ({ctor}, {chw[1]}x{chw[2]}x{chw[0]})"
-            out["config"]["workload"] = (f"{ctor}({kw}) on {chw[1]}x{chw[2]}x{chw[0]} synthetic; same step "
-                                         "definition as the default ImageGPT line (secondary workload)")
-            out["bits_per_dim"] = loss_val / (chw[0] * chw[1] * chw[2] * 0.6931471805599453)
-            out["roofline"] = {"step_tflops": value * gflop_img / 1e12,
-                               "step_hbm_gbps_algorithmic": value * bytes_img / 1e9,
-                               "note": "whole-step view against SURVEY.md §8(d) per-image work"}
-        elif world == 1:
-            r = attention_kernel_roofline(args.batch, device)
+        if "imagegpt_b64" in extras:
+            b64 = extras["imagegpt_b64"]
+            out["imagegpt_b64"] = {"what": "same model and step at the reference's default per-GPU batch 64 "
+                                           "(image_gpt.py:114)", **b64}
+        if "pixel_snail" in extras:
+            out["pixel_snail"] = {"workload": WORKLOAD_TEXT["pixel_snail"] + "; " + STEP_TEXT,
+                                  "unit": "images/s", "dtype": "f32", **extras["pixel_snail"]}
+        if env.world == 1:
+            r = attention_kernel_roofline(args.batch, env.device, 4, 4, 4, 28, False)
             out["roofline"] = {
                 "bound": "mfma",  # fp32: matrix peak == vector peak == 157.3 TF on gfx950; the
                                   # kernel is fp32-MFMA + v_exp issue bound (DESIGN.md §4)
@@ -314,18 +472,29 @@ def main():
                 "traffic": measured_traffic(args.batch),
                 "launch_ms": r["dkv"]["launch_ms"],
                 "flop_per_launch": r["dkv"]["flop_per_launch"],
-                "other_kernels": {
-                    "attn_fwd_m44_kernel": r["fwd"],
-                    "attn_dq_m44_kernel": r["dq"],
-                },
-                # whole step against SURVEY.md §8(d)'s per-image algorithmic work (1.223 GF, 26.2 MB)
-                "step_tflops": value * 1.223e9 / 1e12,
-                "step_hbm_gbps_algorithmic": value * 26.2e6 / 1e9,
+                "other_kernels": {"attn_fwd_m44_kernel": r["fwd"], "attn_dq_m44_kernel": r["dq"]},
+                # whole step; attention counted on the causal triangle (what the kernels execute)
+                "step_tflops": head["step_tflops"],
+                "step_frac": head["step_frac_of_fp32_peak"],
+                "step_tflops_dense_attention_count": head["step_tflops_dense_attention_count"],
+                "step_hbm_gbps_algorithmic": head["step_hbm_gbps_algorithmic"],
             }
+            if "pixel_snail" in out:
+                c = conv_kernel_roofline(args.snail_batch, env.device)
+                a = attention_kernel_roofline(args.snail_batch, env.device, 1, 4, 32, 32, True)
+                out["pixel_snail"]["roofline"] = {
+                    "bound": "mfma",
+                    "kernel": "conv_mfma_kernel<4, 4> (pg_conv2d_mfma: 2x2 64->64 convolution, ELU prologue)",
+                    "achieved": c["tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": c["tflops"] / FP32_PEAK_TFLOPS, "launch_ms": c["launch_ms"],
+                    "flop_per_launch": c["flop_per_launch"], "traffic": None,
+                    "other_kernels": {"attn_fwd_k4_kernel": a["fwd"], "attn_dq_k4_kernel": a["dq"],
+                                      "attn_dkv_k4_kernel": a["dkv"]},
+                }
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if env.world > 1:
         dist.destroy_process_group()
 
 
