@@ -45,7 +45,7 @@ struct MfArgs {
   int NI, TR, tiles_per_grp, tile_h, tile_w, min_dr, min_dc, img_stride, ch_stride, CIB;
   int KQ;  // K steps of the whole problem: ceil(Cin / 4) * T
   int in_act, dact, out_act;
-  int w_off, b_off, dump;  // LDS float offsets
+  int w_off, b_off, dump, buf_stride;  // LDS float offsets (w_off / dump inside a buffer)
   int Q, xslots;    // float4 staging: quads per input row, NI * CIB * tile_h * Q slots per chunk
   int tapoff[PG_MAX_TAPS];
 };
@@ -68,8 +68,6 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
   const int L = a.OH * a.OW;
   const int plane = a.IH * a.IW;
 
-  float* xl = lds;
-  float* wl = lds + a.w_off;
 
   // lane's pixel of each of its 16-pixel groups: LDS offset, validity
   int pixoff[NT];
@@ -125,7 +123,10 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
 
   // zero the tile once: the float4 staging writes in-range elements only (the halo stays zero), and
   // the channels that pad the last group of 4 must hold finite values (their weights are zero)
-  for (int i = tid; i < a.CIB * a.ch_stride; i += MF_THREADS) xl[i] = 0.f;
+  for (int i = tid; i < a.CIB * a.ch_stride; i += MF_THREADS) {
+    lds[i] = 0.f;
+    lds[a.buf_stride + i] = 0.f;
+  }
   if (tid < MF_CO_CHUNK) {
     const int co = co0 + tid;
     lds[a.b_off + tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
@@ -160,41 +161,49 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
     }                                                                                     \
   }
 
-  PG_MF_ISSUE(0)
-  const int kb = lane >> 4;
-  for (int ci0 = 0; ci0 < a.Cin; ci0 += a.CIB) {
-    const int cib = min(a.CIB, a.Cin - ci0);
-    const int ng = (cib + 3) >> 2;  // channel groups of this chunk
-    __syncthreads();                // the previous chunk's fragment reads are done
-#define PG_MF_COMMIT(ACT)                                                   \
+#define PG_MF_COMMIT(ACT, XL)                                               \
   _Pragma("unroll") for (int k = 0; k < XS; ++k) {                          \
     const bool ok = (xok >> k) & 1;                                         \
     const int loff = (s_meta[k] & 0xffff) - 4;                              \
     const float e[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                         \
       const bool oki = ok && ((s_meta[k] >> (16 + i)) & 1);                 \
-      xl[oki ? loff + i : a.dump] = pg_apply_act(e[i], ACT);                \
+      (XL)[oki ? loff + i : a.dump] = pg_apply_act(e[i], ACT);              \
     }                                                                       \
   }
-    switch (a.in_act) {  // wave-uniform
-      case PG_ACT_RELU: PG_MF_COMMIT(PG_ACT_RELU) break;
-      case PG_ACT_ELU:  PG_MF_COMMIT(PG_ACT_ELU) break;
-      case PG_ACT_GELU: PG_MF_COMMIT(PG_ACT_GELU) break;
-      default:          PG_MF_COMMIT(PG_ACT_NONE) break;
-    }
-#undef PG_MF_COMMIT
-    {
-      const int nw4 = ng * a.T * MT * 16;
-      float4* wdst = reinterpret_cast<float4*>(wl);
-#pragma unroll
-      for (int k = 0; k < WS; ++k) {
-        const int i = tid + k * MF_THREADS;
-        if (i < nw4) wdst[i] = wv[k];
-      }
-    }
-    __syncthreads();
-    if (ci0 + a.CIB < a.Cin) PG_MF_ISSUE(ci0 + a.CIB)  // prefetch: lands under the MFMA loop
-    const int gstride = 4 * a.ch_stride;
+  // writes the chunk in flight (x slots with the prologue activation, weight fragments) into buffer BUF
+#define PG_MF_COMMIT_ALL(BUF, CI0)                                                       \
+  {                                                                                      \
+    float* xl_ = lds + (BUF) * a.buf_stride;                                             \
+    switch (a.in_act) { /* wave-uniform */                                               \
+      case PG_ACT_RELU: PG_MF_COMMIT(PG_ACT_RELU, xl_) break;                            \
+      case PG_ACT_ELU:  PG_MF_COMMIT(PG_ACT_ELU, xl_) break;                             \
+      case PG_ACT_GELU: PG_MF_COMMIT(PG_ACT_GELU, xl_) break;                            \
+      default:          PG_MF_COMMIT(PG_ACT_NONE, xl_) break;                            \
+    }                                                                                    \
+    const int nw4_ = ((min(a.CIB, a.Cin - (CI0)) + 3) >> 2) * a.T * MT * 16;             \
+    float4* wdst_ = reinterpret_cast<float4*>(xl_ + a.w_off);                            \
+    _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                     \
+      const int i = tid + k * MF_THREADS;                                                \
+      if (i < nw4_) wdst_[i] = wv[k];                                                    \
+    }                                                                                    \
+  }
+
+  // Two LDS buffers: while the waves run the MFMA loop of chunk c out of one, each wave that finishes
+  // commits chunk c+1 (its loads were issued before the loop) into the other — ONE barrier per chunk.
+  PG_MF_ISSUE(0)
+  PG_MF_COMMIT_ALL(0, 0)
+  __syncthreads();
+  const int kb = lane >> 4;
+  const int gstride = 4 * a.ch_stride;
+  int cur = 0;
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += a.CIB) {
+    const int cib = min(a.CIB, a.Cin - ci0);
+    const int ng = (cib + 3) >> 2;  // channel groups of this chunk
+    const bool more = ci0 + a.CIB < a.Cin;
+    if (more) PG_MF_ISSUE(ci0 + a.CIB)  // prefetch: lands under the MFMA loop
+    const float* xl = lds + cur * a.buf_stride;
+    const float* wl = xl + a.w_off;
     for (int t = 0; t < a.T; ++t) {
       const float* xb = xl + a.tapoff[t] + kb * a.ch_stride;
       const float* wb = wl + t * (MT * 64) + lane;
@@ -215,7 +224,14 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
       }
     }
+    if (more) {
+      PG_MF_COMMIT_ALL(cur ^ 1, ci0 + a.CIB)
+      __syncthreads();
+    }
+    cur ^= 1;
   }
+#undef PG_MF_COMMIT
+#undef PG_MF_COMMIT_ALL
 #undef PG_MF_ISSUE
 
   // ---- epilogue: + bias, out_act, + res, * act'(dact_src) (data gradient of a fused input activation).
@@ -238,79 +254,125 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
     const int r = q - img * rows;
     so = ((size_t)(n0 + img) * a.Cout + co0) * L + (size_t)((row0 + r) * a.OW + c);
   }
-  // One 16-channel tile at a time; the residual / act' operands of tile m+1 are requested BEFORE the
-  // stores of tile m are issued, so waiting for them never waits for a store (loads and stores share
-  // vmcnt and complete in order: a load issued after a store drains it).
+  // One 16-channel tile at a time. Loads and stores share vmcnt and retire in order, so a load that
+  // follows a store drains it (measured: a conditional residual load between the tiles cost a full
+  // store round trip per tile — 20 us of an 80 us launch). Hence two code paths: without residual /
+  // act' operands the epilogue issues NO loads at all; with them, the operands of tile m+1 are
+  // requested unconditionally (absent ones from a valid dummy address, discarded by a select)
+  // BEFORE the stores of tile m, so that waiting for them never waits for a store.
   const int cvalid = a.Cout - co0;  // channels of this chunk that exist (>= 1)
-  const float* resp = a.res ? a.res + so : nullptr;
-  const float* dsp = a.dact_src ? a.dact_src + so : nullptr;
   float* outp = a.out + so;
-  float rv[16], sv[16];
+  const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
+#define PG_MF_TILE_BODY(M)                                                                       \
+  _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) ep[(kb * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[M][n][r]; \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+  float v[16];                                                                                   \
+  _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = ep[c * EPS + lane] + bl[(M) * 16 + c];   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+  switch (a.out_act) { /* wave-uniform */                                                        \
+    case PG_ACT_RELU: _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_RELU); break; \
+    case PG_ACT_ELU:  _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_ELU); break;  \
+    case PG_ACT_GELU: _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_GELU); break; \
+    default: break;                                                                              \
+  }
+#define PG_MF_TILE_STORE(M)                                                   \
+  if (sok) {                                                                  \
+    _Pragma("unroll") for (int c = 0; c < 16; ++c) {                          \
+      const int cc = (M) * 16 + c;                                            \
+      if (cc < cvalid) outp[(size_t)cc * L] = v[c];                           \
+    }                                                                         \
+  }
+  if (!has_res && !has_ds) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      PG_MF_TILE_BODY(m)
+      PG_MF_TILE_STORE(m)
+    }
+  } else if (has_res != has_ds) {
+    // exactly one extra operand (a forward residual, or the act' source of a data gradient — the
+    // only combinations the model code produces): ALL of its values are requested up front, then
+    // the tiles are transposed and stored with no load in between
+    const float* opp = has_res ? a.res + so : a.dact_src + so;
+    float ov[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int cc = m * 16 + c;
+        ov[m][c] = opp[(size_t)(cc < cvalid ? cc : 0) * L];
+      }
+    const int dsel = has_ds ? a.dact : PG_ACT_NONE;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      PG_MF_TILE_BODY(m)
+      switch (dsel) {
+        case PG_ACT_RELU:
+#pragma unroll
+          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m][c], PG_ACT_RELU);
+          break;
+        case PG_ACT_ELU:
+#pragma unroll
+          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m][c], PG_ACT_ELU);
+          break;
+        case PG_ACT_GELU:
+#pragma unroll
+          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m][c], PG_ACT_GELU);
+          break;
+        case PG_ACT_ELU_OUT:
+#pragma unroll
+          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m][c], PG_ACT_ELU_OUT);
+          break;
+        default:
+#pragma unroll
+          for (int c = 0; c < 16; ++c) v[c] += ov[m][c];
+          break;
+      }
+      PG_MF_TILE_STORE(m)
+    }
+  } else {
+    const float* resp = has_res ? a.res + so : outp;   // dummy: readable, value discarded
+    const float* dsp = has_ds ? a.dact_src + so : outp;
+    float rv[16], sv[16];
 #define PG_MF_PRELOAD(M)                                                       \
   _Pragma("unroll") for (int c = 0; c < 16; ++c) {                             \
     const int cc = (M) * 16 + c;                                               \
     const size_t o = (size_t)(cc < cvalid ? cc : 0) * L;                       \
-    rv[c] = resp ? resp[o] : 0.f;                                              \
-    sv[c] = dsp ? dsp[o] : 0.f;                                                \
+    rv[c] = resp[o];                                                           \
+    sv[c] = dsp[o];                                                            \
   }
-  PG_MF_PRELOAD(0)
+    PG_MF_PRELOAD(0)
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MT; ++m) {
+      PG_MF_TILE_BODY(m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+      for (int c = 0; c < 16; ++c) v[c] += has_res ? rv[c] : 0.f;
+      switch (has_ds ? a.dact : PG_ACT_NONE) {
+        case PG_ACT_RELU:
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ep[(kb * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[m][n][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    float v[16];
+          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_RELU);
+          break;
+        case PG_ACT_ELU:
 #pragma unroll
-    for (int c = 0; c < 16; ++c) v[c] = ep[c * EPS + lane] + bl[m * 16 + c];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    switch (a.out_act) {  // wave-uniform
-      case PG_ACT_RELU:
+          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU);
+          break;
+        case PG_ACT_GELU:
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_RELU);
-        break;
-      case PG_ACT_ELU:
+          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
+          break;
+        case PG_ACT_ELU_OUT:
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_ELU);
-        break;
-      case PG_ACT_GELU:
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_GELU);
-        break;
-      default: break;
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) v[c] += rv[c];
-    switch (a.dact) {
-      case PG_ACT_RELU:
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_RELU);
-        break;
-      case PG_ACT_ELU:
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU);
-        break;
-      case PG_ACT_GELU:
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
-        break;
-      case PG_ACT_ELU_OUT:
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU_OUT);
-        break;
-      default: break;
-    }
-    if (m + 1 < MT) { PG_MF_PRELOAD(m + 1) }
-    if (sok) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int cc = m * 16 + c;
-        if (cc < cvalid) outp[(size_t)cc * L] = v[c];
+          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU_OUT);
+          break;
+        default: break;
       }
+      if (m + 1 < MT) { PG_MF_PRELOAD(m + 1) }
+      PG_MF_TILE_STORE(m)
     }
-  }
 #undef PG_MF_PRELOAD
+  }
+#undef PG_MF_TILE_BODY
+#undef PG_MF_TILE_STORE
 }
 
 // ---- A-fragment weight pack ----------------------------------------------------------------
@@ -361,13 +423,24 @@ __global__ void pack_frag_kernel(const FragPackArgs p) {
 inline int mf_mt(int M) { return M >= MF_CO_CHUNK ? 4 : (M + 15) / 16; }
 inline int mf_chunks(int M) { return (M + MF_CO_CHUNK - 1) / MF_CO_CHUNK; }
 
+template <int MT, int NT>
+void mf_launch_one(const MfArgs& a, dim3 grid, size_t shmem, hipStream_t st) {
+  static bool big_lds = false;  // benign race: the attribute call is idempotent
+  if (shmem > 64 * 1024 && !big_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<MT, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    big_lds = true;
+  }
+  hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(MF_THREADS), shmem, st, a);
+}
+
 template <int MT>
 int mf_launch(const MfArgs& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
   switch (nt) {
-    case 1: hipLaunchKernelGGL((conv_mfma_kernel<MT, 1>), grid, dim3(MF_THREADS), shmem, st, a); break;
-    case 2: hipLaunchKernelGGL((conv_mfma_kernel<MT, 2>), grid, dim3(MF_THREADS), shmem, st, a); break;
-    case 3: hipLaunchKernelGGL((conv_mfma_kernel<MT, 3>), grid, dim3(MF_THREADS), shmem, st, a); break;
-    default: hipLaunchKernelGGL((conv_mfma_kernel<MT, 4>), grid, dim3(MF_THREADS), shmem, st, a); break;
+    case 1: mf_launch_one<MT, 1>(a, grid, shmem, st); break;
+    case 2: mf_launch_one<MT, 2>(a, grid, shmem, st); break;
+    case 3: mf_launch_one<MT, 3>(a, grid, shmem, st); break;
+    default: mf_launch_one<MT, 4>(a, grid, shmem, st); break;
   }
   return 0;
 }
@@ -492,8 +565,9 @@ PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* b
              "pg_conv2d_mfma: input rows must be 16-byte aligned (IW %% 4 == 0)");
   const int MT = mf_mt(Cout);
   a.KQ = ((Cin + 3) / 4) * T;
-  // channel chunk: x tile + weight fragments + offset table within ~40 KB (4 workgroups per CU)
-  const long budget = 40 * 1024 / 4;
+  // channel chunk: x tile + weight fragments of ONE buffer within ~36 KB (two buffers per workgroup,
+  // two workgroups per CU)
+  const long budget = 36 * 1024 / 4;
   const long per_ci = a.ch_stride + (long)T * MT * 16;
   long CIB = (budget - 16) / per_ci;
   CIB = (CIB / 4) * 4;
@@ -511,12 +585,13 @@ PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* b
   const long x_floats = CIB * a.ch_stride;
   a.dump = (int)x_floats;
   a.w_off = (int)(((x_floats + 4 + 3) / 4) * 4);
-  size_t shmem = ((size_t)a.w_off + (size_t)(CIB / 4) * T * MT * 64) * sizeof(float);
+  a.buf_stride = (int)(((size_t)a.w_off + (size_t)(CIB / 4) * T * MT * 64 + 3) / 4 * 4);
+  size_t shmem = (size_t)2 * a.buf_stride * sizeof(float);
   if (shmem < (size_t)4 * 16 * 68 * sizeof(float)) shmem = (size_t)4 * 16 * 68 * sizeof(float);
   a.b_off = (int)(shmem / sizeof(float));
   shmem += MF_CO_CHUNK * sizeof(float);
-  PG_REQUIRE(shmem <= 64 * 1024, PG_ESHAPE,
-             "pg_conv2d_mfma: tile %dx%d x %d taps needs %zu B of LDS (> 64 KB)", a.tile_h, a.tile_w,
+  PG_REQUIRE(shmem <= 80 * 1024, PG_ESHAPE,
+             "pg_conv2d_mfma: tile %dx%d x %d taps needs %zu B of LDS (> 80 KB)", a.tile_h, a.tile_w,
              T, shmem);
   for (int t = 0; t < T; ++t) a.tapoff[t] = (tap_dr[t] - min_dr) * a.tile_w + (tap_dc[t] - min_dc);
   const int npx_max = a.NI * a.TR * OW;

@@ -27,6 +27,7 @@ def timeit(fn, iters=20):
     return (time.perf_counter() - t0) / iters * 1e6
 
 CASES = [
+    ("big snail 2x2 64->64 N512", lambda: pg_nn.Conv2d(64, 64, 2, padding=1), (512, 64, 32, 32), dict(crop=(32, 32), in_act="elu")),
     # name, ctor, input shape, forward kwargs
     ("snail 2x2 64->64", lambda: pg_nn.Conv2d(64, 64, 2, padding=1), (128, 64, 32, 32), dict(crop=(32, 32), in_act="elu")),
     ("snail 2x2 64->128", lambda: pg_nn.Conv2d(64, 128, 2, padding=1), (128, 64, 32, 32), dict(crop=(32, 32), in_act="elu")),
