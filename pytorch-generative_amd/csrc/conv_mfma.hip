@@ -50,69 +50,83 @@ struct MfArgs {
   int tapoff[PG_MAX_TAPS];
 };
 
-constexpr int XS = 6;  // float4 staging slots per thread per channel chunk (x tile)
-constexpr int WS = 6;  // float4 slots per thread per channel chunk (weight fragments)
+constexpr int XS = 5;  // float4 staging slots per thread per channel chunk (x tile)
+constexpr int WS = 4;  // float4 slots per thread per channel chunk (weight fragments)
 
 template <int MT, int NT>
 __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = blockIdx.x / a.tiles_per_grp;  // image group
-  const int row0 = (blockIdx.x - grp * a.tiles_per_grp) * a.TR;
-  const int n0 = grp * a.NI;
-  const int ni = min(a.NI, a.N - n0);
+  // PERSISTENT workgroups: gridDim.x is a multiple of the row tiles per image group, so a workgroup
+  // keeps ONE row-tile index and walks the image groups g = g0, g0 + gstep, ...: the staging-slot
+  // geometry is computed once, and the (tile, channel chunk) steps form one software pipeline — the
+  // loads of step s+1 (possibly the next tile's first chunk) fly under the MFMA loop of step s, the
+  // epilogue's stores under the next tile's work. (One tile per workgroup measured 47 % MFMA busy:
+  // every tile paid dispatch + set-up + a cold first load + the store tail, ~20 us per generation.)
+  const int rt = blockIdx.x % a.tiles_per_grp;
+  const int g0 = blockIdx.x / a.tiles_per_grp, gstep = gridDim.x / a.tiles_per_grp;
+  const int row0 = rt * a.TR;
   const int rows = min(a.TR, a.OH - row0);  // NI > 1 implies TR == OH
-  const int npx = ni * rows * a.OW;
   const int co0 = blockIdx.y * MF_CO_CHUNK;
   const int L = a.OH * a.OW;
   const int plane = a.IH * a.IW;
+  const int ngroups = (a.N + a.NI - 1) / a.NI;
+  const int nchunk = (a.Cin + a.CIB - 1) / a.CIB;
+  const int ntiles = g0 < ngroups ? (ngroups - g0 + gstep - 1) / gstep : 0;
+  const int nsteps = ntiles * nchunk;
+  if (nsteps == 0) return;
 
-
-  // lane's pixel of each of its 16-pixel groups: LDS offset, validity
+  // lane's pixel of each of its 16-pixel groups (MFMA phase) and of the store phase
   int pixoff[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int p = (wave * NT + n) * 16 + (lane & 15);
-    const int pc = p < npx ? p : 0;
+    const int pc = p < a.NI * rows * a.OW ? p : 0;
     const int q = pc / a.OW;
     const int c = pc - q * a.OW;
     const int img = q / rows;
     const int r = q - img * rows;
     pixoff[n] = img * a.img_stride + r * a.tile_w + c;
   }
-
-  // ---- staging slots (float4 path): this thread's share of a channel chunk's x tile is the same
-  // set of (image, channel-in-chunk, tile row, quad) elements for every chunk, so global offset, LDS
-  // offset and validity are computed once; per chunk the thread issues its loads BEFORE the MFMA
-  // loop of the previous chunk and commits them to LDS after it (global latency hidden).
-  int s_goff[XS], s_meta[XS];  // meta: (LDS offset + 4) | element mask << 16 | channel-in-chunk << 20
-  int s_base = 0;              // bit k: slot k exists (in-range row of an existing image)
+  const int pw = wave * (NT * 16) + lane;  // this lane's pixel in the store phase
+  size_t so_rel;
   {
+    const int pc = (lane < NT * 16 && pw < a.NI * rows * a.OW) ? pw : 0;
+    const int q = pc / a.OW;
+    const int c = pc - q * a.OW;
+    const int img = q / rows;
+    const int r = q - img * rows;
+    so_rel = ((size_t)img * a.Cout + co0) * L + (size_t)((row0 + r) * a.OW + c);
+  }
+
+  // ---- staging slots: this thread's float4 share of a chunk's x tile is the same set of (image,
+  // channel-in-chunk, tile row, quad) elements for every step
+  int s_goff[XS], s_meta[XS];  // meta: (LDS offset + 4) | element mask << 16 | channel << 20 | image << 28
+  int s_base = 0;              // bit k: slot k exists (in-range row)
 #pragma unroll
-    for (int k = 0; k < XS; ++k) {
-      int e = tid + k * MF_THREADS;
-      const bool in = e < a.xslots;
-      e = in ? e : 0;
-      const int q = e % a.Q;
-      e /= a.Q;
-      const int tr = e % a.tile_h;
-      e /= a.tile_h;
-      const int ch = e % a.CIB;
-      const int img = e / a.CIB;
-      const int ir = row0 + a.min_dr + tr;
-      const bool ok = in && img < ni && ir >= 0 && ir < a.IH;
-      const int irc = ir < 0 ? 0 : (ir >= a.IH ? a.IH - 1 : ir);
-      s_goff[k] = (img * a.Cin + ch) * plane + irc * a.IW + 4 * q;
-      const int tcol = 4 * q - a.min_dc;
-      const int loff = img * a.img_stride + ch * a.ch_stride + tr * a.tile_w + tcol;
-      int mask = 0;
+  for (int k = 0; k < XS; ++k) {
+    int e = tid + k * MF_THREADS;
+    const bool in = e < a.xslots;
+    e = in ? e : 0;
+    const int q = e % a.Q;
+    e /= a.Q;
+    const int tr = e % a.tile_h;
+    e /= a.tile_h;
+    const int ch = e % a.CIB;
+    const int img = e / a.CIB;
+    const int ir = row0 + a.min_dr + tr;
+    const bool ok = in && ir >= 0 && ir < a.IH;
+    const int irc = ir < 0 ? 0 : (ir >= a.IH ? a.IH - 1 : ir);
+    s_goff[k] = (img * a.Cin + ch) * plane + irc * a.IW + 4 * q;
+    const int tcol = 4 * q - a.min_dc;
+    const int loff = img * a.img_stride + ch * a.ch_stride + tr * a.tile_w + tcol;
+    int mask = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (tcol + i >= 0 && tcol + i < a.tile_w) mask |= 1 << i;
-      s_meta[k] = ((loff + 4) & 0xffff) | (mask << 16) | (ch << 20);  // tcol >= -3: loff + 4 > 0
-      if (ok) s_base |= 1 << k;
-    }
+    for (int i = 0; i < 4; ++i)
+      if (tcol + i >= 0 && tcol + i < a.tile_w) mask |= 1 << i;
+    s_meta[k] = ((loff + 4) & 0xffff) | (mask << 16) | (ch << 20) | (img << 28);  // tcol >= -3: loff + 4 > 0
+    if (ok) s_base |= 1 << k;
   }
 
   f32x4 acc[MT][NT];
@@ -121,8 +135,9 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // zero the tile once: the float4 staging writes in-range elements only (the halo stays zero), and
-  // the channels that pad the last group of 4 must hold finite values (their weights are zero)
+  // zero both tiles once: the float4 staging writes in-range elements only (the halo stays zero —
+  // the in-range set is the same for every step of this workgroup), and the channels that pad the
+  // last group of 4 must hold finite values (their weights are zero)
   for (int i = tid; i < a.CIB * a.ch_stride; i += MF_THREADS) {
     lds[i] = 0.f;
     lds[a.buf_stride + i] = 0.f;
@@ -132,47 +147,55 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
     lds[a.b_off + tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
   }
 
-  const float* in_b = a.in + (size_t)n0 * a.Cin * plane;
   const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag + (size_t)blockIdx.y * a.KQ * (MT * 64));
   float4 xv[XS], wv[WS];
 #pragma unroll
   for (int k = 0; k < XS; ++k) xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < WS; ++k) wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  int xok = 0;  // slots loaded for the chunk in flight
+  int xok = 0;  // slots loaded for the step in flight
 
-#define PG_MF_ISSUE(CI0)                                                                  \
+  // step -> (tile, chunk): loads of the step's x slots and weight fragments into registers
+#define PG_MF_ISSUE(STEP)                                                                 \
   {                                                                                       \
-    const int cib_ = min(a.CIB, a.Cin - (CI0));                                           \
+    const int tl_ = (STEP) / nchunk;                                                      \
+    const int ci0_ = ((STEP) - tl_ * nchunk) * a.CIB;                                     \
+    const int n0_ = (g0 + tl_ * gstep) * a.NI;                                            \
+    const int ni_ = min(a.NI, a.N - n0_);                                                 \
+    const int cib_ = min(a.CIB, a.Cin - ci0_);                                            \
     const int nw4_ = ((cib_ + 3) >> 2) * a.T * MT * 16;                                   \
-    const float4* ws_ = wsrc_b + (size_t)((CI0) >> 2) * a.T * (MT * 16);                  \
+    const float4* ws_ = wsrc_b + (size_t)(ci0_ >> 2) * a.T * (MT * 16);                   \
     _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                      \
       const int i = tid + k * MF_THREADS;                                                 \
       if (i < nw4_) wv[k] = ws_[i];                                                       \
     }                                                                                     \
     xok = 0;                                                                              \
-    const float* src_ = in_b + (size_t)(CI0) * plane;                                     \
+    const float* src_ = a.in + ((size_t)n0_ * a.Cin + ci0_) * plane;                      \
     _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                      \
-      const bool ok = ((s_base >> k) & 1) && (s_meta[k] >> 20) < cib_;                    \
+      const bool ok = ((s_base >> k) & 1) && ((s_meta[k] >> 20) & 0xff) < cib_ &&         \
+                      ((s_meta[k] >> 28) & 0xf) < ni_;                                    \
       if (ok) {                                                                           \
         xv[k] = *reinterpret_cast<const float4*>(src_ + s_goff[k]);                       \
         xok |= 1 << k;                                                                    \
       }                                                                                   \
     }                                                                                     \
   }
-
+  // (the empty asm makes the slot word opaque per use: otherwise the compiler hoists the 2 x 24 LDS
+  //  addresses and their predicates out of the step loop and the kernel spills)
 #define PG_MF_COMMIT(ACT, XL)                                               \
   _Pragma("unroll") for (int k = 0; k < XS; ++k) {                          \
     const bool ok = (xok >> k) & 1;                                         \
-    const int loff = (s_meta[k] & 0xffff) - 4;                              \
+    int meta_ = s_meta[k];                                                  \
+    asm volatile("" : "+v"(meta_));                                         \
+    const int loff = (meta_ & 0xffff) - 4;                                  \
     const float e[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                         \
-      const bool oki = ok && ((s_meta[k] >> (16 + i)) & 1);                 \
+      const bool oki = ok && ((meta_ >> (16 + i)) & 1);                     \
       (XL)[oki ? loff + i : a.dump] = pg_apply_act(e[i], ACT);              \
     }                                                                       \
   }
-  // writes the chunk in flight (x slots with the prologue activation, weight fragments) into buffer BUF
-#define PG_MF_COMMIT_ALL(BUF, CI0)                                                       \
+  // writes the step in flight (x slots with the prologue activation, weight fragments) into buffer BUF
+#define PG_MF_COMMIT_ALL(BUF, STEP)                                                      \
   {                                                                                      \
     float* xl_ = lds + (BUF) * a.buf_stride;                                             \
     switch (a.in_act) { /* wave-uniform */                                               \
@@ -181,7 +204,8 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
       case PG_ACT_GELU: PG_MF_COMMIT(PG_ACT_GELU, xl_) break;                            \
       default:          PG_MF_COMMIT(PG_ACT_NONE, xl_) break;                            \
     }                                                                                    \
-    const int nw4_ = ((min(a.CIB, a.Cin - (CI0)) + 3) >> 2) * a.T * MT * 16;             \
+    const int ci0_ = ((STEP) % nchunk) * a.CIB;                                          \
+    const int nw4_ = ((min(a.CIB, a.Cin - ci0_) + 3) >> 2) * a.T * MT * 16;              \
     float4* wdst_ = reinterpret_cast<float4*>(xl_ + a.w_off);                            \
     _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                     \
       const int i = tid + k * MF_THREADS;                                                \
@@ -189,19 +213,23 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
     }                                                                                    \
   }
 
-  // Two LDS buffers: while the waves run the MFMA loop of chunk c out of one, each wave that finishes
-  // commits chunk c+1 (its loads were issued before the loop) into the other — ONE barrier per chunk.
+  // Two LDS buffers: while the waves run the MFMA loop of step s out of one, each wave that finishes
+  // commits step s+1 (its loads were issued before the loop) into the other — one barrier per step.
   PG_MF_ISSUE(0)
   PG_MF_COMMIT_ALL(0, 0)
   __syncthreads();
   const int kb = lane >> 4;
   const int gstride = 4 * a.ch_stride;
+  constexpr int EPS = 68;
+  const float* bl = lds + a.b_off;  // this chunk's bias values
   int cur = 0;
-  for (int ci0 = 0; ci0 < a.Cin; ci0 += a.CIB) {
+  for (int step = 0; step < nsteps; ++step) {
+    const int tl = step / nchunk;
+    const int ci0 = (step - tl * nchunk) * a.CIB;
     const int cib = min(a.CIB, a.Cin - ci0);
     const int ng = (cib + 3) >> 2;  // channel groups of this chunk
-    const bool more = ci0 + a.CIB < a.Cin;
-    if (more) PG_MF_ISSUE(ci0 + a.CIB)  // prefetch: lands under the MFMA loop
+    const bool more = step + 1 < nsteps;
+    if (more) PG_MF_ISSUE(step + 1)  // prefetch: lands under the MFMA loop
     const float* xl = lds + cur * a.buf_stride;
     const float* wl = xl + a.w_off;
     for (int t = 0; t < a.T; ++t) {
@@ -224,45 +252,30 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
       }
     }
-    if (more) {
-      PG_MF_COMMIT_ALL(cur ^ 1, ci0 + a.CIB)
-      __syncthreads();
-    }
-    cur ^= 1;
-  }
-#undef PG_MF_COMMIT
-#undef PG_MF_COMMIT_ALL
-#undef PG_MF_ISSUE
-
-  // ---- epilogue: + bias, out_act, + res, * act'(dact_src) (data gradient of a fused input activation).
-  // The accumulator layout (lane = 4 channels x 1 pixel) would store 64-byte segments; each wave
-  // transposes one 16-channel tile at a time through its own LDS scratch ([16 co][64 px], row stride
-  // 68: conflict-free both ways) so that a store instruction covers 64 consecutive pixels (256 B) of
-  // one channel plane. (Measured: 64-byte-segment stores cost 23-40 us of an 82 us launch.)
-  __syncthreads();  // all waves are done with the x / weight tiles
-  constexpr int EPS = 68;
-  float* ep = lds + wave * (16 * EPS);
-  const float* bl = lds + a.b_off;          // this chunk's bias values (staged at kernel start)
-  const int pw = wave * (NT * 16) + lane;   // this lane's pixel in the store phase
-  const bool sok = (lane < NT * 16) && pw < npx;
-  size_t so;
-  {
-    const int pc = sok ? pw : 0;
-    const int q = pc / a.OW;
-    const int c = pc - q * a.OW;
-    const int img = q / rows;
-    const int r = q - img * rows;
-    so = ((size_t)(n0 + img) * a.Cout + co0) * L + (size_t)((row0 + r) * a.OW + c);
-  }
-  // One 16-channel tile at a time. Loads and stores share vmcnt and retire in order, so a load that
-  // follows a store drains it (measured: a conditional residual load between the tiles cost a full
-  // store round trip per tile — 20 us of an 80 us launch). Hence two code paths: without residual /
-  // act' operands the epilogue issues NO loads at all; with them, the operands of tile m+1 are
-  // requested unconditionally (absent ones from a valid dummy address, discarded by a select)
-  // BEFORE the stores of tile m, so that waiting for them never waits for a store.
-  const int cvalid = a.Cout - co0;  // channels of this chunk that exist (>= 1)
-  float* outp = a.out + so;
-  const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
+    if (more) PG_MF_COMMIT_ALL(cur ^ 1, step + 1)
+    const bool last_chunk = ci0 + a.CIB >= a.Cin;
+    if (more || last_chunk) __syncthreads();
+    if (last_chunk) {
+      // ---- epilogue of this tile: + bias, out_act, + res, * act'(dact_src). Buffer `cur` is free now
+      // (every wave passed the barrier) and serves as transposition scratch: the accumulator layout
+      // (lane = 4 channels x 1 pixel) would store 64-byte segments; each wave transposes one
+      // 16-channel tile at a time ([16 co][64 px], row stride 68: conflict-free both ways) so that
+      // a store instruction covers 64 consecutive pixels (256 B) of one channel plane.
+      const int n0 = (g0 + tl * gstep) * a.NI;
+      const int npx = min(a.NI, a.N - n0) * rows * a.OW;
+      const bool sok = (lane < NT * 16) && pw < npx;
+      const size_t so = so_rel + (size_t)n0 * a.Cout * L;
+      // (scratch = the buffer's WEIGHT area, which every commit rewrites completely; the x tile's
+      //  zero halo must survive)
+      float* ep = lds + cur * a.buf_stride + a.w_off + wave * (16 * EPS);
+      // Loads and stores share vmcnt and retire in order, so a load that follows a store drains it
+      // (measured: a conditional residual load between the tiles cost a store round trip per tile).
+      // Hence: without residual / act' operands the epilogue issues NO loads; with exactly one
+      // (a forward residual, or the act' source of a data gradient — the combinations the model
+      // code produces) ALL of its values are requested up front.
+      const int cvalid = a.Cout - co0;  // channels of this chunk that exist (>= 1)
+      float* outp = a.out + so;
+      const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
 #define PG_MF_TILE_BODY(M)                                                                       \
   _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
   _Pragma("unroll") for (int r = 0; r < 4; ++r) ep[(kb * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[M][n][r]; \
@@ -283,96 +296,83 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
       if (cc < cvalid) outp[(size_t)cc * L] = v[c];                           \
     }                                                                         \
   }
-  if (!has_res && !has_ds) {
+      if (!has_res && !has_ds) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      PG_MF_TILE_BODY(m)
-      PG_MF_TILE_STORE(m)
-    }
-  } else if (has_res != has_ds) {
-    // exactly one extra operand (a forward residual, or the act' source of a data gradient — the
-    // only combinations the model code produces): ALL of its values are requested up front, then
-    // the tiles are transposed and stored with no load in between
-    const float* opp = has_res ? a.res + so : a.dact_src + so;
-    float ov[MT][16];
+        for (int m = 0; m < MT; ++m) {
+          PG_MF_TILE_BODY(m)
+          PG_MF_TILE_STORE(m)
+        }
+      } else {
+        // ov: every value of the (first) extra operand, requested before any store of this tile
+        const float* op1 = (has_res ? a.res : a.dact_src) + so;
+        const float* op2 = (has_res && has_ds) ? a.dact_src + so : nullptr;  // both: second one per tile
+        // (two tiles' worth at a time: 32 registers; one load batch follows stores per pair)
+        constexpr int MH = MT > 2 ? 2 : MT;
+        float ov[MH][16];
+        const int dsel = has_ds ? a.dact : PG_ACT_NONE;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+          if (m % MH == 0) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int cc = m * 16 + c;
-        ov[m][c] = opp[(size_t)(cc < cvalid ? cc : 0) * L];
+            for (int mm = 0; mm < MH; ++mm)
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                const int cc = (m + mm) * 16 + c;
+                ov[mm][c] = op1[(size_t)(cc < cvalid ? cc : 0) * L];
+              }
+          }
+          PG_MF_TILE_BODY(m)
+          float sv[16];
+          if (has_res) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] += ov[m % MH][c];
+            if (op2) {
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                const int cc = m * 16 + c;
+                sv[c] = op2[(size_t)(cc < cvalid ? cc : 0) * L];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sv[c] = ov[m % MH][c];
+          }
+          switch (dsel) {
+            case PG_ACT_RELU:
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_RELU);
+              break;
+            case PG_ACT_ELU:
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU);
+              break;
+            case PG_ACT_GELU:
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
+              break;
+            case PG_ACT_ELU_OUT:
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU_OUT);
+              break;
+            default: break;
+          }
+          PG_MF_TILE_STORE(m)
+        }
       }
-    const int dsel = has_ds ? a.dact : PG_ACT_NONE;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      PG_MF_TILE_BODY(m)
-      switch (dsel) {
-        case PG_ACT_RELU:
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m][c], PG_ACT_RELU);
-          break;
-        case PG_ACT_ELU:
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m][c], PG_ACT_ELU);
-          break;
-        case PG_ACT_GELU:
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m][c], PG_ACT_GELU);
-          break;
-        case PG_ACT_ELU_OUT:
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m][c], PG_ACT_ELU_OUT);
-          break;
-        default:
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] += ov[m][c];
-          break;
-      }
-      PG_MF_TILE_STORE(m)
-    }
-  } else {
-    const float* resp = has_res ? a.res + so : outp;   // dummy: readable, value discarded
-    const float* dsp = has_ds ? a.dact_src + so : outp;
-    float rv[16], sv[16];
-#define PG_MF_PRELOAD(M)                                                       \
-  _Pragma("unroll") for (int c = 0; c < 16; ++c) {                             \
-    const int cc = (M) * 16 + c;                                               \
-    const size_t o = (size_t)(cc < cvalid ? cc : 0) * L;                       \
-    rv[c] = resp[o];                                                           \
-    sv[c] = dsp[o];                                                            \
-  }
-    PG_MF_PRELOAD(0)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      PG_MF_TILE_BODY(m)
-#pragma unroll
-      for (int c = 0; c < 16; ++c) v[c] += has_res ? rv[c] : 0.f;
-      switch (has_ds ? a.dact : PG_ACT_NONE) {
-        case PG_ACT_RELU:
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_RELU);
-          break;
-        case PG_ACT_ELU:
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU);
-          break;
-        case PG_ACT_GELU:
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
-          break;
-        case PG_ACT_ELU_OUT:
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU_OUT);
-          break;
-        default: break;
-      }
-      if (m + 1 < MT) { PG_MF_PRELOAD(m + 1) }
-      PG_MF_TILE_STORE(m)
-    }
-#undef PG_MF_PRELOAD
-  }
 #undef PG_MF_TILE_BODY
 #undef PG_MF_TILE_STORE
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // the scratch buffer receives the commit of step s+2: nobody may still be transposing in it
+      if (more) __syncthreads();
+    }
+    cur ^= 1;
+  }
+#undef PG_MF_ISSUE
+#undef PG_MF_COMMIT
+#undef PG_MF_COMMIT_ALL
 }
 
 // ---- A-fragment weight pack ----------------------------------------------------------------
@@ -580,23 +580,35 @@ PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* b
   PG_REQUIRE((CIB / 4) * (long)T * MT * 16 <= (long)WS * MF_THREADS &&
                  (long)a.NI * CIB * a.tile_h * a.Q <= (long)XS * MF_THREADS,
              PG_ESHAPE, "pg_conv2d_mfma: %d taps x %d-row tile exceeds the staging slots", T, a.tile_h);
-  a.CIB = (int)CIB;
-  a.xslots = a.NI * a.CIB * a.tile_h * a.Q;
-  const long x_floats = CIB * a.ch_stride;
-  a.dump = (int)x_floats;
-  a.w_off = (int)(((x_floats + 4 + 3) / 4) * 4);
-  a.buf_stride = (int)(((size_t)a.w_off + (size_t)(CIB / 4) * T * MT * 64 + 3) / 4 * 4);
-  size_t shmem = (size_t)2 * a.buf_stride * sizeof(float);
-  if (shmem < (size_t)4 * 16 * 68 * sizeof(float)) shmem = (size_t)4 * 16 * 68 * sizeof(float);
-  a.b_off = (int)(shmem / sizeof(float));
-  shmem += MF_CO_CHUNK * sizeof(float);
+  size_t shmem = 0;
+  for (;;) {  // the scratch floor of the weight area can push a buffer over its budget: shrink the chunk
+    a.CIB = (int)CIB;
+    a.xslots = a.NI * a.CIB * a.tile_h * a.Q;
+    const long x_floats = CIB * a.ch_stride;
+    a.dump = (int)x_floats;
+    a.w_off = (int)(((x_floats + 4 + 3) / 4) * 4);
+    size_t w_area = (size_t)(CIB / 4) * T * MT * 64;
+    if (w_area < (size_t)4 * 16 * 68) w_area = (size_t)4 * 16 * 68;  // doubles as the epilogue's transposition scratch
+    a.buf_stride = (int)(((size_t)a.w_off + w_area + 3) / 4 * 4);
+    shmem = (size_t)2 * a.buf_stride * sizeof(float);
+    a.b_off = (int)(shmem / sizeof(float));
+    shmem += MF_CO_CHUNK * sizeof(float);
+    if (shmem <= 80 * 1024 || CIB <= 4) break;
+    CIB -= 4;
+  }
   PG_REQUIRE(shmem <= 80 * 1024, PG_ESHAPE,
              "pg_conv2d_mfma: tile %dx%d x %d taps needs %zu B of LDS (> 80 KB)", a.tile_h, a.tile_w,
              T, shmem);
   for (int t = 0; t < T; ++t) a.tapoff[t] = (tap_dr[t] - min_dr) * a.tile_w + (tap_dc[t] - min_dc);
   const int npx_max = a.NI * a.TR * OW;
   const int nt = (npx_max + 63) / 64;  // 16-pixel groups per wave
-  dim3 grid((unsigned)(groups * a.tiles_per_grp), (unsigned)mf_chunks(Cout));
+  // persistent workgroups: ~2 per CU in total, a multiple of the row tiles per image group
+  const int chunks_y = mf_chunks(Cout);
+  long want = 512 / chunks_y;
+  if (want < a.tiles_per_grp) want = a.tiles_per_grp;
+  long gx = (want / a.tiles_per_grp) * a.tiles_per_grp;
+  if (gx > (long)groups * a.tiles_per_grp) gx = (long)groups * a.tiles_per_grp;
+  dim3 grid((unsigned)gx, (unsigned)chunks_y);
   switch (MT) {
     case 1: mf_launch<1>(a, nt, grid, shmem, st); break;
     case 2: mf_launch<2>(a, nt, grid, shmem, st); break;
