@@ -275,14 +275,15 @@ def conv_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
     wt = (torch.randn(cout, cin, 2, 2, generator=g) * 0.05).to(device)
     bias = torch.zeros(cout, device=device)
     out = torch.empty(batch, cout, hw, hw, device=device)
-    wfrag = ops._pack_frag(lib, wt, spec, transpose=False)
+    fmt = ops._use_mfma(lib, cin, cout, spec, (hw, hw), hw)
+    wfrag = ops._pack_frag(lib, wt, spec, False, fmt)
     stream = torch.cuda.current_stream()
     T = len(spec.fwd_taps)
 
     def run():
         _lib.check(lib.pg_conv2d_mfma(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), 0, out.data_ptr(),
                                       batch, cin, hw, hw, cout, hw, hw, T, spec.f_dr, spec.f_dc,
-                                      ops.ACT_ELU, 0, ops.ACT_NONE, ops.ACT_NONE, stream.cuda_stream),
+                                      ops.ACT_ELU, 0, ops.ACT_NONE, ops.ACT_NONE, fmt, stream.cuda_stream),
                    "pg_conv2d_mfma")
 
     ms = _event_time(run, stream)

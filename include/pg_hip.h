@@ -91,23 +91,30 @@ int pg_conv_b_pad(int b);
 int pg_conv2d_mfma(const float* in, const float* wfrag, const float* bias, const float* res,
                    float* out, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
                    const int* tap_dr, const int* tap_dc, int in_act, const float* dact_src,
-                   int dact, int out_act, void* stream);
-/* 1 if pg_conv2d_mfma takes a (Cin -> Cout, T taps, OH x OW outputs, input rows of IW) problem */
-int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, int IW);
+                   int dact, int out_act, int fmt, void* stream);
+/* Two arithmetic back ends share this entry point; they differ in the weight-fragment FORMAT:
+ *   PG_CONV_FMT_F32: v_mfma_f32_16x16x4_f32 on fp32 fragments (csrc/conv_mfma.hip);
+ *   PG_CONV_FMT_B3:  every fp32 product as six v_mfma_f32_16x16x32_bf16 on exact three-way bf16
+ *                    splits of both operands (csrc/conv_b3.hip; fp32-level accuracy, ~2.5x the rate).
+ * pg_conv_mfma_supported returns the format to use for a (Cin -> Cout, T taps, OH x OW outputs,
+ * input rows of IW, tap-list extent hr x hc) problem, or 0 (call pg_conv2d_taps instead). */
+#define PG_CONV_FMT_F32 1
+#define PG_CONV_FMT_B3 2
+int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, int IW, int hr, int hc);
 /* floats pg_pack_conv_weight_frag writes for K_channels contracted into M_channels over T taps */
-size_t pg_conv_frag_floats(int K_channels, int M_channels, int T);
+size_t pg_conv_frag_floats(int K_channels, int M_channels, int T, int fmt);
 /* wfrag[chunk][g*T + t][m][lane] = Wsel[64 chunk + 16 m + (lane & 15)][4 g + (lane >> 4)][t], with
  *   transpose==0: Wsel[o][c][t] = w[o][c][tap_u[t]][tap_v[t]]  (M = Cout, K channels = Cin)
  *   transpose==1: Wsel[o][c][t] = w[c][o][tap_u[t]][tap_v[t]]  (M = Cin,  K channels = Cout)
  * zero filled outside; w is the torch layout (Cout, Cin, KH, KW). */
 int pg_pack_conv_weight_frag(const float* w, float* wfrag, int Cout, int Cin, int KH, int KW,
-                             int T, const int* tap_u, const int* tap_v, int transpose,
+                             int T, const int* tap_u, const int* tap_v, int transpose, int fmt,
                              void* stream);
 /* both orientations of one weight in ONE launch (either output may be NULL): the forward pass packs
  * the data-gradient fragments it will need in backward at the same time */
 int pg_pack_conv_weight_frag2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout,
                               int Cin, int KH, int KW, int T, const int* tap_u, const int* tap_v,
-                              void* stream);
+                              int fmt_fwd, int fmt_dgrad, void* stream);
 
 /* Weight + bias gradient (MFMA f32 16x16x4). The result is ADDED to dw/db (the caller zeroes
  * them once per step); per-workgroup partial sums go through `workspace` and a second,

@@ -1,0 +1,558 @@
+// conv_b3.hip — the implicit-GEMM convolution of conv_mfma.hip with its fp32 products evaluated on the
+// bf16 matrix pipe ("bf16x3"): x = xh + xm + xl, w = wh + wm + wl with bf16 pieces (8 + 8 + 8
+// significand bits: the split is exact to 2^-24 |x|), and
+//     w.x  =  wh.xh + wh.xm + wm.xh + wh.xl + wl.xh + wm.xm          (6 x v_mfma_f32_16x16x32_bf16)
+// dropping wm.xl + wl.xm + wl.xl <= 3 * 2^-24 |w.x| — the size of one fp32 rounding; every
+// bf16 x bf16 product is exact in the fp32 accumulator. Same reference call sites as conv_mfma.hip
+// (nn/convolution.py:41-43, gated_pixel_cnn.py:63-96, pixel_snail.py:41-55, the 1x1 convolutions and
+// aten::convolution_backward's data gradient); results agree with the fp32-MFMA kernel to ~1e-7.
+//
+// Why: measured on MI355X, v_mfma_f32_16x16x4_f32 costs 33 cycles per 1024 MACs and BLOCKS the VALU
+// of its SIMD, v_mfma_f32_16x16x32_bf16 costs 17.7 cycles per 8192 MACs and co-executes with VALU
+// work: six of them per 16x16x32 tile = 106 cycles against 264 for eight fp32 MFMAs, and the
+// staging arithmetic (activation, splitting) hides under them.
+//
+// GEMM view: M = output channels, N = output pixels; a K step of 32 = four "groups" of 8 input
+// channels at one tap. Lane (i|j = lane & 15, kq = lane >> 4) holds 8 consecutive K values
+// (A: 8 channels of output channel i; B: 8 channels of pixel j) of group 4 ks + kq.
+// LDS: x pieces as planes [channel group of 8][piece][tile pixel] of 16-byte entries, plane stride a
+// multiple of 256 B — a B fragment read (ds_read_b128) of 16 consecutive pixels is conflict free for
+// every tap offset, and a staging lane (= pixel) writes one entry per piece; weights as ready-made A
+// fragments [k step][co tile][piece][lane] (pg_pack_conv_weight_frag*).
+// Workgroups are persistent like conv_mfma's: (tile, channel chunk) steps with the next step's
+// loads in flight under the MFMA loop.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int B3_THREADS = 256;
+constexpr int B3_CO_CHUNK = 64;
+constexpr int B3_XS = 4;       // (pixel, channel-group) staging slots per thread per step: 8 loads each
+constexpr int B3_WS = 6;       // float4 weight-fragment slots per thread per step
+constexpr int B3_MAXG = 20;    // groups per chunk (<= 5 K steps)
+
+struct B3Args {
+  const float* in;
+  const float* wfrag;
+  const float* bias;
+  const float* res;
+  const float* dact_src;
+  float* out;
+  int N, Cin, IH, IW, Cout, OH, OW, T;
+  int TR, tiles_per_img, tile_h, tile_w, min_dr, min_dc;
+  int CIB, cgs, groups, ksteps;   // channels per chunk, CIB / 8, cgs * T, ceil(groups / 4)
+  int plane16;                    // 16-byte entries per (channel group, piece) plane (multiple of 16)
+  int w_off16, b_off, dump16;     // LDS offsets: weights (16-byte units), bias (floats), dump entry
+  int xslots, wslab4;             // staging slots per step; float4 per step's weight slab
+  int in_act, dact, out_act;
+  int g_tapoff[B3_MAXG];          // per group: tap offset in tile pixels
+  int g_cg[B3_MAXG];              // per group: channel group of the chunk
+};
+
+__device__ __forceinline__ unsigned int pack2(__bf16 a, __bf16 b) {
+  return (unsigned int)__builtin_bit_cast(unsigned short, a) |
+         ((unsigned int)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// 8 fp32 -> three bf16x8 (h, m, l pieces)
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
+  __bf16 hh[8], mm[8], ll[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    hh[i] = (__bf16)x[i];
+    const float r1 = x[i] - (float)hh[i];
+    mm[i] = (__bf16)r1;
+    ll[i] = (__bf16)(r1 - (float)mm[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pack2(hh[2 * i], hh[2 * i + 1]);
+    m[i] = pack2(mm[2 * i], mm[2 * i + 1]);
+    l[i] = pack2(ll[2 * i], ll[2 * i + 1]);
+  }
+}
+
+#define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // persistent: one row-tile index per workgroup, images n = n_first, n_first + nstep, ...
+  const int rt = blockIdx.x % a.tiles_per_img;
+  const int n_first = blockIdx.x / a.tiles_per_img, nstep = gridDim.x / a.tiles_per_img;
+  const int row0 = rt * a.TR;
+  const int rows = min(a.TR, a.OH - row0);
+  const int npx = rows * a.OW;
+  const int co0 = blockIdx.y * B3_CO_CHUNK;
+  const int L = a.OH * a.OW;
+  const int plane = a.IH * a.IW;
+  const int nchunk = a.Cin / a.CIB;
+  const int ntiles = n_first < a.N ? (a.N - n_first + nstep - 1) / nstep : 0;
+  const int nsteps = ntiles * nchunk;
+  if (nsteps == 0) return;
+  const int kq = lane >> 4;
+
+  int pixoff[NT];  // tile pixel (16-byte entry index) of this lane's pixel of each 16-pixel group
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int p = (wave * NT + n) * 16 + (lane & 15);
+    const int pc = p < npx ? p : 0;
+    const int r = pc / a.OW;
+    pixoff[n] = r * a.tile_w + (pc - r * a.OW);
+  }
+  const int pw = wave * (NT * 16) + lane;  // store phase: lane = pixel
+  const bool sok = (lane < NT * 16) && pw < npx;
+  size_t so_rel;
+  {
+    const int pc = sok ? pw : 0;
+    const int r = pc / a.OW;
+    so_rel = (size_t)co0 * L + (size_t)((row0 + r) * a.OW + (pc - r * a.OW));
+  }
+  // per group g = 4 ks + kq: where it lives — plane of its channel group + tap offset (LDS table)
+  int* gtab = reinterpret_cast<int*>(lds + a.b_off + B3_CO_CHUNK);
+  if (tid < B3_MAXG) gtab[tid] = tid < a.groups ? a.g_cg[tid] * 3 * a.plane16 + a.g_tapoff[tid] : 0;
+
+  // ---- staging slots: (channel group, tile row, tile column) -> 8 channel loads of one pixel
+  int s_goff[B3_XS], s_loff[B3_XS];  // global offset of channel cg*8 (floats), LDS entry of piece 0; -1: no slot
+#pragma unroll
+  for (int k = 0; k < B3_XS; ++k) {
+    int e = tid + k * B3_THREADS;
+    const bool in = e < a.xslots;
+    e = in ? e : 0;
+    const int tc = e % a.tile_w;
+    e /= a.tile_w;
+    const int tr = e % a.tile_h;
+    const int cg = e / a.tile_h;
+    const int ir = row0 + a.min_dr + tr, ic = a.min_dc + tc;
+    const bool ok = in && ir >= 0 && ir < a.IH && ic >= 0 && ic < a.IW;
+    s_goff[k] = ok ? (cg * 8) * plane + ir * a.IW + ic : -1;
+    s_loff[k] = cg * 3 * a.plane16 + tr * a.tile_w + tc;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // zero the x planes once (halo / out-of-image entries are never written afterwards)
+  for (int i = tid; i < a.cgs * 3 * a.plane16; i += B3_THREADS) lds16[i] = u32x4{0u, 0u, 0u, 0u};
+  if (tid < B3_CO_CHUNK) {
+    const int co = co0 + tid;
+    lds[a.b_off + tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+  }
+
+  const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * a.wslab4;
+  float xv[B3_XS][8];
+  float4 wv[B3_WS];
+#pragma unroll
+  for (int k = 0; k < B3_XS; ++k)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xv[k][c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < B3_WS; ++k) wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define PG_B3_ISSUE(STEP)                                                                  \
+  {                                                                                        \
+    const int tl_ = (STEP) / nchunk;                                                       \
+    const int ch_ = (STEP) - tl_ * nchunk;                                                 \
+    const float4* ws_ = wsrc_b + (size_t)ch_ * a.wslab4;                                   \
+    _Pragma("unroll") for (int k = 0; k < B3_WS; ++k) {                                    \
+      const int i = tid + k * B3_THREADS;                                                  \
+      if (i < a.wslab4) wv[k] = ws_[i];                                                    \
+    }                                                                                      \
+    const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
+    _Pragma("unroll") for (int k = 0; k < B3_XS; ++k) {                                    \
+      if (s_goff[k] >= 0) {                                                                \
+        const float* p_ = src_ + s_goff[k];                                                \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = p_[(size_t)c * plane];    \
+      }                                                                                    \
+    }                                                                                      \
+  }
+#define PG_B3_COMMIT_X(ACT)                                                                \
+  _Pragma("unroll") for (int k = 0; k < B3_XS; ++k) {                                      \
+    int lo_ = s_loff[k];                                                                   \
+    asm volatile("" : "+v"(lo_));                                                          \
+    float e_[8];                                                                           \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) e_[c] = pg_apply_act(xv[k][c], ACT);     \
+    u32x4 h_, m_, l_;                                                                      \
+    split8(e_, h_, m_, l_);                                                                \
+    const int dst_ = s_goff[k] >= 0 ? lo_ : a.dump16;                                      \
+    lds16[dst_] = h_;                                                                      \
+    lds16[dst_ + (s_goff[k] >= 0 ? a.plane16 : 0)] = m_;                                   \
+    lds16[dst_ + (s_goff[k] >= 0 ? 2 * a.plane16 : 0)] = l_;                               \
+  }
+#define PG_B3_COMMIT_ALL()                                                                 \
+  {                                                                                        \
+    switch (a.in_act) { /* wave-uniform */                                                 \
+      case PG_ACT_RELU: PG_B3_COMMIT_X(PG_ACT_RELU) break;                                 \
+      case PG_ACT_ELU:  PG_B3_COMMIT_X(PG_ACT_ELU) break;                                  \
+      case PG_ACT_GELU: PG_B3_COMMIT_X(PG_ACT_GELU) break;                                 \
+      default:          PG_B3_COMMIT_X(PG_ACT_NONE) break;                                 \
+    }                                                                                      \
+    float4* wdst_ = reinterpret_cast<float4*>(lds16 + a.w_off16);                          \
+    _Pragma("unroll") for (int k = 0; k < B3_WS; ++k) {                                    \
+      const int i = tid + k * B3_THREADS;                                                  \
+      if (i < a.wslab4) wdst_[i] = wv[k];                                                  \
+    }                                                                                      \
+  }
+
+  PG_B3_ISSUE(0)
+  constexpr int EPS = 68;
+  const float* bl = lds + a.b_off;
+  const bf16x8* xl = reinterpret_cast<const bf16x8*>(lds16);
+  const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds16 + a.w_off16) + lane;
+  for (int step = 0; step < nsteps; ++step) {
+    const int tl = step / nchunk;
+    const bool more = step + 1 < nsteps;
+    PG_B3_COMMIT_ALL()  // the loads of this step (issued one step ago) -> LDS
+    __syncthreads();
+    if (more) PG_B3_ISSUE(step + 1)  // prefetch: lands under the MFMA loop
+    for (int ks = 0; ks < a.ksteps; ++ks) {
+      bf16x8 af[MT][3];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) af[m][pc] = wl[((ks * MT + m) * 3 + pc) * 64];
+      const bf16x8* xb = xl + gtab[4 * ks + kq];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const bf16x8 bh = xb[pixoff[n]];
+        const bf16x8 bm = xb[pixoff[n] + a.plane16];
+        const bf16x8 bo = xb[pixoff[n] + 2 * a.plane16];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 c = acc[m][n];
+          c = MFMA16B(af[m][2], bh, c);  // small terms first
+          c = MFMA16B(af[m][0], bo, c);
+          c = MFMA16B(af[m][1], bm, c);
+          c = MFMA16B(af[m][1], bh, c);
+          c = MFMA16B(af[m][0], bm, c);
+          c = MFMA16B(af[m][0], bh, c);
+          acc[m][n] = c;
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with the tiles: the next commit / the epilogue scratch may overwrite them
+    const bool last_chunk = (step + 1) % nchunk == 0;
+    if (last_chunk) {
+      // ---- epilogue (as conv_mfma.hip): + bias, out_act, + res, * act'(dact_src); transposition
+      // scratch = the weight area (rewritten by the next commit, which the barrier below orders)
+      const int n_img = n_first + tl * nstep;
+      const size_t so = so_rel + (size_t)n_img * a.Cout * L;
+      float* ep = reinterpret_cast<float*>(lds16 + a.w_off16) + wave * (16 * EPS);
+      const int cvalid = a.Cout - co0;
+      float* outp = a.out + so;
+      const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
+#define PG_B3_TILE_BODY(M)                                                                       \
+  _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[M][n][r]; \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+  float v[16];                                                                                   \
+  _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = ep[c * EPS + lane] + bl[(M) * 16 + c];   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+  switch (a.out_act) { /* wave-uniform */                                                        \
+    case PG_ACT_RELU: _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_RELU); break; \
+    case PG_ACT_ELU:  _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_ELU); break;  \
+    case PG_ACT_GELU: _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_GELU); break; \
+    default: break;                                                                              \
+  }
+#define PG_B3_TILE_STORE(M)                                                   \
+  if (sok) {                                                                  \
+    _Pragma("unroll") for (int c = 0; c < 16; ++c) {                          \
+      const int cc = (M) * 16 + c;                                            \
+      if (cc < cvalid) outp[(size_t)cc * L] = v[c];                           \
+    }                                                                         \
+  }
+      if (!has_res && !has_ds) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          PG_B3_TILE_BODY(m)
+          PG_B3_TILE_STORE(m)
+        }
+      } else {
+        const float* op1 = (has_res ? a.res : a.dact_src) + so;
+        const float* op2 = (has_res && has_ds) ? a.dact_src + so : nullptr;
+        constexpr int MH = MT > 2 ? 2 : MT;
+        float ov[MH][16];
+        const int dsel = has_ds ? a.dact : PG_ACT_NONE;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if (m % MH == 0) {
+#pragma unroll
+            for (int mm = 0; mm < MH; ++mm)
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                const int cc = (m + mm) * 16 + c;
+                ov[mm][c] = op1[(size_t)(cc < cvalid ? cc : 0) * L];
+              }
+          }
+          PG_B3_TILE_BODY(m)
+          float sv[16];
+          if (has_res) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] += ov[m % MH][c];
+            if (op2) {
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                const int cc = m * 16 + c;
+                sv[c] = op2[(size_t)(cc < cvalid ? cc : 0) * L];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sv[c] = ov[m % MH][c];
+          }
+          switch (dsel) {
+            case PG_ACT_RELU:
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_RELU);
+              break;
+            case PG_ACT_ELU:
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU);
+              break;
+            case PG_ACT_GELU:
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
+              break;
+            case PG_ACT_ELU_OUT:
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU_OUT);
+              break;
+            default: break;
+          }
+          PG_B3_TILE_STORE(m)
+        }
+      }
+#undef PG_B3_TILE_BODY
+#undef PG_B3_TILE_STORE
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (more) __syncthreads();  // scratch (weight area) is rewritten by the next commit
+    }
+  }
+#undef PG_B3_ISSUE
+#undef PG_B3_COMMIT_X
+#undef PG_B3_COMMIT_ALL
+}
+
+// ---- weight pack: A fragments of the three bf16 pieces ------------------------------------------
+// wfrag (16-byte units) [co chunk][channel chunk][k step][co tile m][piece][lane]: the 8 bf16 of
+//   Wsel[64 chunk + 16 m + (lane & 15)][channel = CIB * j + 8 cg(g) + 0..7][tap t(g)], g = 4 ks + (lane >> 4)
+// with group g -> (t = g / cgs, cg = g % cgs); zero for g >= groups or an output channel >= M.
+struct B3PackArgs {
+  const float* w;
+  unsigned int* wfrag;
+  int Cout, Cin, KH, KW, T, transpose;
+  int M, Kc, MT, chunks, CIB, cgs, groups, ksteps, nchunk;
+  int tap_u[PG_MAX_TAPS];
+  int tap_v[PG_MAX_TAPS];
+};
+
+__global__ void b3_pack_kernel(const B3PackArgs p) {
+  const long total = (long)p.chunks * p.nchunk * p.ksteps * p.MT * 64;  // lanes (pieces inside)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    long rest = i >> 6;
+    const int m = (int)(rest % p.MT); rest /= p.MT;
+    const int ks = (int)(rest % p.ksteps); rest /= p.ksteps;
+    const int j = (int)(rest % p.nchunk);
+    const int chunk = (int)(rest / p.nchunk);
+    const int o = chunk * B3_CO_CHUNK + m * 16 + (lane & 15);
+    const int g = 4 * ks + (lane >> 4);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = 0.f;
+    if (o < p.M && g < p.groups) {
+      const int t = g / p.cgs, cg = g - t * p.cgs;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = p.CIB * j + 8 * cg + e;
+        const int co = p.transpose ? c : o;
+        const int ci = p.transpose ? o : c;
+        x[e] = p.w[(((size_t)co * p.Cin + ci) * p.KH + p.tap_u[t]) * p.KW + p.tap_v[t]];
+      }
+    }
+    u32x4 h, mm, l;
+    split8(x, h, mm, l);
+    // [chunk][j][ks][m][piece][lane] in 16-byte units
+    const size_t base = ((((size_t)chunk * p.nchunk + j) * p.ksteps + ks) * p.MT + m) * 3 * 64 + lane;
+    u32x4* dst = reinterpret_cast<u32x4*>(p.wfrag);
+    dst[base] = h;
+    dst[base + 64] = mm;
+    dst[base + 128] = l;
+  }
+}
+
+inline int b3_mt(int M) { return M >= B3_CO_CHUNK ? 4 : (M + 15) / 16; }
+inline int b3_chunks(int M) { return (M + B3_CO_CHUNK - 1) / B3_CO_CHUNK; }
+
+struct B3Plan {
+  int ok, CIB, cgs, groups, ksteps, MT;
+  size_t w_bytes;
+};
+
+constexpr int B3_PX_CAP = 352;  // tile pixels (with halo) the LDS plan assumes for T > 1 (T == 1: 256)
+
+// Format-level plan, a function of (K channels, M channels, taps) only, so that the weight pack does
+// not depend on the image size: channel chunk CIB in {32, 16, 8}, groups of 8 channels x taps per
+// chunk, K steps of 4 groups. ok = 0: the fp32-MFMA kernel takes the problem.
+B3Plan b3_plan(int Kc, int M, int T) {
+  B3Plan best = {};
+  static const bool on = []() { const char* e = getenv("PG_CONV_B3"); return !(e && e[0] == '0'); }();
+  if (!on || Kc % 8 != 0 || Kc < 16 || M < 16 || T < 1) return best;
+  const int MT = b3_mt(M);
+  const int px = T == 1 ? 256 : B3_PX_CAP;
+  double best_cost = 1e30;
+  for (int CIB = 32; CIB >= 8; CIB >>= 1) {
+    if (Kc % CIB != 0) continue;
+    const int cgs = CIB / 8, groups = cgs * T, ksteps = (groups + 3) / 4;
+    if (ksteps > 5 || groups > B3_MAXG) continue;
+    const size_t xb = (size_t)cgs * 3 * px * 16, wb = (size_t)ksteps * MT * 3 * 1024;
+    const size_t wb_s = wb < (size_t)4 * 16 * 68 * 4 ? (size_t)4 * 16 * 68 * 4 : wb;  // epilogue scratch floor
+    if (xb + wb_s + 1024 > 72 * 1024) continue;
+    if ((long)cgs * px > (long)B3_XS * B3_THREADS) continue;
+    if ((long)ksteps * MT * 192 > (long)B3_WS * B3_THREADS) continue;
+    const double cost = (double)ksteps / CIB + 0.002 / CIB;  // MFMA work per channel, then fewer steps
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = {1, CIB, cgs, groups, ksteps, MT, wb_s};
+    }
+  }
+  return best;
+}
+
+// rows per tile: as many as fit 256 output pixels and the planned tile (with halo)
+int b3_rows(int T, int OH, int OW, int hr, int hc) {
+  const int cap = T == 1 ? 256 : B3_PX_CAP;
+  int TR = 256 / OW;
+  if (TR > OH) TR = OH;
+  while (TR >= 1 && (TR + hr) * (OW + hc) > cap) --TR;
+  if (TR < 1) return 0;
+  const int nt_rows = (OH + TR - 1) / TR;
+  return (OH + nt_rows - 1) / nt_rows;
+}
+
+template <int MT>
+void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
+  static bool big[5] = {false, false, false, false, false};
+#define PG_B3_L(NTV)                                                                                  \
+  {                                                                                                   \
+    if (shmem > 64 * 1024 && !big[NTV]) {                                                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);               \
+      big[NTV] = true;                                                                                \
+    }                                                                                                 \
+    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV>), grid, dim3(B3_THREADS), shmem, st, a);              \
+  }
+  switch (nt) {
+    case 1: PG_B3_L(1) break;
+    case 2: PG_B3_L(2) break;
+    case 3: PG_B3_L(3) break;
+    default: PG_B3_L(4) break;
+  }
+#undef PG_B3_L
+}
+
+void tap_extent(int T, const int* dr, const int* dc, int& min_dr, int& hr, int& min_dc, int& hc) {
+  int a0 = dr[0], a1 = dr[0], b0 = dc[0], b1 = dc[0];
+  for (int t = 1; t < T; ++t) {
+    a0 = dr[t] < a0 ? dr[t] : a0; a1 = dr[t] > a1 ? dr[t] : a1;
+    b0 = dc[t] < b0 ? dc[t] : b0; b1 = dc[t] > b1 ? dc[t] : b1;
+  }
+  min_dr = a0; hr = a1 - a0; min_dc = b0; hc = b1 - b0;
+}
+
+}  // namespace
+
+// ---- interface used by conv_mfma.hip's exported entry points --------------------------------------
+int pg_b3_applicable(int Kc, int M, int T, int OH, int OW, int hr, int hc) {
+  if (OW > 256 || OH * OW < 256) return 0;
+  return b3_plan(Kc, M, T).ok && b3_rows(T, OH, OW, hr, hc) >= 1;
+}
+
+size_t pg_b3_frag_floats(int Kc, int M, int T) {
+  const B3Plan pl = b3_plan(Kc, M, T);
+  if (!pl.ok) return 0;
+  return (size_t)b3_chunks(M) * (Kc / pl.CIB) * pl.ksteps * pl.MT * 3 * 64 * 4;
+}
+
+int pg_b3_pack(const float* w, float* wfrag, int Cout, int Cin, int KH, int KW, int T,
+               const int* tap_u, const int* tap_v, int transpose, hipStream_t st) {
+  B3PackArgs p;
+  p.w = w; p.wfrag = reinterpret_cast<unsigned int*>(wfrag);
+  p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.T = T; p.transpose = transpose;
+  p.M = transpose ? Cin : Cout;
+  p.Kc = transpose ? Cout : Cin;
+  const B3Plan pl = b3_plan(p.Kc, p.M, T);
+  PG_REQUIRE(pl.ok, PG_ESHAPE, "pg_pack_conv_weight_frag: shape not covered by the bf16x3 format");
+  p.MT = pl.MT; p.chunks = b3_chunks(p.M); p.CIB = pl.CIB; p.cgs = pl.cgs; p.groups = pl.groups;
+  p.ksteps = pl.ksteps; p.nchunk = p.Kc / pl.CIB;
+  for (int t = 0; t < T; ++t) { p.tap_u[t] = tap_u[t]; p.tap_v[t] = tap_v[t]; }
+  const long total = (long)p.chunks * p.nchunk * p.ksteps * p.MT * 64;
+  const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  hipLaunchKernelGGL(b3_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
+  PG_LAUNCH_CHECK("pg_pack_conv_weight_frag(bf16x3)");
+  return 0;
+}
+
+int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const float* res, float* out,
+               int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
+               const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
+               hipStream_t st) {
+  B3Args a;
+  a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
+  a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW; a.T = T;
+  a.in_act = in_act; a.dact = dact; a.out_act = out_act;
+  int hr, hc;
+  tap_extent(T, tap_dr, tap_dc, a.min_dr, hr, a.min_dc, hc);
+  const B3Plan pl = b3_plan(Cin, Cout, T);
+  const int TR = b3_rows(T, OH, OW, hr, hc);
+  PG_REQUIRE(pl.ok && TR >= 1 && OH * OW >= 256 && OW <= 256, PG_ESHAPE,
+             "pg_conv2d_mfma(bf16x3): shape not covered");
+  a.TR = TR; a.tile_h = TR + hr; a.tile_w = OW + hc;
+  a.plane16 = ((a.tile_h * a.tile_w + 15) / 16) * 16;
+  a.tiles_per_img = (OH + TR - 1) / TR;
+  a.CIB = pl.CIB; a.cgs = pl.cgs; a.groups = pl.groups; a.ksteps = pl.ksteps;
+  for (int g = 0; g < pl.groups; ++g) {
+    const int t = g / pl.cgs, cg = g - t * pl.cgs;
+    a.g_tapoff[g] = (tap_dr[t] - a.min_dr) * a.tile_w + (tap_dc[t] - a.min_dc);
+    a.g_cg[g] = cg;
+  }
+  for (int g = pl.groups; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }
+  a.xslots = pl.cgs * a.tile_h * a.tile_w;
+  a.wslab4 = pl.ksteps * pl.MT * 192;
+  const size_t x16 = (size_t)pl.cgs * 3 * a.plane16;
+  a.dump16 = (int)x16;              // one spare 16-byte entry (+ padding to a 256-byte boundary)
+  a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
+  size_t shmem = (size_t)a.w_off16 * 16 + pl.w_bytes;
+  a.b_off = (int)(shmem / 4);
+  shmem += (B3_CO_CHUNK + B3_MAXG + 4) * sizeof(float);
+  PG_REQUIRE(shmem <= 80 * 1024, PG_ESHAPE, "pg_conv2d_mfma(bf16x3): %zu B of LDS", shmem);
+  const int nt = (TR * OW + 63) / 64;
+  const int chunks_y = b3_chunks(Cout);
+  long want = 512 / chunks_y;
+  if (want < a.tiles_per_img) want = a.tiles_per_img;
+  long gx = (want / a.tiles_per_img) * a.tiles_per_img;
+  if (gx > (long)N * a.tiles_per_img) gx = (long)N * a.tiles_per_img;
+  dim3 grid((unsigned)gx, (unsigned)chunks_y);
+  switch (pl.MT) {
+    case 1: b3_launch<1>(a, nt, grid, shmem, st); break;
+    case 2: b3_launch<2>(a, nt, grid, shmem, st); break;
+    case 3: b3_launch<3>(a, nt, grid, shmem, st); break;
+    default: b3_launch<4>(a, nt, grid, shmem, st); break;
+  }
+  PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3)");
+  return 0;
+}

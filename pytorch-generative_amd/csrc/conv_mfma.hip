@@ -458,28 +458,59 @@ static void mf_pack_job(FragPackJob& j, float* wfrag, int Cout, int Cin, int T, 
 
 }  // namespace
 
+// conv_b3.hip: the same convolution with its fp32 products on the bf16 matrix pipe (format 2)
+int pg_b3_applicable(int Kc, int M, int T, int OH, int OW, int hr, int hc);
+size_t pg_b3_frag_floats(int Kc, int M, int T);
+int pg_b3_pack(const float* w, float* wfrag, int Cout, int Cin, int KH, int KW, int T,
+               const int* tap_u, const int* tap_v, int transpose, hipStream_t st);
+int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const float* res, float* out,
+               int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
+               const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
+               hipStream_t st);
+
 // The matrix-core path pays off once both channel extents fill MFMA tiles; tiny contractions
 // (the 1- / 3-channel image convolutions, 4-channel query projections) stay on conv_direct.hip.
-PG_EXPORT int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, int IW) {
-  if ((IW % 4) != 0) return 0;  // float4 staging slots
+// Returns the weight-fragment FORMAT the matrix-core path uses for this problem: 0 = none (use
+// pg_conv2d_taps), PG_CONV_FMT_F32 = fp32 MFMA fragments, PG_CONV_FMT_B3 = bf16x3 fragments.
+// hr / hc: row / column extent of the tap list (max - min offset).
+PG_EXPORT int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, int IW, int hr, int hc) {
   if (OW > 256 || T < 1 || T > PG_MAX_TAPS) return 0;
+  if (pg_b3_applicable(Cin, Cout, T, OH, OW, hr, hc)) return PG_CONV_FMT_B3;
+  if ((IW % 4) != 0) return 0;  // float4 staging slots
   if (OH * OW < 64) return 0;  // tiny images (VD-VAE's 4x4 .. 1x1 levels): launch bound either way
-  return (Cin >= 8 && Cout >= 8) ? 1 : 0;
+  return (Cin >= 8 && Cout >= 8) ? PG_CONV_FMT_F32 : 0;
 }
 
-PG_EXPORT size_t pg_conv_frag_floats(int K_channels, int M_channels, int T) {
+PG_EXPORT size_t pg_conv_frag_floats(int K_channels, int M_channels, int T, int fmt) {
+  if (fmt == PG_CONV_FMT_B3) return pg_b3_frag_floats(K_channels, M_channels, T);
   const size_t KQ = (size_t)((K_channels + 3) / 4) * T;
   return (size_t)mf_chunks(M_channels) * KQ * mf_mt(M_channels) * 64;
 }
 
-
 PG_EXPORT int pg_pack_conv_weight_frag2(const float* w, float* wfrag_fwd, float* wfrag_dgrad,
                                         int Cout, int Cin, int KH, int KW, int T, const int* tap_u,
-                                        const int* tap_v, void* stream) {
+                                        const int* tap_v, int fmt_fwd, int fmt_dgrad, void* stream) {
   PG_REQUIRE(w && (wfrag_fwd || wfrag_dgrad) && tap_u && tap_v, PG_EINVAL,
              "pg_pack_conv_weight_frag: null pointer");
   PG_REQUIRE(T >= 1 && T <= PG_MAX_TAPS, PG_ESHAPE, "pg_pack_conv_weight_frag: T=%d not in [1,%d]",
              T, PG_MAX_TAPS);
+  for (int t = 0; t < T; ++t)
+    PG_REQUIRE(tap_u[t] >= 0 && tap_u[t] < KH && tap_v[t] >= 0 && tap_v[t] < KW, PG_EINVAL,
+               "pg_pack_conv_weight_frag: tap %d (%d,%d) outside %dx%d", t, tap_u[t], tap_v[t], KH, KW);
+  hipStream_t st = (hipStream_t)stream;
+  if (wfrag_fwd && fmt_fwd == PG_CONV_FMT_B3) {
+    const int rc = pg_b3_pack(w, wfrag_fwd, Cout, Cin, KH, KW, T, tap_u, tap_v, 0, st);
+    if (rc) return rc;
+    wfrag_fwd = nullptr;
+  }
+  if (wfrag_dgrad && fmt_dgrad == PG_CONV_FMT_B3) {
+    const int rc = pg_b3_pack(w, wfrag_dgrad, Cout, Cin, KH, KW, T, tap_u, tap_v, 1, st);
+    if (rc) return rc;
+    wfrag_dgrad = nullptr;
+  }
+  if (!wfrag_fwd && !wfrag_dgrad) return 0;
+  PG_REQUIRE((!wfrag_fwd || fmt_fwd == PG_CONV_FMT_F32) && (!wfrag_dgrad || fmt_dgrad == PG_CONV_FMT_F32),
+             PG_EINVAL, "pg_pack_conv_weight_frag: unknown fragment format");
   FragPackArgs p;
   p.w = w; p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.T = T;
   p.njobs = 0;
@@ -487,31 +518,30 @@ PG_EXPORT int pg_pack_conv_weight_frag2(const float* w, float* wfrag_fwd, float*
   if (wfrag_dgrad) mf_pack_job(p.job[p.njobs++], wfrag_dgrad, Cout, Cin, T, 1);
   if (p.njobs == 1) p.job[1] = p.job[0];
   for (int t = 0; t < T; ++t) {
-    PG_REQUIRE(tap_u[t] >= 0 && tap_u[t] < KH && tap_v[t] >= 0 && tap_v[t] < KW, PG_EINVAL,
-               "pg_pack_conv_weight_frag: tap %d (%d,%d) outside %dx%d", t, tap_u[t], tap_v[t], KH, KW);
     p.tap_u[t] = tap_u[t];
     p.tap_v[t] = tap_v[t];
   }
   const long total = p.job[0].total + (p.njobs > 1 ? p.job[1].total : 0);
   const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-  hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, st, p);
   PG_LAUNCH_CHECK("pg_pack_conv_weight_frag");
   return 0;
 }
 
 PG_EXPORT int pg_pack_conv_weight_frag(const float* w, float* wfrag, int Cout, int Cin, int KH,
                                        int KW, int T, const int* tap_u, const int* tap_v,
-                                       int transpose, void* stream) {
+                                       int transpose, int fmt, void* stream) {
   return pg_pack_conv_weight_frag2(w, transpose ? nullptr : wfrag, transpose ? wfrag : nullptr, Cout,
-                                   Cin, KH, KW, T, tap_u, tap_v, stream);
+                                   Cin, KH, KW, T, tap_u, tap_v, fmt, fmt, stream);
 }
 
 PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* bias,
                              const float* res, float* out, int N, int Cin, int IH, int IW,
                              int Cout, int OH, int OW, int T, const int* tap_dr,
                              const int* tap_dc, int in_act, const float* dact_src, int dact,
-                             int out_act, void* stream) {
+                             int out_act, int fmt, void* stream) {
   PG_REQUIRE(in && wfrag && out && tap_dr && tap_dc, PG_EINVAL, "pg_conv2d_mfma: null pointer");
+  PG_REQUIRE(fmt == PG_CONV_FMT_F32 || fmt == PG_CONV_FMT_B3, PG_EINVAL, "pg_conv2d_mfma: bad format %d", fmt);
   PG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, PG_EINVAL,
              "pg_conv2d_mfma: non-positive dimension");
   PG_REQUIRE(T >= 1 && T <= PG_MAX_TAPS, PG_ESHAPE, "pg_conv2d_mfma: T=%d not in [1,%d]", T,
@@ -522,6 +552,9 @@ PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* b
   PG_REQUIRE(dact >= PG_ACT_NONE && dact <= PG_ACT_ELU_OUT && ((dact == PG_ACT_NONE) == (dact_src == nullptr)),
              PG_EINVAL, "pg_conv2d_mfma: dact_src / dact mismatch");
   hipStream_t st = (hipStream_t)stream;
+  if (fmt == PG_CONV_FMT_B3)
+    return pg_b3_conv(in, wfrag, bias, res, out, N, Cin, IH, IW, Cout, OH, OW, T, tap_dr, tap_dc, in_act,
+                      dact_src, dact, out_act, st);
   MfArgs a;
   a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
   a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW; a.T = T;

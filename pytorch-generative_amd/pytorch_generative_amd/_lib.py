@@ -33,12 +33,12 @@ SIGNATURES = {
     "pg_conv2d_mfma": (
         c_i,
         [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_f, c_i,
-         c_i, c_s],
+         c_i, c_i, c_s],
     ),
-    "pg_conv_mfma_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
-    "pg_conv_frag_floats": (c_z, [c_i, c_i, c_i]),
-    "pg_pack_conv_weight_frag": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_s]),
-    "pg_pack_conv_weight_frag2": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_s]),
+    "pg_conv_mfma_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "pg_conv_frag_floats": (c_z, [c_i, c_i, c_i, c_i]),
+    "pg_pack_conv_weight_frag": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_i, c_s]),
+    "pg_pack_conv_weight_frag2": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_i, c_s]),
     "pg_pack_conv_weight": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_i, c_s]),
     "pg_packed_weight_floats": (c_z, [c_i, c_i, c_i]),
     "pg_conv_b_pad": (c_i, [c_i]),

@@ -87,6 +87,9 @@ class ConvSpec:
         self.w_dc = ia([v - pad_w for _, v in self.wg_taps])
         self.w_u = ia([u for u, _ in self.wg_taps])
         self.w_v = ia([v for _, v in self.wg_taps])
+        # extent of the active tap list (identical for the negated list of the data gradient)
+        self.hr = max(u for u, _ in act) - min(u for u, _ in act)
+        self.hc = max(v for _, v in act) - min(v for _, v in act)
 
     def full_out(self, h, w):
         return h + 2 * self.pad_h - self.kh + 1, w + 2 * self.pad_w - self.kw + 1
@@ -97,34 +100,37 @@ CONV_MFMA = os.environ.get("PG_CONV_MFMA", "1") != "0"
 
 
 def _use_mfma(lib, k_channels, m_channels, spec, out_hw, in_w):
-    return CONV_MFMA and bool(
-        lib.pg_conv_mfma_supported(k_channels, m_channels, len(spec.fwd_taps), out_hw[0], out_hw[1],
-                                   in_w))
+    """Fragment format of the matrix-core path for this problem (0: none -> VALU tap kernels,
+    1: fp32 MFMA, 2: bf16x3 MFMA; include/pg_hip.h PG_CONV_FMT_*)."""
+    if not CONV_MFMA:
+        return 0
+    return int(lib.pg_conv_mfma_supported(k_channels, m_channels, len(spec.fwd_taps), out_hw[0],
+                                          out_hw[1], in_w, spec.hr, spec.hc))
 
 
-def _pack_frag(lib, weight, spec, transpose):
-    """MFMA A-fragment pack of the active taps (csrc/conv_mfma.hip)."""
+def _pack_frag(lib, weight, spec, transpose, fmt):
+    """MFMA A-fragment pack of the active taps (csrc/conv_mfma.hip, csrc/conv_b3.hip)."""
     cout, cin, kh, kw = weight.shape
     kc, m = (cout, cin) if transpose else (cin, cout)
     t = len(spec.fwd_taps)
-    wfrag = torch.empty(lib.pg_conv_frag_floats(kc, m, t), device=weight.device, dtype=torch.float32)
+    wfrag = torch.empty(lib.pg_conv_frag_floats(kc, m, t, fmt), device=weight.device, dtype=torch.float32)
     _lib.check(
         lib.pg_pack_conv_weight_frag(weight.data_ptr(), wfrag.data_ptr(), cout, cin, kh, kw, t,
-                                     spec.f_u, spec.f_v, int(transpose), _stream()),
+                                     spec.f_u, spec.f_v, int(transpose), fmt, _stream()),
         "pg_pack_conv_weight_frag",
     )
     return wfrag
 
 
-def _pack_frag_both(lib, weight, spec):
-    """Forward and data-gradient fragments in one launch."""
+def _pack_frag_both(lib, weight, spec, fmt_f, fmt_t):
+    """Forward and data-gradient fragments (one launch when both use the fp32 format)."""
     cout, cin, kh, kw = weight.shape
     t = len(spec.fwd_taps)
-    wf = torch.empty(lib.pg_conv_frag_floats(cin, cout, t), device=weight.device, dtype=torch.float32)
-    wt = torch.empty(lib.pg_conv_frag_floats(cout, cin, t), device=weight.device, dtype=torch.float32)
+    wf = torch.empty(lib.pg_conv_frag_floats(cin, cout, t, fmt_f), device=weight.device, dtype=torch.float32)
+    wt = torch.empty(lib.pg_conv_frag_floats(cout, cin, t, fmt_t), device=weight.device, dtype=torch.float32)
     _lib.check(
         lib.pg_pack_conv_weight_frag2(weight.data_ptr(), wf.data_ptr(), wt.data_ptr(), cout, cin, kh,
-                                      kw, t, spec.f_u, spec.f_v, _stream()),
+                                      kw, t, spec.f_u, spec.f_v, fmt_f, fmt_t, _stream()),
         "pg_pack_conv_weight_frag2",
     )
     return wf, wt
@@ -171,15 +177,16 @@ class _ConvTaps(torch.autograd.Function):
                              "(check ops.conv_mfma_ok first)")
         ctx.wfrag_t = None
         if mfma:
-            if ctx.needs_input_grad[0] and _use_mfma(lib, cout, cin, spec, (ih, iw), ow):
-                wfrag, ctx.wfrag_t = _pack_frag_both(lib, weight, spec)  # backward's fragments too
+            fmt_t = _use_mfma(lib, cout, cin, spec, (ih, iw), ow) if ctx.needs_input_grad[0] else 0
+            if fmt_t:
+                wfrag, ctx.wfrag_t = _pack_frag_both(lib, weight, spec, mfma, fmt_t)  # backward's fragments too
             else:
-                wfrag = _pack_frag(lib, weight, spec, transpose=False)
+                wfrag = _pack_frag(lib, weight, spec, False, mfma)
             _lib.check(
                 lib.pg_conv2d_mfma(
                     x.data_ptr(), wfrag.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih,
                     iw, cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, 0, ACT_NONE,
-                    out_act, _stream(),
+                    out_act, mfma, _stream(),
                 ),
                 "pg_conv2d_mfma",
             )
@@ -227,12 +234,13 @@ class _ConvTaps(torch.autograd.Function):
         n, cin, ih, iw = x.shape
         _, cout, oh, ow = dy.shape
         dx = dw = db = None
-        if need_dx and _use_mfma(lib, cout, cin, spec, (ih, iw), ow):
+        fmt_t = _use_mfma(lib, cout, cin, spec, (ih, iw), ow) if need_dx else 0
+        if fmt_t:
             # matrix-core data gradient; act'(x) of a fused input activation in its epilogue (one
             # exp / erf per output element is noise next to the MFMA work of the tile)
             wfrag_t = getattr(ctx, "wfrag_t", None)
             if wfrag_t is None:
-                wfrag_t = _pack_frag(lib, weight, spec, transpose=True)
+                wfrag_t = _pack_frag(lib, weight, spec, True, fmt_t)
             dx = torch.empty_like(x)
             dact = ctx.in_act if ctx.in_act != ACT_NONE else (ACT_ELU_OUT if in_post == ACT_ELU else ACT_NONE)
             fuse = dact != ACT_NONE
@@ -240,7 +248,7 @@ class _ConvTaps(torch.autograd.Function):
                 lib.pg_conv2d_mfma(
                     dy.data_ptr(), wfrag_t.data_ptr(), 0, 0, dx.data_ptr(), n, cout, oh, ow, cin,
                     ih, iw, len(spec.fwd_taps), spec.f_ndr, spec.f_ndc, ACT_NONE,
-                    x.data_ptr() if fuse else 0, dact, ACT_NONE, _stream(),
+                    x.data_ptr() if fuse else 0, dact, ACT_NONE, fmt_t, _stream(),
                 ),
                 "pg_conv2d_mfma(dgrad)",
             )
@@ -366,8 +374,8 @@ def conv_mfma_ok(x, weight, spec, out_hw=None):
         out_hw = spec.full_out(x.shape[2], x.shape[3])
     lib = _lib.load()
     cout, cin = weight.shape[0], weight.shape[1]
-    return (x.is_cuda and _use_mfma(lib, cin, cout, spec, out_hw, x.shape[3])
-            and _use_mfma(lib, cout, cin, spec, (x.shape[2], x.shape[3]), out_hw[1]))
+    return bool(x.is_cuda and _use_mfma(lib, cin, cout, spec, out_hw, x.shape[3])
+                and _use_mfma(lib, cout, cin, spec, (x.shape[2], x.shape[3]), out_hw[1]))
 
 
 def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
