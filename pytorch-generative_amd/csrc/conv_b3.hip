@@ -47,9 +47,10 @@ struct B3Args {
   int TR, tiles_per_img, tile_h, tile_w, min_dr, min_dc;
   int CIB, cgs, groups, ksteps;   // channels per chunk, CIB / 8, cgs * T, ceil(groups / 4)
   int plane16;                    // 16-byte entries per (channel group, piece) plane (multiple of 16)
-  int w_off16, b_off, dump16;     // LDS offsets: weights (16-byte units), bias (floats), dump entry
+  int w_off16, b_off, ep_off, dump16;  // LDS offsets: weights (16-byte units), bias / epilogue scratch (floats), dump entry
   int xslots, wslab4;             // staging slots per step; float4 per step's weight slab
   int in_act, dact, out_act;
+  int dbg;                        // ablation switches (PG_B3_DBG), 0 in production
   int g_tapoff[B3_MAXG];          // per group: tap offset in tile pixels
   int g_cg[B3_MAXG];              // per group: channel group of the chunk
 };
@@ -170,6 +171,7 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
       if (i < a.wslab4) wv[k] = ws_[i];                                                    \
     }                                                                                      \
     const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
+    if (!((a.dbg & 1) && (STEP) > 0))                                                      \
     _Pragma("unroll") for (int k = 0; k < B3_XS; ++k) {                                    \
       if (s_goff[k] >= 0) {                                                                \
         const float* p_ = src_ + s_goff[k];                                                \
@@ -205,17 +207,22 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
     }                                                                                      \
   }
 
-  PG_B3_ISSUE(0)
+  // Pipeline over the (tile, channel chunk) steps of this workgroup, ONE x / weight tile in LDS:
+  //   MFMA(s) | barrier | commit(s+1) (its loads were issued a whole step earlier) |
+  //   issue loads(s+2) | [epilogue of the tile that ended at s, in per-wave scratch] | barrier
+  // so loads have a whole step (+ an epilogue) to land and the epilogue's stores fly under MFMA(s+1).
   constexpr int EPS = 68;
   const float* bl = lds + a.b_off;
   const bf16x8* xl = reinterpret_cast<const bf16x8*>(lds16);
   const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds16 + a.w_off16) + lane;
+  PG_B3_ISSUE(0)
+  PG_B3_COMMIT_ALL()
+  __syncthreads();
+  if (nsteps > 1) PG_B3_ISSUE(1)
   for (int step = 0; step < nsteps; ++step) {
     const int tl = step / nchunk;
     const bool more = step + 1 < nsteps;
-    PG_B3_COMMIT_ALL()  // the loads of this step (issued one step ago) -> LDS
-    __syncthreads();
-    if (more) PG_B3_ISSUE(step + 1)  // prefetch: lands under the MFMA loop
+    if (!(a.dbg & 4))
     for (int ks = 0; ks < a.ksteps; ++ks) {
       bf16x8 af[MT][3];
 #pragma unroll
@@ -241,14 +248,16 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
         }
       }
     }
-    __syncthreads();  // every wave is done with the tiles: the next commit / the epilogue scratch may overwrite them
+    __syncthreads();  // every wave is done with the tiles: the next commit may overwrite them
+    if (more && !((a.dbg & 2))) PG_B3_COMMIT_ALL()
+    if (step + 2 < nsteps) PG_B3_ISSUE(step + 2)
     const bool last_chunk = (step + 1) % nchunk == 0;
-    if (last_chunk) {
-      // ---- epilogue (as conv_mfma.hip): + bias, out_act, + res, * act'(dact_src); transposition
-      // scratch = the weight area (rewritten by the next commit, which the barrier below orders)
+    if (last_chunk && !(a.dbg & 8)) {
+      // ---- epilogue (as conv_mfma.hip): + bias, out_act, + res, * act'(dact_src); per-wave
+      // transposition scratch of its own (the tiles already hold the next step)
       const int n_img = n_first + tl * nstep;
       const size_t so = so_rel + (size_t)n_img * a.Cout * L;
-      float* ep = reinterpret_cast<float*>(lds16 + a.w_off16) + wave * (16 * EPS);
+      float* ep = lds + a.ep_off + wave * (16 * EPS);
       const int cvalid = a.Cout - co0;
       float* outp = a.out + so;
       const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
@@ -335,12 +344,14 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
       }
 #undef PG_B3_TILE_BODY
 #undef PG_B3_TILE_STORE
+    }
+    if (last_chunk) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (more) __syncthreads();  // scratch (weight area) is rewritten by the next commit
     }
+    if (more) __syncthreads();  // the commit is visible before the next MFMA loop
   }
 #undef PG_B3_ISSUE
 #undef PG_B3_COMMIT_X
@@ -420,8 +431,8 @@ B3Plan b3_plan(int Kc, int M, int T) {
     const int cgs = CIB / 8, groups = cgs * T, ksteps = (groups + 3) / 4;
     if (ksteps > 5 || groups > B3_MAXG) continue;
     const size_t xb = (size_t)cgs * 3 * px * 16, wb = (size_t)ksteps * MT * 3 * 1024;
-    const size_t wb_s = wb < (size_t)4 * 16 * 68 * 4 ? (size_t)4 * 16 * 68 * 4 : wb;  // epilogue scratch floor
-    if (xb + wb_s + 1024 > 72 * 1024) continue;
+    const size_t wb_s = wb;
+    if (xb + wb_s + (size_t)4 * 16 * 68 * 4 + 1024 > 80 * 1024) continue;  // + per-wave epilogue scratch
     if ((long)cgs * px > (long)B3_XS * B3_THREADS) continue;
     if ((long)ksteps * MT * 192 > (long)B3_WS * B3_THREADS) continue;
     const double cost = (double)ksteps / CIB + 0.002 / CIB;  // MFMA work per channel, then fewer steps
@@ -515,6 +526,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
   a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW; a.T = T;
   a.in_act = in_act; a.dact = dact; a.out_act = out_act;
+  { const char* e = getenv("PG_B3_DBG"); a.dbg = e ? atoi(e) : 0; }
   int hr, hc;
   tap_extent(T, tap_dr, tap_dc, a.min_dr, hr, a.min_dc, hc);
   const B3Plan pl = b3_plan(Cin, Cout, T);
@@ -537,6 +549,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.dump16 = (int)x16;              // one spare 16-byte entry (+ padding to a 256-byte boundary)
   a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
   size_t shmem = (size_t)a.w_off16 * 16 + pl.w_bytes;
+  a.ep_off = (int)(shmem / 4);
+  shmem += (size_t)4 * 16 * 68 * 4;
   a.b_off = (int)(shmem / 4);
   shmem += (B3_CO_CHUNK + B3_MAXG + 4) * sizeof(float);
   PG_REQUIRE(shmem <= 80 * 1024, PG_ESHAPE, "pg_conv2d_mfma(bf16x3): %zu B of LDS", shmem);
