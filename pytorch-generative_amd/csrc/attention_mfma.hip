@@ -694,18 +694,20 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // waves per workgroup: forward / dK,dV use 4 (a multiple of the 4 SIMDs; 3-4 workgroups per CU),
 // dQ (68 KB of LDS: two workgroups per CU) 8. PG_ATTN_WAVES="f,q,k" overrides for tuning.
+struct AttnWaveCfg { int w[3]; };
 static void attn_waves(int* w) {
-  static int cfg[3] = {0, 0, 0};
-  if (cfg[0] == 0) {
-    cfg[0] = 4; cfg[1] = 8; cfg[2] = 4;
+  // function-local static with an initialiser: thread-safe one-time init (the library is entered from
+  // the main thread and from the autograd thread)
+  static const AttnWaveCfg cfg = []() {
+    AttnWaveCfg c = {{4, 8, 4}};
     if (const char* e = getenv("PG_ATTN_WAVES")) {
       int f = 0, q = 0, k = 0;
-      if (sscanf(e, "%d,%d,%d", &f, &q, &k) == 3 && f >= 1 && f <= 8 && q >= 1 && q <= 8 && k >= 1 && k <= 8) {
-        cfg[0] = f; cfg[1] = q; cfg[2] = k;
-      }
+      if (sscanf(e, "%d,%d,%d", &f, &q, &k) == 3 && f >= 1 && f <= 8 && q >= 1 && q <= 8 && k >= 1 && k <= 8)
+        c = {{f, q, k}};
     }
-  }
-  w[0] = cfg[0]; w[1] = cfg[1]; w[2] = cfg[2];
+    return c;
+  }();
+  w[0] = cfg.w[0]; w[1] = cfg.w[1]; w[2] = cfg.w[2];
 }
 
 int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st);  // attention_k4.hip

@@ -423,7 +423,18 @@ PG_EXPORT int pg_conv2d_taps(const float* in, const float* wpk, const float* bia
   dim3 grid((unsigned)(N * a.tiles_per_img), (unsigned)((ytiles + a.CT - 1) / a.CT));
   threads *= a.CT;
   a.w_off = ((CIB * a.ch_stride + 4 + 3) / 4) * 4;  // x tile + dump word, rounded to 16 bytes
-  const size_t shmem = ((size_t)a.w_off + (size_t)CIB * T * a.CT * COB) * sizeof(float);
+  // x tile + the chunk's weights must fit the 64 KB a kernel gets without opting in to more: shrink
+  // the channel chunk (small images make CIB == Cin and the weight slab CIB*T*CT*16 floats unbounded)
+  size_t shmem = ((size_t)a.w_off + (size_t)CIB * T * a.CT * COB) * sizeof(float);
+  while (shmem > 64 * 1024 && CIB > 1) {
+    CIB = (CIB + 1) / 2;
+    a.CIB = CIB;
+    a.w_off = ((CIB * a.ch_stride + 4 + 3) / 4) * 4;
+    shmem = ((size_t)a.w_off + (size_t)CIB * T * a.CT * COB) * sizeof(float);
+  }
+  PG_REQUIRE(shmem <= 64 * 1024, PG_ESHAPE,
+             "pg_conv2d_taps: a %dx%d tile with %d taps x %d output channels needs %zu B of LDS (> 64 KB)",
+             a.tile_h, a.tile_w, T, a.CT * COB, shmem);
   switch (in_act) {
     case PG_ACT_RELU: hipLaunchKernelGGL(conv_taps_kernel<PG_ACT_RELU>, grid, dim3(threads), shmem, st, a); break;
     case PG_ACT_ELU:  hipLaunchKernelGGL(conv_taps_kernel<PG_ACT_ELU>, grid, dim3(threads), shmem, st, a); break;

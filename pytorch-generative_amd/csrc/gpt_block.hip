@@ -508,7 +508,15 @@ int grid_blocks(int which, int N, int L) {
         for (int i = 0; i < 4; ++i) cap[i] = v[i];
     }
   }
-  const int min_tiles = (which & 1) ? 8 : 4;
+  static int mt_cfg[2] = {0, 0};  // tiles per wave below which the grid shrinks: forward, backward
+  if (mt_cfg[0] == 0) {
+    mt_cfg[0] = 1; mt_cfg[1] = 2;  // measured at batch 64: (4, 8) 1.82 ms/step, (2, 4) 1.59, (1, 2) 1.53, (1, 1) 1.56
+    if (const char* e = getenv("PG_BLOCK_MINTILES")) {
+      int f = 0, b = 0;
+      if (sscanf(e, "%d,%d", &f, &b) == 2 && f > 0 && b > 0) { mt_cfg[0] = f; mt_cfg[1] = b; }
+    }
+  }
+  const int min_tiles = (which & 1) ? mt_cfg[1] : mt_cfg[0];
   const long tiles = (long)N * (L / 16);
   long b = (tiles + 4 * min_tiles - 1) / (4 * min_tiles);
   if (b > cap[which]) b = cap[which];
