@@ -46,6 +46,11 @@ CASES = [
     ("3x3 16->24 30x30", lambda: pg_nn.Conv2d(16, 24, 3, padding=1), (5, 16, 30, 30), {}),
 ]
 SEL = sys.argv[1:]
+if os.environ.get("PG_CAL"):  # traffic calibration for PMC passes: add_kernel reads 2 x 134 MB, writes 134 MB
+    ca, cb = torch.randn(512, 64, 32, 32, device=dev), torch.randn(512, 64, 32, 32, device=dev)
+    for _ in range(5):
+        ops.add(ca, cb)
+    torch.cuda.synchronize()
 for name, ctor, shape, kw in CASES:
     if SEL and not any(k in name for k in SEL):
         continue

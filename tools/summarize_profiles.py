@@ -31,6 +31,9 @@ def per_launch(tag, counter):
 for run, cfg in RUNS.items():
     shutil.copy(os.path.join(src, f"{run}_kernel_stats.csv"), os.path.join(dst, f"r02_{run}_kernel_stats.csv"))
     fetch, write = per_launch(f"{run}_fetch", "FETCH_SIZE"), per_launch(f"{run}_write", "WRITE_SIZE")
+    if not fetch:  # PMC passes of this workload were not collected (see profiles/README.md)
+        print(f"[{run}] kernel stats only")
+        continue
     cal = [k for k in fetch if cfg["cal"] in k][0]
     rf = cfg["read_b"](cfg["batch"]) / (fetch[cal] * 1024)
     wf = cfg["write_b"](cfg["batch"]) / (write[cal] * 1024)
