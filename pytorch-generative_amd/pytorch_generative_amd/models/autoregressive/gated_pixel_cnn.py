@@ -70,6 +70,8 @@ class GatedPixelCNNLayer(nn.Module):
 
 
 class GatedPixelCNN(base.AutoregressiveModel):
+    _row_decode = True  # every layer is row-causal: sample() runs row by row (models/base.py)
+
     def __init__(
         self,
         in_channels=1,

@@ -37,6 +37,8 @@ class CausalResidualBlock(nn.Module):
 
 
 class PixelCNN(base.AutoregressiveModel):
+    _row_decode = True  # every layer is row-causal: sample() runs row by row (models/base.py)
+
     def __init__(
         self,
         in_channels=1,

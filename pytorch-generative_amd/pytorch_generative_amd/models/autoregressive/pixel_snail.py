@@ -86,6 +86,8 @@ class PixelSNAILBlock(nn.Module):
 
 
 class PixelSNAIL(base.AutoregressiveModel):
+    _row_decode = True  # every layer is row-causal: sample() runs row by row (models/base.py)
+
     def __init__(
         self,
         in_channels=1,

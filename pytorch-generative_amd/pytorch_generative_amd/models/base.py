@@ -55,15 +55,50 @@ class AutoregressiveModel(GenerativeModel):
         shape = (n_samples, int(self._c), int(self._h), int(self._w))
         return torch.full(shape, -1.0, device=self.device)
 
+    # Models whose every layer is row-causal set this: sample() then evaluates one image ROW per step
+    # against per-layer caches of the rows above (ops.RowDecode) instead of the whole image.
+    _row_decode = False
+
     @torch.no_grad()
-    def sample(self, n_samples=None, conditioned_on=None):
-        """Generates samples; entries of `conditioned_on` that are >= 0 are kept as given."""
+    def sample(self, n_samples=None, conditioned_on=None, *, incremental=True, return_logits=False):
+        """Generates samples; entries of `conditioned_on` that are >= 0 are kept as given
+        (reference models/base.py:97-120: raster order, `_sample_fn` once per pixel).
+
+        incremental (extension): the reference runs a full forward per pixel; row-causal models here
+        run the forward on the CURRENT ROW only, every convolution reading the few rows above it from
+        a private cache and attention its cached keys / values (same logits, ~H x less arithmetic).
+        return_logits (extension): also returns the (N, C, H, W) logits the draws were made from."""
         canvas = self._start_canvas(n_samples, conditioned_on)
         n, c, h, w = canvas.shape
+        logits_map = torch.zeros_like(canvas) if return_logits else None
+        if incremental and self._row_decode:
+            from pytorch_generative_amd import ops
+
+            for m in self.modules():
+                if hasattr(m, "_row_reset"):
+                    m._row_reset()
+            with ops.RowDecode(h) as ctx:
+                for row in range(h):
+                    ctx.row, ctx.commit = row, False
+                    for col in range(w):
+                        logits = self.forward(canvas[:, :, row:row + 1, :].contiguous())[:, :, 0, col]
+                        if return_logits:
+                            logits_map[:, :, row, col] = logits
+                        drawn = self._sample_fn(logits).view(n, c)
+                        current = canvas[:, :, row, col]
+                        canvas[:, :, row, col] = torch.where(current < 0, drawn, current)
+                    ctx.commit = True  # the row is final: push it into every layer's cache
+                    self.forward(canvas[:, :, row:row + 1, :].contiguous())
+            for m in self.modules():
+                if hasattr(m, "_row_reset"):
+                    m._row_reset()
+            return (canvas, logits_map) if return_logits else canvas
         for row in range(h):
             for col in range(w):
                 logits = self.forward(canvas)[:, :, row, col]
+                if return_logits:
+                    logits_map[:, :, row, col] = logits
                 drawn = self._sample_fn(logits).view(n, c)
                 current = canvas[:, :, row, col]
                 canvas[:, :, row, col] = torch.where(current < 0, drawn, current)
-        return canvas
+        return (canvas, logits_map) if return_logits else canvas

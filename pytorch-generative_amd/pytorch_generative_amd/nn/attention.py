@@ -26,6 +26,11 @@ def image_positional_encoding(shape, device=None):
     """
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
+    ctx = ops.RowDecode.current
+    if ctx is not None:  # row-cached sampling: `shape` is one image row; return that row of the full map
+        n, c, _, w = (int(s) for s in shape)
+        full = _posenc_cached((n, c, ctx.height, w), torch.device(device))
+        return full[:, :, ctx.row:ctx.row + 1, :].contiguous()
     return _posenc_cached(tuple(int(s) for s in shape), torch.device(device))
 
 
@@ -61,11 +66,34 @@ class CausalAttention(nn.Module):
             self._kv.weight._pg_follows = self._q.weight
             self._kv.bias._pg_follows = self._q.bias
 
+    def _row_reset(self):
+        self._row_q = self._row_kv = None
+
+    def _row_forward(self, ctx, x, extra_x, res):
+        """Row-cached sampling: x / extra_x are row `ctx.row`. The row's q / k / v are written into
+        full-size caches and the attention core runs over rows <= ctx.row (everything an earlier
+        position contributed is final); only the current row of the output is kept."""
+        q = self._q(x)
+        kv = self._kv(x if extra_x is None else torch.cat((x, extra_x), dim=1))
+        n, _, _, w = q.shape
+        if getattr(self, "_row_q", None) is None or self._row_q.shape[0] != n or self._row_q.shape[3] != w:
+            self._row_q = torch.zeros((n, q.shape[1], ctx.height, w), device=q.device)
+            self._row_kv = torch.zeros((n, kv.shape[1], ctx.height, w), device=q.device)
+        r = ctx.row
+        self._row_q[:, :, r:r + 1].copy_(q)
+        self._row_kv[:, :, r:r + 1].copy_(kv)
+        out = ops.causal_attention(self._row_q[:, :, :r + 1].contiguous(), self._row_kv[:, :, :r + 1].contiguous(),
+                                   self._n_heads, self._embed_channels, self._out_channels, self._mask_center)
+        return self._proj(out[:, :, r:r + 1].contiguous(), res=res)
+
     def forward(self, x, extra_x=None, *, res=None):
         """x feeds q, k and v; extra_x (optional) is concatenated for k and v only.
 
         `res` (extension) is added to the projected output inside the projection kernel.
         """
+        ctx = ops.RowDecode.current
+        if ctx is not None:
+            return self._row_forward(ctx, x, extra_x, res)
         if extra_x is None and ops.FUSE_PAIR:
             views = ops.conv_pair_views(self._q, self._kv)
             if views is not None:

@@ -64,8 +64,50 @@ class Conv2d(nn.Conv2d):
         out_act / out_pre_scaled / in_post are available)."""
         return (not self._down2) and ops.conv_mfma_ok(x, self.weight, self._conv_spec(), crop)
 
+    # ---- row-cached incremental sampling (ops.RowDecode) ------------------------------------------
+    def _row_reset(self):
+        self._row_band = None
+        self._row_spec_cached = None
+
+    def _row_forward(self, ctx, x, crop, in_act, res, out_act):
+        """x is row `ctx.row` of this convolution's input: evaluates the same row of the output from
+        a band of the k + 1 most recent input rows (k = how far the active taps reach upward)."""
+        if self._down2:
+            raise ValueError("row decode: strided convolutions are not row-causal")
+        spec = self._conv_spec()
+        reach = [spec.pad_h - u for u, _ in spec.fwd_taps]  # rows above the output row a tap reads
+        if min(reach) < 0:
+            raise ValueError("row decode: a tap below the output row (the layer is not row-causal)")
+        k = max(reach)
+        n, c, one, w = x.shape
+        if one != 1:
+            raise ValueError("row decode expects one image row")
+        if getattr(self, "_row_spec_cached", None) is None:
+            self._row_spec_cached = ops.ConvSpec(spec.kh, spec.kw, spec.pad_h - k, spec.pad_w,
+                                                 active=spec.fwd_taps)
+        if k == 0:
+            band = x
+        else:
+            if getattr(self, "_row_band", None) is None or self._row_band.shape != (n, c, k + 1, w):
+                self._row_band = torch.zeros((n, c, k + 1, w), device=x.device, dtype=x.dtype)
+            band = self._row_band
+            band[:, :, k:, :].copy_(x)
+        ow = crop[1] if crop is not None else spec.full_out(1, w)[1]
+        y = ops.conv2d_taps(band, self.weight, self.bias, self._row_spec_cached, out_hw=(1, ow),
+                            in_act=_ACTS[in_act], res=None if out_act is not None else res)
+        if out_act is not None:  # (one row: the unfused epilogue is three tiny launches)
+            y = ops._Act.apply(y, _ACTS[out_act])
+            if res is not None:
+                y = ops.add(y, res)
+        if ctx.commit and k > 0:  # the row is final: it becomes the newest cached row
+            band[:, :, :k, :].copy_(band[:, :, 1:, :].clone())
+        return y
+
     def forward(self, x, *, crop=None, in_act=None, res=None, out_act=None, out_pre_scaled=False,
                 in_post=None):
+        ctx = ops.RowDecode.current
+        if ctx is not None:
+            return self._row_forward(ctx, x, crop, in_act, res, out_act)
         if self._down2:
             if out_act is not None or in_post is not None:
                 raise ValueError("Conv2d: fused output activations are not available for stride 2")

@@ -29,6 +29,30 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class RowDecode:
+    """Context of row-cached incremental sampling (models/base.py).
+
+    While active, the convolutional models' ordinary forward() is called on ONE image row
+    (N, C, 1, W): every layer of these models is row-causal (its output row r depends on input rows
+    <= r only), so nn.Conv2d keeps the last k input rows it needs (k = upward reach of its taps) in a
+    private band buffer and evaluates only the current row; nn.CausalAttention keeps its q / k / v
+    maps; image_positional_encoding returns the current row of the full-size encoding. `commit`
+    marks the pass that runs once a row is final and pushes it into the caches."""
+
+    current = None
+
+    def __init__(self, height):
+        self.height, self.row, self.commit = int(height), 0, False
+
+    def __enter__(self):
+        RowDecode.current = self
+        return self
+
+    def __exit__(self, *exc):
+        RowDecode.current = None
+        return False
+
+
 def _chk(t, name):
     if not t.is_cuda:
         raise RuntimeError(
