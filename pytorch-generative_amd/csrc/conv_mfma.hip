@@ -477,7 +477,7 @@ PG_EXPORT int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, i
   if (OW > 256 || T < 1 || T > PG_MAX_TAPS) return 0;
   if (pg_b3_applicable(Cin, Cout, T, OH, OW, hr, hc)) return PG_CONV_FMT_B3;
   if ((IW % 4) != 0) return 0;  // float4 staging slots
-  if (OH * OW < 64) return 0;  // tiny images (VD-VAE's 4x4 .. 1x1 levels): launch bound either way
+  if (OH * OW < 16) return 0;  // tiny images (VD-VAE's 2x2 / 1x1 levels): launch bound either way
   return (Cin >= 8 && Cout >= 8) ? PG_CONV_FMT_F32 : 0;
 }
 
@@ -572,6 +572,7 @@ PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* b
   static const int px_cap = []() { const char* e = getenv("PG_MF_PX"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 192) ? v : 256; }();
   if (L <= 128) {
     a.NI = 256 / L;
+    if (a.NI > 15) a.NI = 15;  // the image index of a staging slot is packed into 4 bits
     if (a.NI > N) a.NI = N;
     a.TR = OH;
   } else {

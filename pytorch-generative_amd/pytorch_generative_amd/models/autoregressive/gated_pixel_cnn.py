@@ -71,6 +71,8 @@ class GatedPixelCNNLayer(nn.Module):
 
 class GatedPixelCNN(base.AutoregressiveModel):
     _row_decode = True  # every layer is row-causal: sample() runs row by row (models/base.py)
+    _row_graph = True
+    _row_decode_min_batch = 32  # measured: 16 samples 3.7 s row-cached vs 3.2 s full forwards; 256 samples 3.9 s vs ~24 s
 
     def __init__(
         self,

@@ -38,6 +38,7 @@ class CausalResidualBlock(nn.Module):
 
 class PixelCNN(base.AutoregressiveModel):
     _row_decode = True  # every layer is row-causal: sample() runs row by row (models/base.py)
+    _row_graph = True
 
     def __init__(
         self,

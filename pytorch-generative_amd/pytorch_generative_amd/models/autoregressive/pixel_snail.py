@@ -87,6 +87,7 @@ class PixelSNAILBlock(nn.Module):
 
 class PixelSNAIL(base.AutoregressiveModel):
     _row_decode = True  # every layer is row-causal: sample() runs row by row (models/base.py)
+    _row_decode_min_batch = 64  # its row step (attention over a growing prefix) runs eagerly: pays off at larger batches
 
     def __init__(
         self,

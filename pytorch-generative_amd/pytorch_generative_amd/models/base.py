@@ -58,6 +58,8 @@ class AutoregressiveModel(GenerativeModel):
     # Models whose every layer is row-causal set this: sample() then evaluates one image ROW per step
     # against per-layer caches of the rows above (ops.RowDecode) instead of the whole image.
     _row_decode = False
+    _row_graph = False            # the row step is identical for every row (no attention): hipGraph it
+    _row_decode_min_batch = 1     # below this batch the per-pixel full forward is used (launch-bound row steps)
 
     @torch.no_grad()
     def sample(self, n_samples=None, conditioned_on=None, *, incremental=True, return_logits=False):
@@ -71,27 +73,71 @@ class AutoregressiveModel(GenerativeModel):
         canvas = self._start_canvas(n_samples, conditioned_on)
         n, c, h, w = canvas.shape
         logits_map = torch.zeros_like(canvas) if return_logits else None
-        if incremental and self._row_decode:
+        if incremental and self._row_decode and (n >= self._row_decode_min_batch or return_logits):
             from pytorch_generative_amd import ops
 
-            for m in self.modules():
-                if hasattr(m, "_row_reset"):
-                    m._row_reset()
+            def reset():
+                for m in self.modules():
+                    if hasattr(m, "_row_reset"):
+                        m._row_reset()
+
+            reset()
+            row_in = torch.empty((n, c, 1, w), device=canvas.device, dtype=canvas.dtype)
             with ops.RowDecode(h) as ctx:
+                # Row-invariant models (no attention): the row step touches the same buffers for every
+                # row, so it is captured ONCE into two hipGraphs (evaluate / evaluate-and-commit) and
+                # replayed H*W + H times — the eager row step is ~100 tiny launches, launch bound.
+                step_graph = commit_graph = step_out = None
+                if self._row_graph:
+                    try:
+                        row_in.fill_(0.0)
+                        side = torch.cuda.Stream()
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):  # warm-up: allocates every band buffer
+                            ctx.commit = False
+                            self.forward(row_in)
+                            ctx.commit = True
+                            self.forward(row_in)
+                        torch.cuda.current_stream().wait_stream(side)
+                        step_graph, commit_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                        ctx.commit = False
+                        with torch.cuda.graph(step_graph, capture_error_mode="thread_local"):
+                            step_out = self.forward(row_in)
+                        ctx.commit = True
+                        with torch.cuda.graph(commit_graph, capture_error_mode="thread_local"):
+                            self.forward(row_in)
+                        for m in self.modules():  # the warm-up pushed rows of zeros: start clean
+                            band = getattr(m, "_row_band", None)
+                            if band is not None:
+                                band.zero_()
+                    except Exception as e:  # noqa: BLE001 — capture is an optimisation only
+                        import os
+                        if os.environ.get("PG_DEBUG"):
+                            print(f"[sample] row-step capture failed: {type(e).__name__}: {e}")
+                        step_graph = commit_graph = None
+                        torch.cuda.synchronize()
+                        reset()
                 for row in range(h):
                     ctx.row, ctx.commit = row, False
                     for col in range(w):
-                        logits = self.forward(canvas[:, :, row:row + 1, :].contiguous())[:, :, 0, col]
+                        row_in.copy_(canvas[:, :, row:row + 1, :])
+                        if step_graph is not None:
+                            step_graph.replay()
+                            logits = step_out[:, :, 0, col]
+                        else:
+                            logits = self.forward(row_in)[:, :, 0, col]
                         if return_logits:
                             logits_map[:, :, row, col] = logits
                         drawn = self._sample_fn(logits).view(n, c)
                         current = canvas[:, :, row, col]
                         canvas[:, :, row, col] = torch.where(current < 0, drawn, current)
                     ctx.commit = True  # the row is final: push it into every layer's cache
-                    self.forward(canvas[:, :, row:row + 1, :].contiguous())
-            for m in self.modules():
-                if hasattr(m, "_row_reset"):
-                    m._row_reset()
+                    row_in.copy_(canvas[:, :, row:row + 1, :])
+                    if commit_graph is not None:
+                        commit_graph.replay()
+                    else:
+                        self.forward(row_in)
+            reset()
             return (canvas, logits_map) if return_logits else canvas
         for row in range(h):
             for col in range(w):
