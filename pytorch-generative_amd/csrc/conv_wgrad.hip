@@ -538,6 +538,11 @@ inline int pad_stride(int s) {  // smallest s' >= s with s' % 32 == 2
 
 }  // namespace
 
+// conv_wgrad_b3.hip: the bf16x3 kernel for the shapes it takes (returns the partial rows it wrote)
+int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_stride, long max_rows,
+                       int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
+                       const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st);
+
 static long wgrad_max_rows(int Cout, int Cin) {
   const long chunks = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
   const long g = 512 / chunks;
@@ -589,6 +594,16 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     launch_reduce(workspace, stride, (int)gx, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
     PG_LAUNCH_CHECK("pg_conv2d_wgrad(reduce)");
     return 0;
+  }
+  {
+    const int g = pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
+                                     Cout, OH, OW, T, tap_dr, tap_dc, in_act, st);
+    PG_REQUIRE(g >= 0, PG_EINVAL, "pg_conv2d_wgrad(bf16x3): launch failed");
+    if (g > 0) {
+      launch_reduce(workspace, stride, g, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
+      PG_LAUNCH_CHECK("pg_conv2d_wgrad(reduce)");
+      return 0;
+    }
   }
   WgArgs a;
   a.x = x; a.dy = dy; a.dw = dw; a.db = db;

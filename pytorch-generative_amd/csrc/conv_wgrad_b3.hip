@@ -1,0 +1,389 @@
+// conv_wgrad_b3.hip — convolution weight/bias gradient with its fp32 products evaluated on the bf16
+// matrix pipe ("bf16x3", see conv_b3.hip): dy = dh + dm + dl, x = xh + xm + xl (exact 3-way bf16
+// splits) and   dy.x = dh.xh + dh.xm + dm.xh + dh.xl + dl.xh + dm.xm   (6 x v_mfma_f32_16x16x32_bf16),
+// fp32 accumulation. Same reference call sites as conv_wgrad.hip (the weight/bias outputs of
+// aten::convolution_backward behind loss.backward(), trainer.py:180; unmasked taps,
+// nn/convolution.py:42). conv_wgrad.hip keeps every shape this file does not take.
+//
+//   dw[co][ci][t] = sum_{n,r,c} dy[n,co,r,c] * act(x[n,ci,r+dr_t,c+dc_t])      db[co] = sum dy
+//
+// GEMM view: M = co, N = ci, K = output pixels. One K step = 32 pixels = four "pixel blocks" of 8
+// consecutive pixels of one image row (W % 8 == 0): lane (i|j = lane & 15, kg = lane >> 4) holds the
+// 8 pixels of block 4 ks + kg for dy channel i (A) / x channel j (B).
+// The tap shift lives on the K axis here, and a packed-bf16 fragment cannot be read at an odd
+// element offset, so x is staged once per DISTINCT COLUMN SHIFT dc in {-1, 0, +1} ("copies":
+// copy_dc[row][c] = x[row][c + dc], zero outside the image — the column halo disappears); the row
+// shift dr is a whole number of pixel blocks. LDS entries are 16 bytes (8 bf16):
+//   dy: [piece][co tile][pixel block][16 channels]      x: [copy][piece][ci tile][pixel block][16 channels]
+// so a fragment read is `scalar base + lane` (ds_read_b128, 256 B per 16 lanes: conflict free) and a
+// staging thread (= 8 pixels of one channel, channel fastest across lanes) writes whole entries.
+// A workgroup owns 64 co x 32 ci x all taps, walks pixel tiles of TR rows with the next tile's
+// loads in flight under the MFMA loop, and writes ONE row of partial sums; conv_wgrad.hip's
+// deterministic reduction adds the rows into dw / db.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WB_THREADS = 256;
+constexpr int WB_CO = 64;   // dy channels per workgroup (4 MFMA row tiles: 2 per wave)
+constexpr int WB_CI = 32;   // x channels per workgroup (2 MFMA column tiles: 1 per wave)
+constexpr int WB_DS = 3;    // staging slots (8 pixels each) per thread per tile: dy
+constexpr int WB_XS = 3;    // ... and x
+constexpr int WB_MAXT = 9;
+constexpr int WB_LDS_BUDGET = 76 * 1024;  // two workgroups per CU
+
+struct WbArgs {
+  const float* x; const float* dy; float* part;
+  long part_stride;
+  int N, Cin, Cout, H, W, T;
+  int TR, xh, tiles_per_img, total_tiles, min_dr;
+  int PBR, dpb, xpb, ksteps;   // pixel blocks per row / per dy tile / per x tile; K steps per tile
+  int dslots, xslots;
+  int ndc, dcs[3];             // distinct column shifts (copies)
+  int x_off16;                 // first 16-byte entry of the x area
+  int in_act, has_bias;
+  int tap_base[WB_MAXT];       // entry offset of tap t inside the x area: copy plane + row-shift blocks
+};
+
+__device__ __forceinline__ unsigned int pack2(__bf16 a, __bf16 b) {
+  return (unsigned int)__builtin_bit_cast(unsigned short, a) |
+         ((unsigned int)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// 8 fp32 -> three bf16x8 (h, m, l pieces), element 2i in the low half of dword i
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
+  __bf16 hh[8], mm[8], ll[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    hh[i] = (__bf16)x[i];
+    const float r1 = x[i] - (float)hh[i];
+    mm[i] = (__bf16)r1;
+    ll[i] = (__bf16)(r1 - (float)mm[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pack2(hh[2 * i], hh[2 * i + 1]);
+    m[i] = pack2(mm[2 * i], mm[2 * i + 1]);
+    l[i] = pack2(ll[2 * i], ll[2 * i + 1]);
+  }
+}
+
+__device__ __forceinline__ void split1(float x, unsigned int& h, unsigned int& m, unsigned int& l) {
+  const __bf16 hh = (__bf16)x;
+  const float r1 = x - (float)hh;
+  const __bf16 mm = (__bf16)r1;
+  const __bf16 ll = (__bf16)(r1 - (float)mm);
+  h = __builtin_bit_cast(unsigned short, hh);
+  m = __builtin_bit_cast(unsigned short, mm);
+  l = __builtin_bit_cast(unsigned short, ll);
+}
+
+// entry of the copy shifted by one pixel: prev = the pixel left of the entry (dc = -1) ...
+__device__ __forceinline__ u32x4 shift_right1(const u32x4 d, unsigned int prev) {
+  u32x4 r;
+  r[0] = prev | (d[0] << 16);
+  r[1] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+  r[2] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+  r[3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+  return r;
+}
+// ... next = the pixel right of the entry (dc = +1)
+__device__ __forceinline__ u32x4 shift_left1(const u32x4 d, unsigned int next) {
+  u32x4 r;
+  r[0] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+  r[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+  r[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+  r[3] = (d[3] >> 16) | (next << 16);
+  return r;
+}
+
+#define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
+
+template <int T>
+__global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wi = wave >> 1;   // co half (2 row tiles), ci tile of this wave
+  const int co0 = blockIdx.y * WB_CO, ci0 = blockIdx.z * WB_CI;
+  const int dplane = 4 * a.dpb * 16;         // entries per dy piece plane
+  const int xplane = 2 * a.xpb * 16;         // entries per x (copy, piece) plane
+
+  // ---- staging slots: the same (channel, tile row, column block) for every tile
+  int d_goff[WB_DS], d_meta[WB_DS], x_goff[WB_XS], x_meta[WB_XS];  // meta: LDS entry | tile row << 20
+  int x_edge = 0;  // bit k: slot k is the first column block of its row; bit 8 + k: the last
+#pragma unroll
+  for (int k = 0; k < WB_DS; ++k) {
+    int e = tid + k * WB_THREADS;
+    const bool in = e < a.dslots;
+    e = in ? e : 0;
+    const int i = e & 15; e >>= 4;
+    const int cb = e % a.PBR; e /= a.PBR;
+    const int tr = e % a.TR;
+    const int cot = e / a.TR;
+    d_goff[k] = in ? ((cot * 16 + i) * a.H + tr) * a.W + 8 * cb : -1;
+    d_meta[k] = ((cot * a.dpb + tr * a.PBR + cb) * 16 + i) | (tr << 20);
+  }
+#pragma unroll
+  for (int k = 0; k < WB_XS; ++k) {
+    int e = tid + k * WB_THREADS;
+    const bool in = e < a.xslots;
+    e = in ? e : 0;
+    const int i = e & 15; e >>= 4;
+    const int cb = e % a.PBR; e /= a.PBR;
+    const int tr = e % a.xh;
+    const int cit = e / a.xh;
+    x_goff[k] = in ? ((cit * 16 + i) * a.H + tr) * a.W + 8 * cb : -1;
+    x_meta[k] = (a.x_off16 + (cit * a.xpb + tr * a.PBR + cb) * 16 + i) | (tr << 20);
+    if (cb == 0) x_edge |= 1 << k;
+    if (cb == a.PBR - 1) x_edge |= 256 << k;
+  }
+  bool want_m1 = false, want_p1 = false;  // wave-uniform
+  for (int v = 0; v < a.ndc; ++v) {
+    want_m1 |= a.dcs[v] == -1;
+    want_p1 |= a.dcs[v] == 1;
+  }
+
+  float4 dv[WB_DS][2], xv[WB_XS][2];
+  float xe[WB_XS][2];  // the pixel left / right of the slot's 8
+#pragma unroll
+  for (int k = 0; k < WB_DS; ++k) dv[k][0] = dv[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < WB_XS; ++k) {
+    xv[k][0] = xv[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    xe[k][0] = xe[k][1] = 0.f;
+  }
+  int dok = 0, xok = 0;
+
+#define PG_WB_ISSUE(TILE)                                                                          \
+  {                                                                                                \
+    const int n_ = (TILE) / a.tiles_per_img;                                                       \
+    const int row0_ = ((TILE) - n_ * a.tiles_per_img) * a.TR;                                      \
+    const float* dyb_ = a.dy + (((long)n_ * a.Cout + co0) * a.H + row0_) * (long)a.W;              \
+    const float* xb_ = a.x + (((long)n_ * a.Cin + ci0) * a.H + (row0_ + a.min_dr)) * (long)a.W;    \
+    dok = 0; xok = 0;                                                                              \
+    _Pragma("unroll") for (int k = 0; k < WB_DS; ++k) {                                            \
+      if (d_goff[k] >= 0 && row0_ + (d_meta[k] >> 20) < a.H) {                                     \
+        const float4* p_ = reinterpret_cast<const float4*>(dyb_ + d_goff[k]);                      \
+        dv[k][0] = p_[0]; dv[k][1] = p_[1];                                                        \
+        dok |= 1 << k;                                                                             \
+      }                                                                                            \
+    }                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < WB_XS; ++k) {                                            \
+      const int ir_ = row0_ + a.min_dr + (x_meta[k] >> 20);                                        \
+      if (x_goff[k] >= 0 && ir_ >= 0 && ir_ < a.H) {                                               \
+        const float* q_ = xb_ + x_goff[k];                                                         \
+        const float4* p_ = reinterpret_cast<const float4*>(q_);                                    \
+        xv[k][0] = p_[0]; xv[k][1] = p_[1];                                                        \
+        if (want_m1) xe[k][0] = ((x_edge >> k) & 1) ? 0.f : q_[-1];                                \
+        if (want_p1) xe[k][1] = ((x_edge >> (8 + k)) & 1) ? 0.f : q_[8];                           \
+        xok |= 1 << k;                                                                             \
+      }                                                                                            \
+    }                                                                                              \
+  }
+
+#define PG_WB_COMMIT_X(ACT)                                                                        \
+  _Pragma("unroll") for (int k = 0; k < WB_XS; ++k) {                                              \
+    if (x_goff[k] >= 0) {                                                                          \
+      const bool ld_ = (xok >> k) & 1;                                                             \
+      const float r_[8] = {xv[k][0].x, xv[k][0].y, xv[k][0].z, xv[k][0].w,                         \
+                           xv[k][1].x, xv[k][1].y, xv[k][1].z, xv[k][1].w};                        \
+      float e_[8];                                                                                 \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) e_[c] = ld_ ? pg_apply_act(r_[c], ACT) : 0.f;  \
+      u32x4 p_[3];                                                                                 \
+      split8(e_, p_[0], p_[1], p_[2]);                                                             \
+      const int ent_ = x_meta[k] & 0xfffff;                                                        \
+      _Pragma("unroll") for (int v = 0; v < 3; ++v) {                                              \
+        if (v < a.ndc) {                                                                           \
+          const int dc_ = a.dcs[v];                                                                \
+          u32x4* dst_ = lds16 + ent_ + v * 3 * xplane;                                             \
+          if (dc_ == 0) {                                                                          \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) dst_[q * xplane] = p_[q];                \
+          } else {                                                                                 \
+            unsigned int s_[3];                                                                    \
+            split1(ld_ ? pg_apply_act(dc_ < 0 ? xe[k][0] : xe[k][1], ACT) : 0.f, s_[0], s_[1], s_[2]);     \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q)                                          \
+              dst_[q * xplane] = dc_ < 0 ? shift_right1(p_[q], s_[q]) : shift_left1(p_[q], s_[q]); \
+          }                                                                                        \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+  }
+
+  f32x4 acc[2][T];
+  f32x4 accb[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool bias_wave = a.has_bias && wi == 0 && blockIdx.z == 0;  // wave-uniform
+  bf16x8 ones;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
+
+  const bf16x8* L = reinterpret_cast<const bf16x8*>(lds16) + lane;
+  const int a_base = 2 * wc * a.dpb * 16;
+  int b_base[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) b_base[t] = a.x_off16 + a.tap_base[t] + wi * a.xpb * 16;
+
+  int tile = blockIdx.x;
+  if (tile < a.total_tiles) PG_WB_ISSUE(tile)
+  for (; tile < a.total_tiles; tile += gridDim.x) {
+    __syncthreads();  // the previous tile's fragment reads are done
+#pragma unroll
+    for (int k = 0; k < WB_DS; ++k) {
+      if (d_goff[k] >= 0) {
+        const bool ld = (dok >> k) & 1;
+        const float r[8] = {dv[k][0].x, dv[k][0].y, dv[k][0].z, dv[k][0].w,
+                            dv[k][1].x, dv[k][1].y, dv[k][1].z, dv[k][1].w};
+        float e[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) e[c] = ld ? r[c] : 0.f;
+        u32x4 h, m, l;
+        split8(e, h, m, l);
+        u32x4* dst = lds16 + (d_meta[k] & 0xfffff);
+        dst[0] = h; dst[dplane] = m; dst[2 * dplane] = l;
+      }
+    }
+    switch (a.in_act) {  // wave-uniform
+      case PG_ACT_RELU: PG_WB_COMMIT_X(PG_ACT_RELU) break;
+      case PG_ACT_ELU:  PG_WB_COMMIT_X(PG_ACT_ELU) break;
+      case PG_ACT_GELU: PG_WB_COMMIT_X(PG_ACT_GELU) break;
+      default:          PG_WB_COMMIT_X(PG_ACT_NONE) break;
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.total_tiles) PG_WB_ISSUE(tile + (int)gridDim.x)
+    // ---- MFMA over the tile's K steps
+    for (int ks = 0; ks < a.ksteps; ++ks) {
+      const bf16x8* Lk = L + ks * 64;
+      bf16x8 af[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[m][p] = Lk[a_base + (p * 4 + m) * a.dpb * 16];
+      if (bias_wave) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) accb[m] = MFMA16B(af[m][p], ones, accb[m]);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        bf16x8 bf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[p] = Lk[b_base[t] + p * xplane];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          f32x4 c = acc[m][t];
+          c = MFMA16B(af[m][2], bf[0], c);  // l.h
+          c = MFMA16B(af[m][0], bf[2], c);  // h.l
+          c = MFMA16B(af[m][1], bf[1], c);  // m.m
+          c = MFMA16B(af[m][1], bf[0], c);  // m.h
+          c = MFMA16B(af[m][0], bf[1], c);  // h.m
+          c = MFMA16B(af[m][0], bf[0], c);  // h.h
+          acc[m][t] = c;
+        }
+      }
+    }
+  }
+#undef PG_WB_ISSUE
+#undef PG_WB_COMMIT_X
+
+  // ---- this workgroup's row of partial sums: D[row = (lane >> 4) * 4 + r][col = lane & 15]
+  float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
+  const int ci = ci0 + wi * 16 + (lane & 15);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int co_b = co0 + (2 * wc + m) * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        prow[((size_t)(co_b + r) * a.Cin + ci) * T + t] = acc[m][t][r];
+    if (bias_wave && (lane & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) prow[(size_t)a.Cout * a.Cin * T + co_b + r] = accb[m][r];
+    }
+  }
+}
+
+}  // namespace
+
+// Launches the bf16x3 kernel when it takes the problem; returns the number of partial rows written
+// (the caller runs the reduction over them), 0 when the shape stays on the fp32 kernels, < 0 on a
+// launch error. Called by pg_conv2d_wgrad (conv_wgrad.hip) only.
+int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_stride, long max_rows,
+                       int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
+                       const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st) {
+  static const bool on = []() { const char* e = getenv("PG_WGRAD_B3"); return !(e && e[0] == '0'); }();
+  if (!on) return 0;
+  if (IH != OH || IW != OW || OW % 8 != 0 || Cout % WB_CO != 0 || Cin % WB_CI != 0) return 0;
+  if (!(T == 2 || T == 3 || T == 4 || T == 6 || T == 9)) return 0;
+  if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return 0;
+  WbArgs a;
+  int min_dr = tap_dr[0], max_dr = tap_dr[0];
+  a.ndc = 0;
+  int copy_of[WB_MAXT];
+  for (int t = 0; t < T; ++t) {
+    if (tap_dc[t] < -1 || tap_dc[t] > 1) return 0;
+    min_dr = tap_dr[t] < min_dr ? tap_dr[t] : min_dr;
+    max_dr = tap_dr[t] > max_dr ? tap_dr[t] : max_dr;
+    int v = 0;
+    while (v < a.ndc && a.dcs[v] != tap_dc[t]) ++v;
+    if (v == a.ndc) a.dcs[a.ndc++] = tap_dc[t];
+    copy_of[t] = v;
+  }
+  for (int v = a.ndc; v < 3; ++v) a.dcs[v] = 0;
+  const int hr = max_dr - min_dr;
+  const int PBR = OW / 8;
+  // tile rows: K steps of 4 pixel blocks, staging slots within the per-thread caps, LDS within budget
+  int TR = 0;
+  for (int tr = 1; tr <= OH + 3; ++tr) {
+    if ((tr * PBR) % 4 != 0) continue;
+    const long dslots = (long)WB_CO * tr * PBR, xslots = (long)WB_CI * (tr + hr) * PBR;
+    const long bytes = (3 * dslots + 3L * a.ndc * xslots) * 16;
+    if (dslots > WB_DS * WB_THREADS || xslots > WB_XS * WB_THREADS || bytes > WB_LDS_BUDGET) break;
+    TR = tr;
+    if (tr >= OH) break;
+  }
+  if (TR == 0) return 0;
+  a.x = x; a.dy = dy; a.part = part; a.part_stride = part_stride;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = OH; a.W = OW; a.T = T;
+  a.TR = TR; a.xh = TR + hr; a.min_dr = min_dr;
+  a.tiles_per_img = (OH + TR - 1) / TR;
+  a.total_tiles = N * a.tiles_per_img;
+  a.PBR = PBR; a.dpb = TR * PBR; a.xpb = a.xh * PBR; a.ksteps = a.dpb / 4;
+  a.dslots = WB_CO * a.dpb; a.xslots = WB_CI * a.xpb;
+  a.x_off16 = 3 * 4 * a.dpb * 16;
+  a.in_act = in_act; a.has_bias = has_bias;
+  const int xplane = 2 * a.xpb * 16;
+  for (int t = 0; t < T; ++t) a.tap_base[t] = copy_of[t] * 3 * xplane + (tap_dr[t] - min_dr) * PBR * 16;
+  for (int t = T; t < WB_MAXT; ++t) a.tap_base[t] = 0;
+  const size_t shmem = ((size_t)a.x_off16 + (size_t)a.ndc * 3 * xplane) * 16;
+  const int co_chunks = Cout / WB_CO, ci_chunks = Cin / WB_CI;
+  long G = 512 / ((long)co_chunks * ci_chunks);
+  if (G < 16) G = 16;
+  if (G > a.total_tiles) G = a.total_tiles;
+  if (G > max_rows) G = max_rows;
+  dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
+#define PG_WB(TT) hipLaunchKernelGGL((conv_wgrad_b3_kernel<TT>), grid, dim3(WB_THREADS), shmem, st, a)
+  switch (T) {
+    case 2: PG_WB(2); break;
+    case 3: PG_WB(3); break;
+    case 4: PG_WB(4); break;
+    case 6: PG_WB(6); break;
+    default: PG_WB(9); break;
+  }
+#undef PG_WB
+  if (hipGetLastError() != hipSuccess) return -1;
+  return (int)G;
+}
