@@ -47,6 +47,8 @@ struct WbArgs {
   int ndc, dcs[3];             // distinct column shifts (copies)
   int x_off16;                 // first 16-byte entry of the x area
   int in_act, has_bias;
+  int dephase;                 // experiment (PG_WB_DEPHASE = mode * 100 + n): delay half of the workgroups by n x 1024 cycles
+  int dbg;                     // ablation switches (PG_WB_DBG: 1 no loads, 2 no commit, 4 no MFMA), 0 in production
   int tap_base[WB_MAXT];       // entry offset of tap t inside the x area: copy plane + row-shift blocks
 };
 
@@ -181,8 +183,10 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
         const float* q_ = xb_ + x_goff[k];                                                         \
         const float4* p_ = reinterpret_cast<const float4*>(q_);                                    \
         xv[k][0] = p_[0]; xv[k][1] = p_[1];                                                        \
-        if (want_m1) xe[k][0] = ((x_edge >> k) & 1) ? 0.f : q_[-1];                                \
-        if (want_p1) xe[k][1] = ((x_edge >> (8 + k)) & 1) ? 0.f : q_[8];                           \
+        /* edge slots load an in-image neighbour instead (zeroed at commit): no select on a   */   \
+        /* loaded value here, it would put an s_waitcnt vmcnt into the issue phase             */   \
+        if (want_m1) xe[k][0] = q_[((x_edge >> k) & 1) ? 0 : -1];                                  \
+        if (want_p1) xe[k][1] = q_[((x_edge >> (8 + k)) & 1) ? 7 : 8];                             \
         xok |= 1 << k;                                                                             \
       }                                                                                            \
     }                                                                                              \
@@ -207,7 +211,8 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
             _Pragma("unroll") for (int q = 0; q < 3; ++q) dst_[q * xplane] = p_[q];                \
           } else {                                                                                 \
             unsigned int s_[3];                                                                    \
-            split1(ld_ ? pg_apply_act(dc_ < 0 ? xe[k][0] : xe[k][1], ACT) : 0.f, s_[0], s_[1], s_[2]);     \
+            const bool edge_ = (x_edge >> (dc_ < 0 ? k : 8 + k)) & 1;                              \
+            split1(ld_ && !edge_ ? pg_apply_act(dc_ < 0 ? xe[k][0] : xe[k][1], ACT) : 0.f, s_[0], s_[1], s_[2]);     \
             _Pragma("unroll") for (int q = 0; q < 3; ++q)                                          \
               dst_[q * xplane] = dc_ < 0 ? shift_right1(p_[q], s_[q]) : shift_left1(p_[q], s_[q]); \
           }                                                                                        \
@@ -236,9 +241,31 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
   for (int t = 0; t < T; ++t) b_base[t] = a.x_off16 + a.tap_base[t] + wi * a.xpb * 16;
 
   int tile = blockIdx.x;
-  if (tile < a.total_tiles) PG_WB_ISSUE(tile)
+  if (tile < a.total_tiles && !(a.dbg & 1)) PG_WB_ISSUE(tile)
+  if (a.dephase) {
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int nb = gridDim.x * gridDim.y * gridDim.z;
+    const int mode = a.dephase / 100;
+    const bool late = mode == 1 ? lin >= nb / 2 : (mode == 2 ? (lin & 1) : ((lin >> 8) & 1));
+    if (late)
+      for (int i = 0; i < a.dephase % 100; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   for (; tile < a.total_tiles; tile += gridDim.x) {
     __syncthreads();  // the previous tile's fragment reads are done
+    // every prefetch register is "used" here on every path: ONE s_waitcnt vmcnt(0) lands at this
+    // point. Without it the slots whose commit is skipped leave their loads pending in the
+    // compiler's model and it puts a vmcnt(0) in front of every slot of the next issue phase
+    // (measured: the load phase did not overlap the MFMA loop at all).
+#pragma unroll
+    for (int k = 0; k < WB_DS; ++k)
+      asm volatile("" :: "v"(dv[k][0].x), "v"(dv[k][0].y), "v"(dv[k][0].z), "v"(dv[k][0].w),
+                         "v"(dv[k][1].x), "v"(dv[k][1].y), "v"(dv[k][1].z), "v"(dv[k][1].w));
+#pragma unroll
+    for (int k = 0; k < WB_XS; ++k)
+      asm volatile("" :: "v"(xv[k][0].x), "v"(xv[k][0].y), "v"(xv[k][0].z), "v"(xv[k][0].w),
+                         "v"(xv[k][1].x), "v"(xv[k][1].y), "v"(xv[k][1].z), "v"(xv[k][1].w),
+                         "v"(xe[k][0]), "v"(xe[k][1]));
+    if (!(a.dbg & 2)) {
 #pragma unroll
     for (int k = 0; k < WB_DS; ++k) {
       if (d_goff[k] >= 0) {
@@ -260,9 +287,11 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
       case PG_ACT_GELU: PG_WB_COMMIT_X(PG_ACT_GELU) break;
       default:          PG_WB_COMMIT_X(PG_ACT_NONE) break;
     }
+    }
     __syncthreads();
-    if (tile + (int)gridDim.x < a.total_tiles) PG_WB_ISSUE(tile + (int)gridDim.x)
+    if (tile + (int)gridDim.x < a.total_tiles && !(a.dbg & 1)) PG_WB_ISSUE(tile + (int)gridDim.x)
     // ---- MFMA over the tile's K steps
+    if (!(a.dbg & 4))
     for (int ks = 0; ks < a.ksteps; ++ks) {
       const bf16x8* Lk = L + ks * 64;
       bf16x8 af[2][3];
@@ -365,6 +394,10 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   a.dslots = WB_CO * a.dpb; a.xslots = WB_CI * a.xpb;
   a.x_off16 = 3 * 4 * a.dpb * 16;
   a.in_act = in_act; a.has_bias = has_bias;
+  static const int dbg = []() { const char* e = getenv("PG_WB_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
+  static const int dephase = []() { const char* e = getenv("PG_WB_DEPHASE"); return e ? atoi(e) : 0; }();
+  a.dephase = dephase;
   const int xplane = 2 * a.xpb * 16;
   for (int t = 0; t < T; ++t) a.tap_base[t] = copy_of[t] * 3 * xplane + (tap_dr[t] - min_dr) * PBR * 16;
   for (int t = T; t < WB_MAXT; ++t) a.tap_base[t] = 0;
