@@ -47,42 +47,43 @@ struct WbArgs {
   int ndc, dcs[3];             // distinct column shifts (copies)
   int x_off16;                 // first 16-byte entry of the x area
   int in_act, has_bias;
-  int dephase;                 // experiment (PG_WB_DEPHASE = mode * 100 + n): delay half of the workgroups by n x 1024 cycles
   int dbg;                     // ablation switches (PG_WB_DBG: 1 no loads, 2 no commit, 4 no MFMA), 0 in production
   int tap_base[WB_MAXT];       // entry offset of tap t inside the x area: copy plane + row-shift blocks
 };
 
-__device__ __forceinline__ unsigned int pack2(__bf16 a, __bf16 b) {
-  return (unsigned int)__builtin_bit_cast(unsigned short, a) |
-         ((unsigned int)__builtin_bit_cast(unsigned short, b) << 16);
-}
-
-// 8 fp32 -> three bf16x8 (h, m, l pieces), element 2i in the low half of dword i
+// 8 fp32 -> three bf16x8 (h, m, l pieces), element 2i in the low half of dword i.
+// The pieces are TRUNCATIONS (h = top 16 bits of x, m = top 16 bits of x - h, l = x - h - m, whose
+// low 16 bits are zero because 24 = 8 + 8 + 8 significand bits): h + m + l == x exactly, and a piece
+// costs and + sub instead of the convert / unpack / sub of a round-to-nearest split (the staging
+// arithmetic is what bounds this kernel). Against round-to-nearest pieces the dropped products
+// m.l + l.m + l.l are up to 2^-23 |dy.x| instead of 2^-24 and share x.dy's sign (a relative bias of
+// ~3e-8): still below one fp32 rounding of the product.
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
-  __bf16 hh[8], mm[8], ll[8];
+  unsigned int xb[8], r1b[8], r2b[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    hh[i] = (__bf16)x[i];
-    const float r1 = x[i] - (float)hh[i];
-    mm[i] = (__bf16)r1;
-    ll[i] = (__bf16)(r1 - (float)mm[i]);
+    xb[i] = __builtin_bit_cast(unsigned int, x[i]);
+    const float r1 = x[i] - __builtin_bit_cast(float, xb[i] & 0xffff0000u);
+    r1b[i] = __builtin_bit_cast(unsigned int, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, r1b[i] & 0xffff0000u);
+    r2b[i] = __builtin_bit_cast(unsigned int, r2);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = pack2(hh[2 * i], hh[2 * i + 1]);
-    m[i] = pack2(mm[2 * i], mm[2 * i + 1]);
-    l[i] = pack2(ll[2 * i], ll[2 * i + 1]);
+  for (int i = 0; i < 4; ++i) {  // v_perm_b32: {hi16(odd element), hi16(even element)}
+    h[i] = __builtin_amdgcn_perm(xb[2 * i + 1], xb[2 * i], 0x07060302u);
+    m[i] = __builtin_amdgcn_perm(r1b[2 * i + 1], r1b[2 * i], 0x07060302u);
+    l[i] = __builtin_amdgcn_perm(r2b[2 * i + 1], r2b[2 * i], 0x07060302u);
   }
 }
 
 __device__ __forceinline__ void split1(float x, unsigned int& h, unsigned int& m, unsigned int& l) {
-  const __bf16 hh = (__bf16)x;
-  const float r1 = x - (float)hh;
-  const __bf16 mm = (__bf16)r1;
-  const __bf16 ll = (__bf16)(r1 - (float)mm);
-  h = __builtin_bit_cast(unsigned short, hh);
-  m = __builtin_bit_cast(unsigned short, mm);
-  l = __builtin_bit_cast(unsigned short, ll);
+  const unsigned int xb = __builtin_bit_cast(unsigned int, x);
+  const float r1 = x - __builtin_bit_cast(float, xb & 0xffff0000u);
+  const unsigned int r1b = __builtin_bit_cast(unsigned int, r1);
+  const float r2 = r1 - __builtin_bit_cast(float, r1b & 0xffff0000u);
+  h = xb >> 16;
+  m = r1b >> 16;
+  l = __builtin_bit_cast(unsigned int, r2) >> 16;
 }
 
 // entry of the copy shifted by one pixel: prev = the pixel left of the entry (dc = -1) ...
@@ -242,14 +243,6 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
 
   int tile = blockIdx.x;
   if (tile < a.total_tiles && !(a.dbg & 1)) PG_WB_ISSUE(tile)
-  if (a.dephase) {
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int nb = gridDim.x * gridDim.y * gridDim.z;
-    const int mode = a.dephase / 100;
-    const bool late = mode == 1 ? lin >= nb / 2 : (mode == 2 ? (lin & 1) : ((lin >> 8) & 1));
-    if (late)
-      for (int i = 0; i < a.dephase % 100; ++i) __builtin_amdgcn_s_sleep(16);
-  }
   for (; tile < a.total_tiles; tile += gridDim.x) {
     __syncthreads();  // the previous tile's fragment reads are done
     // every prefetch register is "used" here on every path: ONE s_waitcnt vmcnt(0) lands at this
@@ -305,23 +298,35 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
 #pragma unroll
           for (int p = 0; p < 3; ++p) accb[m] = MFMA16B(af[m][p], ones, accb[m]);
       }
+      // taps in groups of two: four independent accumulators per product (a dependent
+      // v_mfma_f32_16x16x32_bf16 every 2nd issue stalls the matrix pipe), the next group's
+      // fragments in flight under the current group's MFMAs
+      constexpr int NG = (T + 1) / 2;
+      bf16x8 bf[2][2][3];
+#define PG_WB_LOAD_B(BUF, G)                                                                       \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
+    if (2 * (G) + u < T)                                                                           \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                \
+        bf[BUF][u][p] = Lk[b_base[2 * (G) + u < T ? 2 * (G) + u : 0] + p * xplane];
+#define PG_WB_PRODUCT(PA, PB, G)                                                                   \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
+    if (2 * (G) + u < T)                                                                           \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
+        acc[m][2 * (G) + u < T ? 2 * (G) + u : 0] =                                                \
+            MFMA16B(af[m][PA], bf[(G) & 1][u][PB], acc[m][2 * (G) + u < T ? 2 * (G) + u : 0]);
+      PG_WB_LOAD_B(0, 0)
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        bf16x8 bf[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) bf[p] = Lk[b_base[t] + p * xplane];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          f32x4 c = acc[m][t];
-          c = MFMA16B(af[m][2], bf[0], c);  // l.h
-          c = MFMA16B(af[m][0], bf[2], c);  // h.l
-          c = MFMA16B(af[m][1], bf[1], c);  // m.m
-          c = MFMA16B(af[m][1], bf[0], c);  // m.h
-          c = MFMA16B(af[m][0], bf[1], c);  // h.m
-          c = MFMA16B(af[m][0], bf[0], c);  // h.h
-          acc[m][t] = c;
-        }
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) PG_WB_LOAD_B((g + 1) & 1, g + 1)
+        PG_WB_PRODUCT(2, 0, g)  // l.h
+        PG_WB_PRODUCT(0, 2, g)  // h.l
+        PG_WB_PRODUCT(1, 1, g)  // m.m
+        PG_WB_PRODUCT(1, 0, g)  // m.h
+        PG_WB_PRODUCT(0, 1, g)  // h.m
+        PG_WB_PRODUCT(0, 0, g)  // h.h
       }
+#undef PG_WB_LOAD_B
+#undef PG_WB_PRODUCT
     }
   }
 #undef PG_WB_ISSUE
@@ -396,8 +401,6 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   a.in_act = in_act; a.has_bias = has_bias;
   static const int dbg = []() { const char* e = getenv("PG_WB_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
-  static const int dephase = []() { const char* e = getenv("PG_WB_DEPHASE"); return e ? atoi(e) : 0; }();
-  a.dephase = dephase;
   const int xplane = 2 * a.xpb * 16;
   for (int t = 0; t < T; ++t) a.tap_base[t] = copy_of[t] * 3 * xplane + (tap_dr[t] - min_dr) * PBR * 16;
   for (int t = T; t < WB_MAXT; ++t) a.tap_base[t] = 0;
