@@ -298,35 +298,23 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
 #pragma unroll
           for (int p = 0; p < 3; ++p) accb[m] = MFMA16B(af[m][p], ones, accb[m]);
       }
-      // taps in groups of two: four independent accumulators per product (a dependent
-      // v_mfma_f32_16x16x32_bf16 every 2nd issue stalls the matrix pipe), the next group's
-      // fragments in flight under the current group's MFMAs
-      constexpr int NG = (T + 1) / 2;
-      bf16x8 bf[2][2][3];
-#define PG_WB_LOAD_B(BUF, G)                                                                       \
-  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
-    if (2 * (G) + u < T)                                                                           \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                \
-        bf[BUF][u][p] = Lk[b_base[2 * (G) + u < T ? 2 * (G) + u : 0] + p * xplane];
-#define PG_WB_PRODUCT(PA, PB, G)                                                                   \
-  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                    \
-    if (2 * (G) + u < T)                                                                           \
-      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
-        acc[m][2 * (G) + u < T ? 2 * (G) + u : 0] =                                                \
-            MFMA16B(af[m][PA], bf[(G) & 1][u][PB], acc[m][2 * (G) + u < T ? 2 * (G) + u : 0]);
-      PG_WB_LOAD_B(0, 0)
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) PG_WB_LOAD_B((g + 1) & 1, g + 1)
-        PG_WB_PRODUCT(2, 0, g)  // l.h
-        PG_WB_PRODUCT(0, 2, g)  // h.l
-        PG_WB_PRODUCT(1, 1, g)  // m.m
-        PG_WB_PRODUCT(1, 0, g)  // m.h
-        PG_WB_PRODUCT(0, 1, g)  // h.m
-        PG_WB_PRODUCT(0, 0, g)  // h.h
+      for (int t = 0; t < T; ++t) {
+        bf16x8 bf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[p] = Lk[b_base[t] + p * xplane];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          f32x4 c = acc[m][t];
+          c = MFMA16B(af[m][2], bf[0], c);  // l.h
+          c = MFMA16B(af[m][0], bf[2], c);  // h.l
+          c = MFMA16B(af[m][1], bf[1], c);  // m.m
+          c = MFMA16B(af[m][1], bf[0], c);  // m.h
+          c = MFMA16B(af[m][0], bf[1], c);  // h.m
+          c = MFMA16B(af[m][0], bf[0], c);  // h.h
+          acc[m][t] = c;
+        }
       }
-#undef PG_WB_LOAD_B
-#undef PG_WB_PRODUCT
     }
   }
 #undef PG_WB_ISSUE
