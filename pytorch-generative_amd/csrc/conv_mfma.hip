@@ -264,7 +264,10 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
       const int n0 = (g0 + tl * gstep) * a.NI;
       const int npx = min(a.NI, a.N - n0) * rows * a.OW;
       const bool sok = (lane < NT * 16) && pw < npx;
-      const size_t so = so_rel + (size_t)n0 * a.Cout * L;
+      // lanes that store nothing still LOAD the residual / act' operands below: in a partial last
+      // image group their pixel lies in an image past N, so they are pointed at the group's first
+      // pixel instead (an out-of-allocation read faulted at batch 128 / 512 with 15-image tiles)
+      const size_t so = (sok ? so_rel : (size_t)co0 * L) + (size_t)n0 * a.Cout * L;
       // (scratch = the buffer's WEIGHT area, which every commit rewrites completely; the x tile's
       //  zero halo must survive)
       float* ep = lds + cur * a.buf_stride + a.w_off + wave * (16 * EPS);

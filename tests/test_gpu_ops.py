@@ -45,6 +45,7 @@ CONV_CASES = [
     (2, 5, 7, 7, 3, 1, 1, 0, 0, None, None, "relu", False, False),      # L % 4 != 0 scalar path, no bias
     (2, 5, 9, 11, 7, 3, 3, 1, 1, None, "B", None, True, True),          # odd sizes, OW % 4 != 0
     (1, 4, 64, 64, 8, 3, 3, 1, 1, None, None, None, False, True),       # 64x64: several row tiles
+    (17, 32, 4, 4, 32, 3, 3, 1, 1, None, None, "gelu", True, True),     # 4x4 images: 15 per tile, partial last group
     # shapes the bf16x3 weight-gradient kernel takes (Cout % 64 == 0, Cin % 32 == 0, W % 8 == 0)
     (3, 32, 16, 16, 64, 3, 3, 1, 1, None, "B", "relu", False, True),    # 9 taps, 3 column shifts
     (2, 64, 12, 8, 64, 2, 3, 1, 1, "hw", None, None, False, False),     # 6 taps, W = 8, no bias
