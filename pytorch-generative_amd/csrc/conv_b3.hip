@@ -78,6 +78,29 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, 
   }
 }
 
+// the same split by TRUNCATION for the x tiles staged inside the kernel (h = top 16 bits of x,
+// m = top 16 bits of x - h, l = x - h - m: exact, 24 = 8 + 8 + 8 significand bits): and + sub per
+// piece instead of convert / unpack / sub — the staging arithmetic is paid per step by every
+// workgroup (conv_wgrad_b3.hip measures the difference). Weights keep round-to-nearest pieces
+// (packed once per step by b3_pack_kernel); the dropped products stay below one fp32 rounding.
+__device__ __forceinline__ void split8t(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
+  unsigned int xb[8], r1b[8], r2b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    xb[i] = __builtin_bit_cast(unsigned int, x[i]);
+    const float r1 = x[i] - __builtin_bit_cast(float, xb[i] & 0xffff0000u);
+    r1b[i] = __builtin_bit_cast(unsigned int, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, r1b[i] & 0xffff0000u);
+    r2b[i] = __builtin_bit_cast(unsigned int, r2);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // v_perm_b32: {hi16(odd element), hi16(even element)}
+    h[i] = __builtin_amdgcn_perm(xb[2 * i + 1], xb[2 * i], 0x07060302u);
+    m[i] = __builtin_amdgcn_perm(r1b[2 * i + 1], r1b[2 * i], 0x07060302u);
+    l[i] = __builtin_amdgcn_perm(r2b[2 * i + 1], r2b[2 * i], 0x07060302u);
+  }
+}
+
 #define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
 
 template <int MT, int NT>
@@ -186,7 +209,7 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
     float e_[8];                                                                           \
     _Pragma("unroll") for (int c = 0; c < 8; ++c) e_[c] = pg_apply_act(xv[k][c], ACT);     \
     u32x4 h_, m_, l_;                                                                      \
-    split8(e_, h_, m_, l_);                                                                \
+    split8t(e_, h_, m_, l_);                                                               \
     const int dst_ = s_goff[k] >= 0 ? lo_ : a.dump16;                                      \
     lds16[dst_] = h_;                                                                      \
     lds16[dst_ + (s_goff[k] >= 0 ? a.plane16 : 0)] = m_;                                   \
