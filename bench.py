@@ -35,6 +35,7 @@ for _p in (ROOT, os.path.join(ROOT, "pytorch-generative_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix == vector peak (no TF32 on gfx950)
 LN2 = 0.6931471805599453
 
@@ -291,6 +292,34 @@ def conv_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
     return {"launch_ms": ms, "flop_per_launch": flop, "tflops": flop / ms / 1e9}
 
 
+def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
+    """The weight gradient of the same 2x2 64 -> 64 convolution (conv_wgrad_b3_kernel<4> +
+    wgrad_reduce_kernel behind pg_conv2d_wgrad), timed through the C-ABI with HIP events."""
+    from pytorch_generative_amd import _lib, ops
+
+    lib = _lib.load()
+    spec = ops.ConvSpec(2, 2, 1, 1)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(batch, cin, hw, hw, generator=g).to(device)
+    dy = torch.randn(batch, cout, hw, hw, generator=g).to(device)
+    dw = torch.zeros(cout, cin, 2, 2, device=device)
+    db = torch.zeros(cout, device=device)
+    T = len(spec.wg_taps)
+    ws_n = lib.pg_conv2d_wgrad_workspace_floats(cout, cin, T)
+    ws = torch.empty(ws_n, device=device)
+    stream = torch.cuda.current_stream()
+
+    def run():
+        _lib.check(lib.pg_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), batch, cin,
+                                       hw, hw, cout, hw, hw, 2, 2, T, spec.w_dr, spec.w_dc, spec.w_u, spec.w_v,
+                                       ops.ACT_ELU, ws.data_ptr(), ws_n, stream.cuda_stream),
+                   "pg_conv2d_wgrad")
+
+    ms = _event_time(run, stream)
+    flop = 2.0 * batch * hw * hw * cin * cout * T
+    return {"launch_ms": ms, "flop_per_launch": flop, "tflops": flop / ms / 1e9}
+
+
 def measured_traffic(batch):
     """HBM bytes per launch of the headline's dominant kernel from the committed PMC profile
     (collected in separate rocprofv3 --pmc passes, see profiles/README.md); None when no profile
@@ -484,13 +513,21 @@ def main():
             if "pixel_snail" in out:
                 c = conv_kernel_roofline(args.snail_batch, env.device)
                 a = attention_kernel_roofline(args.snail_batch, env.device, 1, 4, 32, 32, True)
+                w = wgrad_kernel_roofline(args.snail_batch, env.device)
                 out["pixel_snail"]["roofline"] = {
                     "bound": "mfma",
-                    "kernel": "conv_mfma_kernel<4, 4> (pg_conv2d_mfma: 2x2 64->64 convolution, ELU prologue)",
+                    "kernel": "conv_b3_kernel<4, 4> (pg_conv2d_mfma: 2x2 64->64 convolution, ELU prologue; "
+                              "fp32 products as 6 bf16 MFMAs)",
+                    # algorithmic fp32 flops; `peak` stays the fp32 matrix-core peak (the arithmetic the
+                    # path computes in), the bf16x3 scheme's own ceiling is bf16 peak / 6
                     "achieved": c["tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": c["tflops"] / FP32_PEAK_TFLOPS, "launch_ms": c["launch_ms"],
+                    "frac": c["tflops"] / FP32_PEAK_TFLOPS,
+                    "bf16x3_ceiling": BF16_PEAK_TFLOPS / 6.0,
+                    "frac_of_bf16x3_ceiling": c["tflops"] / (BF16_PEAK_TFLOPS / 6.0),
+                    "launch_ms": c["launch_ms"],
                     "flop_per_launch": c["flop_per_launch"], "traffic": None,
-                    "other_kernels": {"attn_fwd_k4_kernel": a["fwd"], "attn_dq_k4_kernel": a["dq"],
+                    "other_kernels": {"conv_wgrad_b3_kernel<4> + wgrad_reduce_kernel": w,
+                                      "attn_fwd_k4_kernel": a["fwd"], "attn_dq_k4_kernel": a["dq"],
                                       "attn_dkv_k4_kernel": a["dkv"]},
                 }
             if not args.no_cpu_baseline:
