@@ -79,7 +79,7 @@ class PixelSNAILBlock(nn.Module):
         (pixel_snail.py:186) fused into the block's last convolution."""
         res = self._residual(x)
         pos = pg_nn.image_positional_encoding(input_img.shape, res.device)
-        attn = self._attention(torch.cat((pos, res), dim=1), input_img)
+        attn = self._attention((pos, res), input_img)  # cat(pos, res[, img]) happens inside, once
         res = _elu_conv_elu(self._residual_out, res)
         both = _elu_conv_elu(self._attention_out, attn, res=res)  # elu(conv(elu(attn))) + res
         return _elu_conv_elu(self._out, both, res=x if add_input else None)

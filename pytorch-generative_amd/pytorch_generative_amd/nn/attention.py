@@ -90,10 +90,31 @@ class CausalAttention(nn.Module):
         """x feeds q, k and v; extra_x (optional) is concatenated for k and v only.
 
         `res` (extension) is added to the projected output inside the projection kernel.
+        x may be a tuple of tensors (extension): they are concatenated on dim 1 — together with
+        extra_x in ONE copy when the merged projection below runs.
         """
+        parts = list(x) if isinstance(x, (tuple, list)) else [x]
         ctx = ops.RowDecode.current
         if ctx is not None:
-            return self._row_forward(ctx, x, extra_x, res)
+            return self._row_forward(ctx, parts[0] if len(parts) == 1 else torch.cat(parts, dim=1), extra_x, res)
+        if extra_x is not None and ops.FUSE_QKV_EXTRA and extra_x.is_cuda:
+            # q reads a channel PREFIX of what k / v read (attention.py:139-143): one 1x1 convolution
+            # over cat(x, extra_x) with q's weight rows zero-padded over the extra channels gives
+            # [q | k | v] in one tensor — one concatenation, one projection, one data gradient and
+            # one weight gradient instead of two each plus the sum of the two input gradients.
+            # The parameters keep the reference's shapes; the merged weight is rebuilt per step
+            # (40 x 69 values for PixelSNAIL) and its gradient flows back through the cat / pad.
+            x_all = torch.cat(parts + [extra_x], dim=1)
+            cin_q, cin_kv = self._q.weight.shape[1], self._kv.weight.shape[1]
+            wq = torch.nn.functional.pad(self._q.weight.flatten(1), (0, cin_kv - cin_q))
+            w = torch.cat((wq, self._kv.weight.flatten(1)), dim=0).view(-1, cin_kv, 1, 1)
+            b = torch.cat((self._q.bias, self._kv.bias))
+            qkv = ops.conv2d_taps(x_all, w, b, self._kv._conv_spec())
+            out = ops.causal_attention_qkv(
+                qkv, self._n_heads, self._embed_channels, self._out_channels, self._mask_center
+            )
+            return self._proj(out, res=res)
+        x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         if extra_x is None and ops.FUSE_PAIR:
             views = ops.conv_pair_views(self._q, self._kv)
             if views is not None:

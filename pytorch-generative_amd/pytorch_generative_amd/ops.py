@@ -328,6 +328,7 @@ class _ConvTaps(torch.autograd.Function):
 # A/B switches for measurements (PG_FUSE_PAIR=0 / PG_FUSE_LNSKIP=0 select the unfused graphs)
 FUSE_PAIR = os.environ.get("PG_FUSE_PAIR", "1") != "0"
 FUSE_LNSKIP = os.environ.get("PG_FUSE_LNSKIP", "1") != "0"
+FUSE_QKV_EXTRA = os.environ.get("PG_FUSE_QKV_EXTRA", "1") != "0"  # CausalAttention with extra_x: merged [q|k|v] projection
 
 
 def _adjacent_view(a, b, shape):
