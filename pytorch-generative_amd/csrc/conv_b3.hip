@@ -385,18 +385,26 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
 // wfrag (16-byte units) [co chunk][channel chunk][k step][co tile m][piece][lane]: the 8 bf16 of
 //   Wsel[64 chunk + 16 m + (lane & 15)][channel = CIB * j + 8 cg(g) + 0..7][tap t(g)], g = 4 ks + (lane >> 4)
 // with group g -> (t = g / cgs, cg = g % cgs); zero for g >= groups or an output channel >= M.
+struct B3PackJob {
+  unsigned int* wfrag;
+  int transpose, M, Kc, MT, chunks, CIB, cgs, groups, ksteps, nchunk;
+  long total;  // lanes (pieces inside)
+};
+
 struct B3PackArgs {
   const float* w;
-  unsigned int* wfrag;
-  int Cout, Cin, KH, KW, T, transpose;
-  int M, Kc, MT, chunks, CIB, cgs, groups, ksteps, nchunk;
+  int Cout, Cin, KH, KW, T, njobs;
+  B3PackJob job[2];  // forward and data-gradient orientation in ONE launch
   int tap_u[PG_MAX_TAPS];
   int tap_v[PG_MAX_TAPS];
 };
 
-__global__ void b3_pack_kernel(const B3PackArgs p) {
-  const long total = (long)p.chunks * p.nchunk * p.ksteps * p.MT * 64;  // lanes (pieces inside)
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+__global__ void b3_pack_kernel(const B3PackArgs a) {
+  const long total = a.job[0].total + (a.njobs > 1 ? a.job[1].total : 0);
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += (long)gridDim.x * blockDim.x) {
+    const bool second = i0 >= a.job[0].total;
+    const B3PackJob& p = a.job[second ? 1 : 0];
+    const long i = second ? i0 - a.job[0].total : i0;
     const int lane = (int)(i & 63);
     long rest = i >> 6;
     const int m = (int)(rest % p.MT); rest /= p.MT;
@@ -415,7 +423,7 @@ __global__ void b3_pack_kernel(const B3PackArgs p) {
         const int c = p.CIB * j + 8 * cg + e;
         const int co = p.transpose ? c : o;
         const int ci = p.transpose ? o : c;
-        x[e] = p.w[(((size_t)co * p.Cin + ci) * p.KH + p.tap_u[t]) * p.KW + p.tap_v[t]];
+        x[e] = a.w[(((size_t)co * a.Cin + ci) * a.KH + a.tap_u[t]) * a.KW + a.tap_v[t]];
       }
     }
     u32x4 h, mm, l;
@@ -522,21 +530,38 @@ size_t pg_b3_frag_floats(int Kc, int M, int T) {
   return (size_t)b3_chunks(M) * (Kc / pl.CIB) * pl.ksteps * pl.MT * 3 * 64 * 4;
 }
 
-int pg_b3_pack(const float* w, float* wfrag, int Cout, int Cin, int KH, int KW, int T,
-               const int* tap_u, const int* tap_v, int transpose, hipStream_t st) {
-  B3PackArgs p;
-  p.w = w; p.wfrag = reinterpret_cast<unsigned int*>(wfrag);
-  p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.T = T; p.transpose = transpose;
+static int b3_pack_job(B3PackJob& p, float* wfrag, int Cout, int Cin, int T, int transpose) {
+  p.wfrag = reinterpret_cast<unsigned int*>(wfrag);
+  p.transpose = transpose;
   p.M = transpose ? Cin : Cout;
   p.Kc = transpose ? Cout : Cin;
   const B3Plan pl = b3_plan(p.Kc, p.M, T);
   PG_REQUIRE(pl.ok, PG_ESHAPE, "pg_pack_conv_weight_frag: shape not covered by the bf16x3 format");
   p.MT = pl.MT; p.chunks = b3_chunks(p.M); p.CIB = pl.CIB; p.cgs = pl.cgs; p.groups = pl.groups;
   p.ksteps = pl.ksteps; p.nchunk = p.Kc / pl.CIB;
-  for (int t = 0; t < T; ++t) { p.tap_u[t] = tap_u[t]; p.tap_v[t] = tap_v[t]; }
-  const long total = (long)p.chunks * p.nchunk * p.ksteps * p.MT * 64;
+  p.total = (long)p.chunks * p.nchunk * p.ksteps * p.MT * 64;
+  return 0;
+}
+
+// either destination may be null (then only the other orientation is packed)
+int pg_b3_pack2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout, int Cin, int KH, int KW,
+                int T, const int* tap_u, const int* tap_v, hipStream_t st) {
+  B3PackArgs a;
+  a.w = w; a.Cout = Cout; a.Cin = Cin; a.KH = KH; a.KW = KW; a.T = T; a.njobs = 0;
+  if (wfrag_fwd) {
+    const int rc = b3_pack_job(a.job[a.njobs++], wfrag_fwd, Cout, Cin, T, 0);
+    if (rc) return rc;
+  }
+  if (wfrag_dgrad) {
+    const int rc = b3_pack_job(a.job[a.njobs++], wfrag_dgrad, Cout, Cin, T, 1);
+    if (rc) return rc;
+  }
+  if (a.njobs == 0) return 0;
+  if (a.njobs == 1) a.job[1] = a.job[0];
+  for (int t = 0; t < T; ++t) { a.tap_u[t] = tap_u[t]; a.tap_v[t] = tap_v[t]; }
+  const long total = a.job[0].total + (a.njobs > 1 ? a.job[1].total : 0);
   const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-  hipLaunchKernelGGL(b3_pack_kernel, dim3(blocks), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(b3_pack_kernel, dim3(blocks), dim3(256), 0, st, a);
   PG_LAUNCH_CHECK("pg_pack_conv_weight_frag(bf16x3)");
   return 0;
 }

@@ -464,8 +464,8 @@ static void mf_pack_job(FragPackJob& j, float* wfrag, int Cout, int Cin, int T, 
 // conv_b3.hip: the same convolution with its fp32 products on the bf16 matrix pipe (format 2)
 int pg_b3_applicable(int Kc, int M, int T, int OH, int OW, int hr, int hc);
 size_t pg_b3_frag_floats(int Kc, int M, int T);
-int pg_b3_pack(const float* w, float* wfrag, int Cout, int Cin, int KH, int KW, int T,
-               const int* tap_u, const int* tap_v, int transpose, hipStream_t st);
+int pg_b3_pack2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout, int Cin, int KH, int KW,
+                int T, const int* tap_u, const int* tap_v, hipStream_t st);
 int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const float* res, float* out,
                int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
                const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
@@ -501,15 +501,15 @@ PG_EXPORT int pg_pack_conv_weight_frag2(const float* w, float* wfrag_fwd, float*
     PG_REQUIRE(tap_u[t] >= 0 && tap_u[t] < KH && tap_v[t] >= 0 && tap_v[t] < KW, PG_EINVAL,
                "pg_pack_conv_weight_frag: tap %d (%d,%d) outside %dx%d", t, tap_u[t], tap_v[t], KH, KW);
   hipStream_t st = (hipStream_t)stream;
-  if (wfrag_fwd && fmt_fwd == PG_CONV_FMT_B3) {
-    const int rc = pg_b3_pack(w, wfrag_fwd, Cout, Cin, KH, KW, T, tap_u, tap_v, 0, st);
-    if (rc) return rc;
-    wfrag_fwd = nullptr;
-  }
-  if (wfrag_dgrad && fmt_dgrad == PG_CONV_FMT_B3) {
-    const int rc = pg_b3_pack(w, wfrag_dgrad, Cout, Cin, KH, KW, T, tap_u, tap_v, 1, st);
-    if (rc) return rc;
-    wfrag_dgrad = nullptr;
+  {
+    float* b3_fwd = (wfrag_fwd && fmt_fwd == PG_CONV_FMT_B3) ? wfrag_fwd : nullptr;
+    float* b3_dgrad = (wfrag_dgrad && fmt_dgrad == PG_CONV_FMT_B3) ? wfrag_dgrad : nullptr;
+    if (b3_fwd || b3_dgrad) {  // both orientations in one launch
+      const int rc = pg_b3_pack2(w, b3_fwd, b3_dgrad, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
+      if (rc) return rc;
+      if (b3_fwd) wfrag_fwd = nullptr;
+      if (b3_dgrad) wfrag_dgrad = nullptr;
+    }
   }
   if (!wfrag_fwd && !wfrag_dgrad) return 0;
   PG_REQUIRE((!wfrag_fwd || fmt_fwd == PG_CONV_FMT_F32) && (!wfrag_dgrad || fmt_dgrad == PG_CONV_FMT_F32),
