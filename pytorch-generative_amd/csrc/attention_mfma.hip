@@ -730,6 +730,10 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   attn_waves(wcfg);
   int W = wcfg[which];
   if (which == PG_ATTN_DKV && dkv_bf16 && !getenv("PG_ATTN_WAVES")) W = 8;
+  // few (n, head) units (the reference's default batch 64 x 4 heads = one workgroup per CU): the launch
+  // lasts as long as its most loaded wave, so the forward kernel also spreads its 13 query blocks over
+  // 8 waves (longest list 94 -> 58 cost units; with many units per CU 4-wave workgroups pack better)
+  if (which == PG_ATTN_FWD && (long)a.N * a.heads <= 512 && !getenv("PG_ATTN_WAVES")) W = 8;
   if (W > NB) W = NB;
   if ((NB + W - 1) / W > 16) return 0;  // block lists hold 16 entries per wave
   // LPT: blocks by decreasing cost (later query blocks / earlier key blocks stream more), each to
