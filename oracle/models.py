@@ -248,6 +248,26 @@ def vae(p, x, eps, beta=1.0):
     return z, beta * kl
 
 
+def vq_vae(p, x, training=True, decay=0.99):
+    """VectorQuantizedVAE.forward (reference models/vae/vq_vae.py:69-81): Encoder (stride 4) ->
+    Quantizer = 1x1 convolution + VectorQuantizer (vaes.py:244-264) -> Decoder (stride 4).
+    Returns (reconstruction, quantization loss, vq) with vq = ops.vector_quantize's dict: the EMA
+    buffers after the step are vq["embedding"], vq["cluster_size"], vq["embedding_avg"]."""
+    h = _vae_encoder(p, "_encoder.", x)
+    h = F.conv2d(h, p["_quantizer._net.0.weight"], p["_quantizer._net.0.bias"])
+    pre = "_quantizer._net.1."
+    use_ema = pre + "_cluster_size" in p
+    vq = ops.vector_quantize(h, p[pre + "_embedding"], p.get(pre + "_cluster_size"),
+                             p.get(pre + "_embedding_avg"), use_ema=use_ema, training=training,
+                             decay=decay)
+    return _vae_decoder(p, "_decoder.", vq["quantized"]), vq["loss"], vq
+
+
+def vq_vae_loss(recon, x, vq_loss):
+    """loss_fn of vq_vae.reproduce (vq_vae.py:127-136): mse(preds, x) + vq_loss."""
+    return F.mse_loss(recon, x) + vq_loss
+
+
 def elbo_terms(logits, x, kl):
     """loss_fn of the VAE reproduce()s, vae.py:149-159: (recon.mean(), kl.mean(), elbo.mean())."""
     recon = F.binary_cross_entropy_with_logits(logits, x, reduction="none").sum(dim=(1, 2, 3))

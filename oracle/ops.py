@@ -103,3 +103,39 @@ def gaussian_kl_div(p_mean, p_log_std, q_mean, q_log_std):
 def sample_from_gaussian(mu, log_sig, eps):
     """models/vae/vaes.py:31-33 with the noise made explicit."""
     return mu + log_sig.exp() * eps
+
+
+def vector_quantize(x, embedding, cluster_size=None, embedding_avg=None, *, use_ema=True,
+                    training=True, decay=0.99):
+    """VectorQuantizer.forward (reference nn/utils.py:53-96), functional: nothing is updated in place.
+
+    x: (N, D, H, W); embedding: (K, D). Every position's D-vector goes to its nearest codebook row
+    (squared Euclidean distance in the expanded form |x|^2 + |e|^2 - 2 x.e of :61-65, argmin keeps the
+    FIRST minimum like torch.argmin :68). Returns a dict:
+      quantized     x + (q - x).detach()           straight-through estimator (:95)
+      loss          mse(x, q.detach())             commitment loss (:79), + mse(q, x.detach()) when
+                                                   use_ema is False (:93)
+      idxs          (N*H*W,) codebook indices, positions in NHW order (:56)
+      embedding / cluster_size / embedding_avg     the buffers AFTER the EMA update of :80-90 when
+                                                   use_ema and training, else the inputs unchanged
+    """
+    n, d, h, w = x.shape
+    flat = x.permute(0, 2, 3, 1).contiguous().view(-1, d)
+    dist = (flat ** 2).sum(dim=1, keepdim=True) + (embedding ** 2).sum(dim=1) - 2 * flat @ embedding.t()
+    idxs = torch.argmin(dist, dim=1)
+    q = embedding[idxs].view(n, h, w, d).permute(0, 3, 1, 2).contiguous()
+    loss = F.mse_loss(x, q.detach())
+    out = {"idxs": idxs, "embedding": embedding, "cluster_size": cluster_size, "embedding_avg": embedding_avg}
+    if use_ema and training:
+        k = embedding.shape[0]
+        one_hot = F.one_hot(idxs, k).to(flat.dtype)
+        batch_cluster = one_hot.sum(dim=0)
+        batch_avg = (flat.detach().t() @ one_hot).t()
+        cs = cluster_size * decay + batch_cluster * (1 - decay)
+        ea = embedding_avg * decay + batch_avg * (1 - decay)
+        out.update(cluster_size=cs, embedding_avg=ea, embedding=ea / (cs + 1e-5).unsqueeze(1))
+    elif not use_ema:
+        loss = loss + F.mse_loss(q, x.detach())
+    out["quantized"] = x + (q - x).detach()
+    out["loss"] = loss
+    return out

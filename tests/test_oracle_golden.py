@@ -74,3 +74,50 @@ def test_oracle_matches_vae_golden(name):
             assert go is None or float(go.abs().max()) == 0.0, k
         else:
             _util.assert_close(go, want, 2e-4, f"grad {k}")
+
+
+# ---- VectorQuantizer / VQ-VAE — the oracle restatement against outputs of the
+# ---- reference (tests/golden/make_vq_golden.py). The HIP path for this row is not built yet.
+@pytest.mark.parametrize("case", ["ema_train", "ema_eval", "sgd_train"])
+def test_vector_quantizer_oracle_matches_reference_golden(case):
+    from oracle import ops as oops
+
+    g = _util.load_golden("vq_quantizer")["cases"][case]
+    b = g["before"]
+    x = g["x"].clone().requires_grad_(True)
+    emb = b["_embedding"].clone().requires_grad_(not g["use_ema"])
+    out = oops.vector_quantize(x, emb, b.get("_cluster_size"), b.get("_embedding_avg"),
+                               use_ema=g["use_ema"], training=g["training"])
+    assert torch.equal(out["quantized"].detach(), g["quantized"])  # same codebook rows, bit for bit
+    _util.assert_close(out["loss"], g["loss"], 1e-6, "vq loss")
+    (out["quantized"].sum() * 0.5 + out["loss"]).backward()
+    _util.assert_close(x.grad, g["dx"], 1e-6, "dx (straight-through + commitment)")
+    if not g["use_ema"]:
+        _util.assert_close(emb.grad, g["d_embedding"], 1e-6, "d embedding")
+    for key in ("_embedding", "_cluster_size", "_embedding_avg"):
+        if key in g["after"]:
+            _util.assert_close(out[key[1:]], g["after"][key], 1e-6, f"buffer {key} after forward")
+    if g["use_ema"] and not g["training"]:
+        assert all(torch.equal(g["after"][k], b[k]) for k in b)  # eval leaves the buffers alone
+
+
+def test_vq_vae_oracle_matches_reference_golden_step():
+    g = _util.load_golden("vq_vae_small")
+    state = {k: v.clone() for k, v in g["state0"].items()}
+    leaves = {k: v.requires_grad_(True) for k, v in state.items() if otrain.is_param(k)}
+    p = dict(state)
+    p.update(leaves)
+    recon, vq_loss, vq = omodels.vq_vae(p, g["x"], training=True)
+    loss = omodels.vq_vae_loss(recon, g["x"], vq_loss)
+    _util.assert_close(recon, g["recon"], 1e-5, "reconstruction")
+    _util.assert_close(vq_loss, g["vq_loss"], 1e-5, "vq loss")
+    _util.assert_close(loss, g["loss"], 1e-5, "loss")
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)))
+    for k, want in g["grads"].items():
+        if want is None:
+            assert grads[k] is None, k
+        else:
+            _util.assert_close(grads[k], want, 2e-4, f"grad {k}")
+    pre = "_quantizer._net.1."
+    for key in ("_embedding", "_cluster_size", "_embedding_avg"):  # EMA buffers move in forward
+        _util.assert_close(vq[key[1:]], g["state_after_forward"][pre + key], 1e-6, key)

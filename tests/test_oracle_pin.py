@@ -184,3 +184,22 @@ def test_beta_vae_forward_elbo_and_grads(ref):
     assert torch.allclose(o_kl, kl.detach(), rtol=1e-5, atol=1e-4)
     for (k, p), go in zip(model.named_parameters(), grads):
         assert torch.allclose(go, p.grad, rtol=1e-4, atol=1e-5), k
+
+
+@pytest.mark.parametrize("use_ema,training", [(True, True), (True, False), (False, True)])
+def test_vector_quantizer_live(ref, use_ema, training):
+    """oracle.ops.vector_quantize against the live VectorQuantizer (nn/utils.py:53-96), fresh seeds."""
+    torch.manual_seed(11)
+    vq = ref.nn.VectorQuantizer(n_embeddings=32, embedding_dim=6, use_ema=use_ema)
+    vq.train(training)
+    before = _ref.clone_state(vq)
+    x = torch.randn(4, 6, 7, 5)
+    q, loss = vq(x)
+    out = oops.vector_quantize(x, before["_embedding"], before.get("_cluster_size"),
+                               before.get("_embedding_avg"), use_ema=use_ema, training=training)
+    assert torch.equal(out["quantized"], q.detach())
+    assert torch.allclose(out["loss"], loss.detach(), rtol=1e-6, atol=0)
+    after = _ref.clone_state(vq)
+    for key in ("_embedding", "_cluster_size", "_embedding_avg"):
+        if key in after:
+            assert torch.allclose(out[key[1:]], after[key], rtol=1e-6, atol=1e-7), key
