@@ -103,19 +103,28 @@ __device__ __forceinline__ void split8t(const float (&x)[8], u32x4& h, u32x4& m,
 
 #define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
 
-template <int MT, int NT>
-__global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) {
+// CG = output-channel chunks per workgroup. CG = 1: 4 waves, one 64-channel chunk (two workgroups per
+// CU). CG = 2 ("wide", EXPERIMENTAL, PG_CONV_B3_WIDE=1, not measured yet): 8 waves = two 64-channel
+// chunks x four pixel quarters sharing ONE staged x tile — for Cout >= 128 every chunk re-stages the
+// same tile today (loads + activation + split are ~30 % of a launch), the wide workgroup halves that
+// per MFMA; both chunks of a gate input also meet in one workgroup (a later gate-fusing epilogue).
+template <int MT, int NT, int CG>
+__global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kernel(const B3Args a) {
+  constexpr int THREADS = B3_THREADS * CG;
+  constexpr int XS = CG == 1 ? B3_XS : (B3_XS + 1) / 2;  // the tile's slots over twice the threads
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cgp = CG == 1 ? 0 : wave_all >> 2;       // which of the workgroup's output chunks
+  const int wave = CG == 1 ? wave_all : wave_all & 3;  // pixel quarter of the tile
   // persistent: one row-tile index per workgroup, images n = n_first, n_first + nstep, ...
   const int rt = blockIdx.x % a.tiles_per_img;
   const int n_first = blockIdx.x / a.tiles_per_img, nstep = gridDim.x / a.tiles_per_img;
   const int row0 = rt * a.TR;
   const int rows = min(a.TR, a.OH - row0);
   const int npx = rows * a.OW;
-  const int co0 = blockIdx.y * B3_CO_CHUNK;
+  const int co0 = (blockIdx.y * CG + cgp) * B3_CO_CHUNK;
   const int L = a.OH * a.OW;
   const int plane = a.IH * a.IW;
   const int nchunk = a.Cin / a.CIB;
@@ -141,14 +150,14 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
     so_rel = (size_t)co0 * L + (size_t)((row0 + r) * a.OW + (pc - r * a.OW));
   }
   // per group g = 4 ks + kq: where it lives — plane of its channel group + tap offset (LDS table)
-  int* gtab = reinterpret_cast<int*>(lds + a.b_off + B3_CO_CHUNK);
+  int* gtab = reinterpret_cast<int*>(lds + a.b_off + B3_CO_CHUNK * CG);
   if (tid < B3_MAXG) gtab[tid] = tid < a.groups ? a.g_cg[tid] * 3 * a.plane16 + a.g_tapoff[tid] : 0;
 
   // ---- staging slots: (channel group, tile row, tile column) -> 8 channel loads of one pixel
-  int s_goff[B3_XS], s_loff[B3_XS];  // global offset of channel cg*8 (floats), LDS entry of piece 0; -1: no slot
+  int s_goff[XS], s_loff[XS];  // global offset of channel cg*8 (floats), LDS entry of piece 0; -1: no slot
 #pragma unroll
-  for (int k = 0; k < B3_XS; ++k) {
-    int e = tid + k * B3_THREADS;
+  for (int k = 0; k < XS; ++k) {
+    int e = tid + k * THREADS;
     const bool in = e < a.xslots;
     e = in ? e : 0;
     const int tc = e % a.tile_w;
@@ -168,17 +177,20 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // zero the x planes once (halo / out-of-image entries are never written afterwards)
-  for (int i = tid; i < a.cgs * 3 * a.plane16; i += B3_THREADS) lds16[i] = u32x4{0u, 0u, 0u, 0u};
-  if (tid < B3_CO_CHUNK) {
-    const int co = co0 + tid;
+  for (int i = tid; i < a.cgs * 3 * a.plane16; i += THREADS) lds16[i] = u32x4{0u, 0u, 0u, 0u};
+  if (tid < B3_CO_CHUNK * CG) {
+    const int co = CG == 1 ? co0 + tid : blockIdx.y * CG * B3_CO_CHUNK + tid;
     lds[a.b_off + tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
   }
 
-  const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * a.wslab4;
-  float xv[B3_XS][8];
+  // weight slab of this thread's chunk: threads [256 c, 256 c + 256) load and commit chunk c's slab
+  const int wt = CG == 1 ? tid : tid & (B3_THREADS - 1);
+  const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) +
+                         (size_t)(CG == 1 ? blockIdx.y : blockIdx.y * CG + (tid >> 8)) * nchunk * a.wslab4;
+  float xv[XS][8];
   float4 wv[B3_WS];
 #pragma unroll
-  for (int k = 0; k < B3_XS; ++k)
+  for (int k = 0; k < XS; ++k)
 #pragma unroll
     for (int c = 0; c < 8; ++c) xv[k][c] = 0.f;
 #pragma unroll
@@ -190,12 +202,12 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
     const int ch_ = (STEP) - tl_ * nchunk;                                                 \
     const float4* ws_ = wsrc_b + (size_t)ch_ * a.wslab4;                                   \
     _Pragma("unroll") for (int k = 0; k < B3_WS; ++k) {                                    \
-      const int i = tid + k * B3_THREADS;                                                  \
+      const int i = wt + k * B3_THREADS;                                                   \
       if (i < a.wslab4) wv[k] = ws_[i];                                                    \
     }                                                                                      \
     const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
     if (!((a.dbg & 1) && (STEP) > 0))                                                      \
-    _Pragma("unroll") for (int k = 0; k < B3_XS; ++k) {                                    \
+    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                       \
       if (s_goff[k] >= 0) {                                                                \
         const float* p_ = src_ + s_goff[k];                                                \
         _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = p_[(size_t)c * plane];    \
@@ -203,7 +215,7 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
     }                                                                                      \
   }
 #define PG_B3_COMMIT_X(ACT)                                                                \
-  _Pragma("unroll") for (int k = 0; k < B3_XS; ++k) {                                      \
+  _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                         \
     int lo_ = s_loff[k];                                                                   \
     asm volatile("" : "+v"(lo_));                                                          \
     float e_[8];                                                                           \
@@ -223,9 +235,10 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
       case PG_ACT_GELU: PG_B3_COMMIT_X(PG_ACT_GELU) break;                                 \
       default:          PG_B3_COMMIT_X(PG_ACT_NONE) break;                                 \
     }                                                                                      \
-    float4* wdst_ = reinterpret_cast<float4*>(lds16 + a.w_off16);                          \
+    float4* wdst_ = reinterpret_cast<float4*>(lds16 + a.w_off16) +                         \
+                    (CG == 1 ? 0 : (tid >> 8) * a.wslab4);                                 \
     _Pragma("unroll") for (int k = 0; k < B3_WS; ++k) {                                    \
-      const int i = tid + k * B3_THREADS;                                                  \
+      const int i = wt + k * B3_THREADS;                                                   \
       if (i < a.wslab4) wdst_[i] = wv[k];                                                  \
     }                                                                                      \
   }
@@ -235,9 +248,9 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
   //   issue loads(s+2) | [epilogue of the tile that ended at s, in per-wave scratch] | barrier
   // so loads have a whole step (+ an epilogue) to land and the epilogue's stores fly under MFMA(s+1).
   constexpr int EPS = 68;
-  const float* bl = lds + a.b_off;
+  const float* bl = lds + a.b_off + (CG == 1 ? 0 : cgp * B3_CO_CHUNK);
   const bf16x8* xl = reinterpret_cast<const bf16x8*>(lds16);
-  const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds16 + a.w_off16) + lane;
+  const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds16 + a.w_off16) + (CG == 1 ? 0 : cgp * a.wslab4) + lane;
   PG_B3_ISSUE(0)
   PG_B3_COMMIT_ALL()
   __syncthreads();
@@ -280,7 +293,7 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3_kernel(const B3Args a) 
       // transposition scratch of its own (the tiles already hold the next step)
       const int n_img = n_first + tl * nstep;
       const size_t so = so_rel + (size_t)n_img * a.Cout * L;
-      float* ep = lds + a.ep_off + wave * (16 * EPS);
+      float* ep = lds + a.ep_off + wave_all * (16 * EPS);
       const int cvalid = a.Cout - co0;
       float* outp = a.out + so;
       const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
@@ -486,17 +499,17 @@ int b3_rows(int T, int OH, int OW, int hr, int hc) {
   return (OH + nt_rows - 1) / nt_rows;
 }
 
-template <int MT>
+template <int MT, int CG = 1>
 void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
   static bool big[5] = {false, false, false, false, false};
 #define PG_B3_L(NTV)                                                                                  \
   {                                                                                                   \
     if (shmem > 64 * 1024 && !big[NTV]) {                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV>),               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV, CG>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, CG == 1 ? 80 * 1024 : 160 * 1024); \
       big[NTV] = true;                                                                                \
     }                                                                                                 \
-    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV>), grid, dim3(B3_THREADS), shmem, st, a);              \
+    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV, CG>), grid, dim3(B3_THREADS * CG), shmem, st, a);     \
   }
   switch (nt) {
     case 1: PG_B3_L(1) break;
@@ -596,19 +609,27 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   const size_t x16 = (size_t)pl.cgs * 3 * a.plane16;
   a.dump16 = (int)x16;              // one spare 16-byte entry (+ padding to a 256-byte boundary)
   a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
-  size_t shmem = (size_t)a.w_off16 * 16 + pl.w_bytes;
+  // EXPERIMENTAL wide workgroups (two output chunks share one staged x tile): opt-in, not yet measured
+  static const bool wide_on = []() { const char* e = getenv("PG_CONV_B3_WIDE"); return e && e[0] == '1'; }();
+  const int CG = (wide_on && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0) ? 2 : 1;
+  size_t shmem = (size_t)a.w_off16 * 16 + pl.w_bytes * CG;
   a.ep_off = (int)(shmem / 4);
-  shmem += (size_t)4 * 16 * 68 * 4;
+  shmem += (size_t)4 * CG * 16 * 68 * 4;
   a.b_off = (int)(shmem / 4);
-  shmem += (B3_CO_CHUNK + B3_MAXG + 4) * sizeof(float);
-  PG_REQUIRE(shmem <= 80 * 1024, PG_ESHAPE, "pg_conv2d_mfma(bf16x3): %zu B of LDS", shmem);
+  shmem += (B3_CO_CHUNK * CG + B3_MAXG + 4) * sizeof(float);
+  PG_REQUIRE(shmem <= (size_t)(CG == 1 ? 80 : 160) * 1024, PG_ESHAPE, "pg_conv2d_mfma(bf16x3): %zu B of LDS", shmem);
   const int nt = (TR * OW + 63) / 64;
-  const int chunks_y = b3_chunks(Cout);
-  long want = 512 / chunks_y;
+  const int chunks_y = b3_chunks(Cout) / CG;
+  long want = (CG == 1 ? 512 : 256) / chunks_y;  // resident workgroups: 2 per CU (4 waves) / 1 per CU (8 waves)
   if (want < a.tiles_per_img) want = a.tiles_per_img;
   long gx = (want / a.tiles_per_img) * a.tiles_per_img;
   if (gx > (long)N * a.tiles_per_img) gx = (long)N * a.tiles_per_img;
   dim3 grid((unsigned)gx, (unsigned)chunks_y);
+  if (CG == 2) {
+    b3_launch<4, 2>(a, nt, grid, shmem, st);
+    PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, wide)");
+    return 0;
+  }
   switch (pl.MT) {
     case 1: b3_launch<1>(a, nt, grid, shmem, st); break;
     case 2: b3_launch<2>(a, nt, grid, shmem, st); break;
