@@ -263,6 +263,29 @@ def vq_vae(p, x, training=True, decay=0.99):
     return _vae_decoder(p, "_decoder.", vq["quantized"]), vq["loss"], vq
 
 
+def _quantizer(p, pre, h, training, decay):
+    """vaes.Quantizer (vaes.py:244-264): 1x1 convolution to the embedding width, then VectorQuantizer."""
+    h = F.conv2d(h, p[pre + "_net.0.weight"], p[pre + "_net.0.bias"])
+    q = pre + "_net.1."
+    return ops.vector_quantize(h, p[q + "_embedding"], p.get(q + "_cluster_size"), p.get(q + "_embedding_avg"),
+                               use_ema=q + "_cluster_size" in p, training=training, decay=decay)
+
+
+def vq_vae_2(p, x, training=True, decay=0.99):
+    """VectorQuantizedVAE2.forward (reference models/vae/vq_vae_2.py:96-110): bottom and top encoders
+    (stride 2 each), both levels quantized, the top level decoded back to the bottom resolution, then
+    the bottom decoder over cat(conv1x1(decoded_t), quantized_b). Returns (xhat, quantization loss,
+    (vq_t, vq_b)); loss = 0.5 (vq_b + vq_t) + mse(decoded_t, encoded_b) (:110, no detach)."""
+    enc_b = _vae_encoder(p, "_encoder_b.", x)
+    enc_t = _vae_encoder(p, "_encoder_t.", enc_b)
+    vq_t = _quantizer(p, "_quantizer_t.", enc_t, training, decay)
+    vq_b = _quantizer(p, "_quantizer_b.", enc_b, training, decay)
+    dec_t = _vae_decoder(p, "_decoder_t.", vq_t["quantized"])
+    xhat = _vae_decoder(p, "_decoder_b.", torch.cat(
+        (F.conv2d(dec_t, p["_conv.weight"], p["_conv.bias"]), vq_b["quantized"]), dim=1))
+    return xhat, 0.5 * (vq_b["loss"] + vq_t["loss"]) + F.mse_loss(dec_t, enc_b), (vq_t, vq_b)
+
+
 def vq_vae_loss(recon, x, vq_loss):
     """loss_fn of vq_vae.reproduce (vq_vae.py:127-136): mse(preds, x) + vq_loss."""
     return F.mse_loss(recon, x) + vq_loss

@@ -7,6 +7,7 @@ so the oracle restatement (oracle.ops.vector_quantize, oracle.models.vq_vae) is 
 outputs of the reference itself:
   vq_quantizer.pt   VectorQuantizer.forward (nn/utils.py:53-96) in the three modes — EMA + training
                     (buffers before / after), EMA + eval, gradient-descent codebook — on a seeded input
+  vq_vae_2_small.pt one forward + backward of a small VectorQuantizedVAE2 (vq_vae_2.py:96-110)
   vq_vae_small.pt   one training step of a small VectorQuantizedVAE (vq_vae.py:69-81, loss of
                     vq_vae.py:127-136): state before, reconstruction, losses, every gradient,
                     state after forward (EMA buffers move in forward) and after the Adam step
@@ -79,7 +80,28 @@ def main():
            "torch_version": torch.__version__}
     path = os.path.join(HERE, "vq_vae_small.pt")
     torch.save(rec, path)
-    print(f"vq_vae_small: loss={float(loss):.6f} vq={float(vq_loss):.6f} norm={float(norm):.6f} "
+    print(f"vq_vae_small: loss={float(loss.detach()):.6f} vq={float(vq_loss.detach()):.6f} norm={float(norm):.6f} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+    # VQ-VAE-2 (vq_vae_2.py:96-110), one forward + backward of a small model
+    kwargs = dict(in_channels=3, out_channels=3, hidden_channels=16, n_residual_blocks=1,
+                  residual_channels=8, n_embeddings=10, embedding_dim=4)
+    torch.manual_seed(1)
+    model = ref.models.VectorQuantizedVAE2(**kwargs)
+    model.train()
+    state0 = _ref.clone_state(model)
+    xhat, vq_loss = model(x)
+    loss = F.mse_loss(xhat, x) + vq_loss
+    loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None)
+             for k, p in model.named_parameters()}
+    rec = {"ctor": "VectorQuantizedVAE2", "kwargs": kwargs, "x": x, "state0": state0,
+           "recon": xhat.detach().clone(), "vq_loss": vq_loss.detach().clone(),
+           "loss": loss.detach().clone(), "grads": grads,
+           "state_after_forward": _ref.clone_state(model), "torch_version": torch.__version__}
+    path = os.path.join(HERE, "vq_vae_2_small.pt")
+    torch.save(rec, path)
+    print(f"vq_vae_2_small: loss={float(loss.detach()):.6f} vq={float(vq_loss.detach()):.6f} "
           f"-> {os.path.getsize(path) / 1024:.0f} KiB")
 
 

@@ -121,3 +121,25 @@ def test_vq_vae_oracle_matches_reference_golden_step():
     pre = "_quantizer._net.1."
     for key in ("_embedding", "_cluster_size", "_embedding_avg"):  # EMA buffers move in forward
         _util.assert_close(vq[key[1:]], g["state_after_forward"][pre + key], 1e-6, key)
+
+
+def test_vq_vae_2_oracle_matches_reference_golden():
+    g = _util.load_golden("vq_vae_2_small")
+    state = {k: v.clone() for k, v in g["state0"].items()}
+    leaves = {k: v.requires_grad_(True) for k, v in state.items() if otrain.is_param(k)}
+    p = dict(state)
+    p.update(leaves)
+    xhat, vq_loss, (vq_t, vq_b) = omodels.vq_vae_2(p, g["x"], training=True)
+    loss = omodels.vq_vae_loss(xhat, g["x"], vq_loss)
+    _util.assert_close(xhat, g["recon"], 1e-5, "reconstruction")
+    _util.assert_close(vq_loss, g["vq_loss"], 1e-5, "quantization loss")
+    _util.assert_close(loss, g["loss"], 1e-5, "loss")
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)))
+    for k, want in g["grads"].items():
+        if want is None:
+            assert grads[k] is None, k
+        else:
+            _util.assert_close(grads[k], want, 2e-4, f"grad {k}")
+    for pre, vq in (("_quantizer_t._net.1.", vq_t), ("_quantizer_b._net.1.", vq_b)):
+        for key in ("_embedding", "_cluster_size", "_embedding_avg"):
+            _util.assert_close(vq[key[1:]], g["state_after_forward"][pre + key], 1e-6, pre + key)
