@@ -337,6 +337,32 @@ int pg_adam_prepare(float* state, void* stream);
 int pg_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* state,
                  float beta1, float beta2, float eps, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * SURVEY.md §8(f) rank 4 — vector quantisation (reference nn/utils.py:53-96) and the MSE loss of
+ * the VQ-VAE recipes (models/vae/vq_vae.py:127-136). csrc/vq.hip: compiled, NOT yet run on
+ * hardware (written after round 2's GPU budget was spent); reached only through
+ * pytorch_generative_amd/experimental/vq.py.
+ * ------------------------------------------------------------------------------------- */
+/* x (N, D, L) NCHW planes, embedding (K, D), D <= 64. Per position p = n*L + l: idx[p] = first
+ * argmin_k (|x|^2 + |e_k|^2) - 2 x.e_k (nn/utils.py:61-68); q = embedding[idx] in NCHW;
+ * st = x + (q - x) (the straight-through VALUE, :95); loss[0] += mean((x - q)^2) (:79; zeroed by caller) */
+int pg_vq_assign(const float* x, const float* embedding, int* idx, float* q, float* st, float* loss,
+                 int N, int D, int L, int K, void* stream);
+/* EMA codebook update in place (nn/utils.py:80-90): count / sum of x per code (workspaces count_ws
+ * (K), sum_ws (K*D), zeroed inside), cluster_size = cluster_size*decay + count*(1-decay), the same
+ * for embedding_avg, embedding = embedding_avg / (cluster_size + 1e-5) */
+int pg_vq_ema_update(const float* x, const int* idx, float* cluster_size, float* embedding_avg,
+                     float* embedding, float* count_ws, float* sum_ws, int N, int D, int L, int K,
+                     float decay, void* stream);
+/* dx = d_st + g_loss[0] * 2 (x - q) / n  (straight-through + commitment loss) */
+int pg_vq_bwd(const float* x, const float* q, const float* d_st, const float* g_loss, float* dx,
+              size_t n, void* stream);
+/* loss[0] += mean((a - b)^2) (zeroed by caller); da = g_loss[0] * 2 (a - b) / n, db = -da
+ * (either may be NULL) */
+int pg_mse_fwd(const float* a, const float* b, float* loss, size_t n, void* stream);
+int pg_mse_bwd(const float* a, const float* b, const float* g_loss, float* da, float* db, size_t n,
+               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,11 @@ SIGNATURES = {
     "pg_add": (c_i, [c_f, c_f, c_f, c_z, c_s]),
     "pg_add_bcast_fwd": (c_i, [c_f, c_f, c_f, c_i, c_z, c_s]),
     "pg_add_bcast_bwd": (c_i, [c_f, c_f, c_i, c_z, c_s]),
+    "pg_vq_assign": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_s]),
+    "pg_vq_ema_update": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, c_s]),
+    "pg_vq_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_z, c_s]),
+    "pg_mse_fwd": (c_i, [c_f, c_f, c_f, c_z, c_s]),
+    "pg_mse_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_z, c_s]),
     "pg_bce_logits_fwd": (c_i, [c_f, c_f, c_f, c_i, c_z, c_s]),
     "pg_bce_logits_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_z, c_s]),
     "pg_avgpool2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
