@@ -8,6 +8,10 @@ echo "-- default"
 timeout 120 python tools/exp/conv_ab.py gated "snail 2x2 64->128" 2>&1 | tail -4
 echo "-- wide"
 PG_CONV_B3_WIDE=1 timeout 120 python tools/exp/conv_ab.py gated "snail 2x2 64->128" 2>&1 | tail -4
+echo "-- vector epilogue"
+PG_B3_VEC_EP=1 timeout 120 python tools/exp/conv_ab.py gated snail 2>&1 | tail -5
+echo "-- wide + vector epilogue"
+PG_CONV_B3_WIDE=1 PG_B3_VEC_EP=1 timeout 120 python tools/exp/conv_ab.py gated "snail 2x2 64->128" 2>&1 | tail -4
 echo "== 2. f4 (VectorQuantizer / VQ-VAE / VQ-VAE-2) against the reference goldens"
 PG_TEST_F4=1 timeout 200 python -m pytest tests/test_gpu_f4.py -m gpu -q 2>&1 | tail -15
 echo "== 3. if 1. is correct and faster: whole models with the wide kernels"
