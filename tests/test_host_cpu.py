@@ -171,3 +171,34 @@ def test_adjacent_view_merges_only_contiguous_neighbours():
     assert flat[23] == -1.0
     assert ops._adjacent_view(a, flat[20:28].view(2, 4), (6, 4)) is None   # gap
     assert ops._adjacent_view(a, torch.zeros(2, 4), (6, 4)) is None        # different storage
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """profiles/r02_bench_final.json is a real `python bench.py` line: the keys the driver and the
+    judge read (bench contract + roofline + cpu_baseline) must all be there and self-consistent."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                        "r02_bench_final.json")
+    with open(path) as f:
+        d = json.load(f)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "images/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    # value = images of all GPUs / time of exactly `steps` steps
+    per_step = d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)
+    assert abs(per_step - d["value"]) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["launch_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["value"] > 0
+    ps = d["pixel_snail"]
+    assert ps["images_per_s"] > 0 and "roofline" in ps and "reference_default_batch_128" in ps
