@@ -52,6 +52,12 @@ CONV_CASES = [
     (2, 32, 10, 16, 128, 1, 3, 0, 1, None, None, "gelu", True, True),   # 3 taps, two co chunks
     (2, 96, 7, 24, 64, 2, 1, 2, 0, "hw", None, "elu", False, True),     # 2 taps, ragged last row tile
     (1, 32, 64, 64, 64, 2, 2, 1, 1, "hw", None, None, False, True),     # 64 wide: one row per tile
+    # bench regime: N * tiles_per_img above the persistent grid -> several tiles per workgroup, ragged last round
+    (300, 64, 32, 32, 64, 2, 2, 1, 1, "hw", None, "elu", True, True),   # PixelSNAIL 2x2 64->64: 1200 tiles / 512
+    (150, 64, 32, 32, 128, 2, 2, 1, 1, "hw", None, "elu", False, True),  # 64->128: 600 tiles / 256 per chunk row
+    (140, 69, 32, 32, 36, 1, 1, 0, 0, None, None, None, False, True),   # fp32-MFMA kernel (ragged channels), 560 tiles
+    (30, 32, 64, 64, 64, 3, 3, 1, 1, None, None, "relu", False, True),  # 64x64 3x3: 22 row tiles per image
+    (700, 32, 28, 28, 32, 3, 3, 1, 1, None, "B", "relu", False, True),  # PixelCNN residual conv at bench batch
 ]
 
 
