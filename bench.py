@@ -142,8 +142,11 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
     model.train()
     opt = optim.FlatAdam(model.parameters(), lr=w["lr"], lr_decay=w["decay"])
     reducer = None
-    if env.world > 1:
-        reducer = parallel.FlatGradAllReduce(opt)
+    if env.world > 1 or os.environ.get("PG_BENCH_FORCE_RCCL") == "1":
+        # world > 1 under the nccl backend: the direct-RCCL transport (pg_allreduce_sum), captured inside
+        # the step's graph; PG_BENCH_FORCE_RCCL=1 runs the same collective with a communicator of ONE
+        # rank (what a 1-GPU box can measure of it)
+        reducer = parallel.FlatGradAllReduce(opt, transport="rccl" if env.world == 1 else None)
         reducer.broadcast_parameters(src=0)
     x = synthetic_batch(batch, env.rank, w["chw"]).to(env.device)
     if name in ("beta_vae", "vd_vae"):
@@ -201,6 +204,9 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
     rec = {
         "images_per_s": value, "ms_per_step": elapsed / steps * 1e3, "per_gpu_batch": batch,
         "global_batch": batch * env.world, "launch": launch, "graph_fallback": fallback,
+        "grad_exchange": None if reducer is None else
+        f"{reducer.transport} all-reduce of the flat gradient ({opt.flat_grad.numel() * 4 / 1e6:.2f} MB), "
+        + ("inside the step graph" if (launch != "eager" and reducer.capturable) else "eager"),
         "loss_nats_per_image": loss_val, "bits_per_dim": loss_val / (dims * LN2),
         # whole step against the per-image algorithmic work of SURVEY.md §8(d)
         "step_hbm_gbps_algorithmic": value * w["mbytes"] * 1e6 / 1e9,
@@ -210,6 +216,9 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
         rec["step_tflops"] = value * w["gflop_causal"] / 1e3
         rec["step_frac_of_fp32_peak"] = rec["step_tflops"] / env.world / FP32_PEAK_TFLOPS
     del model, opt, step
+    if reducer is not None:
+        torch.cuda.synchronize()
+        reducer.close()
     torch.cuda.empty_cache()
     return rec
 

@@ -339,9 +339,9 @@ int pg_adam_step(float* p, const float* g, float* m, float* v, size_t n, const f
 
 /* ---------------------------------------------------------------------------------------
  * SURVEY.md §8(f) rank 4 — vector quantisation (reference nn/utils.py:53-96) and the MSE loss of
- * the VQ-VAE recipes (models/vae/vq_vae.py:127-136). csrc/vq.hip: compiled, NOT yet run on
- * hardware (written after round 2's GPU budget was spent); reached only through
- * pytorch_generative_amd/experimental/vq.py.
+ * the VQ-VAE recipes (models/vae/vq_vae.py:127-136). csrc/vq.hip; reached through
+ * pytorch_generative_amd/nn/utils.py (VectorQuantizer, mse_loss). Validated on MI355X against outputs
+ * of the reference (tests/test_gpu_f4.py).
  * ------------------------------------------------------------------------------------- */
 /* x (N, D, L) NCHW planes, embedding (K, D), D <= 64. Per position p = n*L + l: idx[p] = first
  * argmin_k (|x|^2 + |e_k|^2) - 2 x.e_k (nn/utils.py:61-68); q = embedding[idx] in NCHW;
@@ -362,6 +362,27 @@ int pg_vq_bwd(const float* x, const float* q, const float* d_st, const float* g_
 int pg_mse_fwd(const float* a, const float* b, float* loss, size_t n, void* stream);
 int pg_mse_bwd(const float* a, const float* b, const float* g_loss, float* da, float* db, size_t n,
                void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Data-parallel exchange step: replaces DistributedDataParallel's gradient
+ * all-reduce (reference trainer.py:78-82; process group of train.py:27-37) by ONE RCCL all-reduce of
+ * the flat gradient buffer over xGMI. csrc/comm.hip binds librccl at run time (the copy the process
+ * already carries, if any). One communicator per process (= per GPU).
+ *   rank 0: pg_comm_unique_id(id) -> ship the 128 bytes to every rank out of band (the host side uses
+ *   the torch.distributed rendezvous for that and for nothing else) -> every rank: pg_comm_init.
+ * pg_allreduce_sum / pg_broadcast are in place, asynchronous, enqueue only on `stream`, do not
+ * allocate or synchronise: they may be captured inside the hipGraph of the training step.
+ * Return values: 0, PG_E*, or 1000 + ncclResult_t.
+ * ------------------------------------------------------------------------------------- */
+#define PG_COMM_ID_BYTES 128
+#define PG_DTYPE_F32 0
+int pg_comm_unique_id(char id[PG_COMM_ID_BYTES]);
+int pg_comm_init(int rank, int world, const char id[PG_COMM_ID_BYTES]); /* on the current device */
+int pg_comm_world(void);        /* world size of the live communicator, 0 if none */
+int pg_comm_rccl_version(void); /* ncclGetVersion of the bound library, 0 if it cannot be bound */
+int pg_allreduce_sum(void* buf, size_t n, int dtype, void* stream);
+int pg_broadcast(void* buf, size_t n, int dtype, int root, void* stream);
+int pg_comm_destroy(void);
 
 #ifdef __cplusplus
 }

@@ -104,19 +104,14 @@ __device__ __forceinline__ void split8t(const float (&x)[8], u32x4& h, u32x4& m,
 #define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
 
 // CG = output-channel chunks per workgroup. CG = 1: 4 waves, one 64-channel chunk (two workgroups per
-// CU). CG = 2 ("wide", EXPERIMENTAL, PG_CONV_B3_WIDE=1, not measured yet): 8 waves = two 64-channel
-// chunks x four pixel quarters sharing ONE staged x tile — for Cout >= 128 every chunk re-stages the
-// same tile today (loads + activation + split are ~30 % of a launch), the wide workgroup halves that
-// per MFMA; both chunks of a gate input also meet in one workgroup (a later gate-fusing epilogue).
-// VEP ("vector epilogue", EXPERIMENTAL, PG_B3_VEC_EP=1, not measured yet): after the per-wave LDS
-// transposition a lane takes 4 consecutive PIXELS of 4 channels (float4 LDS reads, float4 operand
-// loads, float4 stores: 16 store instructions of 1 KB per wave and 16-channel tile instead of 64 of
-// 256 B). The epilogue is the second largest phase of a launch (34 of 132 us on the 2x2 64 -> 64)
-// and store-instruction bound. Needs OW % 4 == 0 and 16-byte aligned out / res / dact_src.
-// (As compiled today the NT = 3 / 4 instantiations spill 20-64 VGPRs — the kernel sits at the 256-register
-// limit and float4 temporaries need aligned quads; if the first measurement is not clearly better, move
-// the issue of step s + 2 behind the epilogue in this variant to free the prefetch registers.)
-template <int MT, int NT, int CG, bool VEP>
+// CU). CG = 2 ("wide", the default for Cout % 128 == 0; PG_CONV_B3_WIDE=0 for A/B): 8 waves = two
+// 64-channel chunks x four pixel quarters sharing ONE staged x tile — with one chunk per workgroup every
+// chunk re-stages the same tile (loads + activation + split are ~30 % of a launch). Measured on MI355X
+// (round 3, tools/exp/conv_ab.py): forward 2x2 64 -> 128 75 -> 68 us, 2x1 256 -> 256 71 -> 64 us, 1x3
+// 128 -> 256 59 -> 56 us; GatedPixelCNN 4.27 -> 4.54 k img/s at batch 512. Both halves of a gate input
+// also meet in one workgroup. (A float4 "vector epilogue" variant was measured in the same call and
+// dropped: 136.6 vs 133 us on the 2x2 64 -> 64, slower combined with CG = 2 — it spilled registers.)
+template <int MT, int NT, int CG>
 __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kernel(const B3Args a) {
   constexpr int THREADS = B3_THREADS * CG;
   constexpr int XS = CG == 1 ? B3_XS : (B3_XS + 1) / 2;  // the tile's slots over twice the threads
@@ -156,15 +151,6 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
     const int pc = sok ? pw : 0;
     const int r = pc / a.OW;
     so_rel = (size_t)co0 * L + (size_t)((row0 + r) * a.OW + (pc - r * a.OW));
-  }
-  // VEP: this lane's pixel quad 4 * (lane & 15) .. + 3 of the wave's NT * 16 pixels
-  const int pw4 = wave * (NT * 16) + 4 * (lane & 15);
-  const bool sok4 = VEP && (4 * (lane & 15) < NT * 16) && pw4 < npx;
-  size_t so_rel4 = 0;
-  if constexpr (VEP) {
-    const int pc = sok4 ? pw4 : 0;
-    const int r = pc / a.OW;
-    so_rel4 = (size_t)co0 * L + (size_t)((row0 + r) * a.OW + (pc - r * a.OW));
   }
   // per group g = 4 ks + kq: where it lives — plane of its channel group + tap offset (LDS table)
   int* gtab = reinterpret_cast<int*>(lds + a.b_off + B3_CO_CHUNK * CG);
@@ -309,123 +295,11 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       // ---- epilogue (as conv_mfma.hip): + bias, out_act, + res, * act'(dact_src); per-wave
       // transposition scratch of its own (the tiles already hold the next step)
       const int n_img = n_first + tl * nstep;
-      const size_t so = (VEP ? so_rel4 : so_rel) + (size_t)n_img * a.Cout * L;
+      const size_t so = so_rel + (size_t)n_img * a.Cout * L;
       float* ep = lds + a.ep_off + wave_all * (16 * EPS);
       const int cvalid = a.Cout - co0;
       float* outp = a.out + so;
       const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
-      if constexpr (VEP) {
-        // lane = (pixel quad pq, channel quad cq): rows cq * 4 + j of the transposed tile, columns 4 pq .. + 3
-        const int pq4 = 4 * (lane & 15), cq4 = 4 * (lane >> 4);
-        const float* op1 = (has_res ? a.res : a.dact_src) + so;  // dereferenced only if has_res / has_ds
-        const float* op2 = (has_res && has_ds) ? a.dact_src + so : nullptr;
-        const int dsel = has_ds ? a.dact : PG_ACT_NONE;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          float4 ov[4];  // this tile's (first) operand values, requested before its stores
-          if (has_res || has_ds) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int cc = m * 16 + cq4 + j;
-              ov[j] = *reinterpret_cast<const float4*>(op1 + (size_t)(cc < cvalid ? cc : 0) * L);
-            }
-          }
-#pragma unroll
-          for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[m][n][r];
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          // two channels at a time (the whole quad's values + operands at once spilled ~50 registers)
-#pragma unroll
-          for (int jh = 0; jh < 4; jh += 2) {
-            float v[2][4];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-              const float4 t = *reinterpret_cast<const float4*>(ep + (cq4 + jh + jj) * EPS + pq4);
-              const float b = bl[m * 16 + cq4 + jh + jj];
-              v[jj][0] = t.x + b; v[jj][1] = t.y + b; v[jj][2] = t.z + b; v[jj][3] = t.w + b;
-            }
-            switch (a.out_act) { /* wave-uniform */
-              case PG_ACT_RELU:
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) v[jj][i] = pg_apply_act(v[jj][i], PG_ACT_RELU);
-                break;
-              case PG_ACT_ELU:
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) v[jj][i] = pg_apply_act(v[jj][i], PG_ACT_ELU);
-                break;
-              case PG_ACT_GELU:
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) v[jj][i] = pg_apply_act(v[jj][i], PG_ACT_GELU);
-                break;
-              default: break;
-            }
-            if (has_res || has_ds) {
-              float sv[2][4];
-#pragma unroll
-              for (int jj = 0; jj < 2; ++jj) {
-                const float4 o4 = ov[jh + jj];
-                const float o[4] = {o4.x, o4.y, o4.z, o4.w};
-                if (has_res) {
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) v[jj][i] += o[i];
-                  if (op2) {
-                    const int cc = m * 16 + cq4 + jh + jj;
-                    const float4 t = *reinterpret_cast<const float4*>(op2 + (size_t)(cc < cvalid ? cc : 0) * L);
-                    sv[jj][0] = t.x; sv[jj][1] = t.y; sv[jj][2] = t.z; sv[jj][3] = t.w;
-                  }
-                } else {
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) sv[jj][i] = o[i];
-                }
-              }
-              switch (dsel) {
-                case PG_ACT_RELU:
-#pragma unroll
-                  for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[jj][i] *= pg_act_grad(sv[jj][i], PG_ACT_RELU);
-                  break;
-                case PG_ACT_ELU:
-#pragma unroll
-                  for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[jj][i] *= pg_act_grad(sv[jj][i], PG_ACT_ELU);
-                  break;
-                case PG_ACT_GELU:
-#pragma unroll
-                  for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[jj][i] *= pg_act_grad(sv[jj][i], PG_ACT_GELU);
-                  break;
-                case PG_ACT_ELU_OUT:
-#pragma unroll
-                  for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[jj][i] *= pg_act_grad(sv[jj][i], PG_ACT_ELU_OUT);
-                  break;
-                default: break;
-              }
-            }
-            if (sok4) {
-#pragma unroll
-              for (int jj = 0; jj < 2; ++jj) {
-                const int cc = m * 16 + cq4 + jh + jj;
-                if (cc < cvalid)
-                  *reinterpret_cast<float4*>(outp + (size_t)cc * L) =
-                      make_float4(v[jj][0], v[jj][1], v[jj][2], v[jj][3]);
-              }
-            }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scratch reads done before the next tile's writes
-        }
-      } else {
 #define PG_B3_TILE_BODY(M)                                                                       \
   _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
   _Pragma("unroll") for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[M][n][r]; \
@@ -509,7 +383,6 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       }
 #undef PG_B3_TILE_BODY
 #undef PG_B3_TILE_STORE
-      }  // !VEP
     }
     if (last_chunk) {
 #pragma unroll
@@ -629,17 +502,17 @@ int b3_rows(int T, int OH, int OW, int hr, int hc) {
   return (OH + nt_rows - 1) / nt_rows;
 }
 
-template <int MT, int CG = 1, bool VEP = false>
+template <int MT, int CG = 1>
 void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
-  static bool big[5] = {false, false, false, false, false};
+  // the LDS opt-in is set once per instantiation by a function-local static initialiser: thread-safe
+  // (the library is entered from the main thread and from the autograd thread)
 #define PG_B3_L(NTV)                                                                                  \
   {                                                                                                   \
-    if (shmem > 64 * 1024 && !big[NTV]) {                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV, CG, VEP>),      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, CG == 1 ? 80 * 1024 : 160 * 1024); \
-      big[NTV] = true;                                                                                \
-    }                                                                                                 \
-    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV, CG, VEP>), grid, dim3(B3_THREADS * CG), shmem, st, a); \
+    static const hipError_t attr_##NTV = hipFuncSetAttribute(                                         \
+        reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV, CG>),                                   \
+        hipFuncAttributeMaxDynamicSharedMemorySize, CG == 1 ? 80 * 1024 : 160 * 1024);                \
+    (void)attr_##NTV;                                                                                 \
+    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV, CG>), grid, dim3(B3_THREADS * CG), shmem, st, a);     \
   }
   switch (nt) {
     case 1: PG_B3_L(1) break;
@@ -739,8 +612,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   const size_t x16 = (size_t)pl.cgs * 3 * a.plane16;
   a.dump16 = (int)x16;              // one spare 16-byte entry (+ padding to a 256-byte boundary)
   a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
-  // EXPERIMENTAL wide workgroups (two output chunks share one staged x tile): opt-in, not yet measured
-  static const bool wide_on = []() { const char* e = getenv("PG_CONV_B3_WIDE"); return e && e[0] == '1'; }();
+  // wide workgroups (two output chunks share one staged x tile): default; PG_CONV_B3_WIDE=0 for A/B
+  static const bool wide_on = []() { const char* e = getenv("PG_CONV_B3_WIDE"); return !(e && e[0] == '0'); }();
   const int CG = (wide_on && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0) ? 2 : 1;
   size_t shmem = (size_t)a.w_off16 * 16 + pl.w_bytes * CG;
   a.ep_off = (int)(shmem / 4);
@@ -755,19 +628,9 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   long gx = (want / a.tiles_per_img) * a.tiles_per_img;
   if (gx > (long)N * a.tiles_per_img) gx = (long)N * a.tiles_per_img;
   dim3 grid((unsigned)gx, (unsigned)chunks_y);
-  // EXPERIMENTAL vector epilogue: opt-in, not yet measured
-  static const bool vep_on = []() { const char* e = getenv("PG_B3_VEC_EP"); return e && e[0] == '1'; }();
-  const bool vep = vep_on && pl.MT == 4 && OW % 4 == 0 &&
-                   (((uintptr_t)out | (uintptr_t)res | (uintptr_t)dact_src) & 15) == 0;
   if (CG == 2) {
-    if (vep) b3_launch<4, 2, true>(a, nt, grid, shmem, st);
-    else b3_launch<4, 2>(a, nt, grid, shmem, st);
+    b3_launch<4, 2>(a, nt, grid, shmem, st);
     PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, wide)");
-    return 0;
-  }
-  if (vep) {
-    b3_launch<4, 1, true>(a, nt, grid, shmem, st);
-    PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, vector epilogue)");
     return 0;
   }
   switch (pl.MT) {

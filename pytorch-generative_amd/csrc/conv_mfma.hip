@@ -428,12 +428,10 @@ inline int mf_chunks(int M) { return (M + MF_CO_CHUNK - 1) / MF_CO_CHUNK; }
 
 template <int MT, int NT>
 void mf_launch_one(const MfArgs& a, dim3 grid, size_t shmem, hipStream_t st) {
-  static bool big_lds = false;  // benign race: the attribute call is idempotent
-  if (shmem > 64 * 1024 && !big_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<MT, NT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    big_lds = true;
-  }
+  // function-local static initialiser: thread-safe one-time LDS opt-in (main + autograd thread)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<MT, NT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  (void)attr;
   hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(MF_THREADS), shmem, st, a);
 }
 

@@ -499,23 +499,26 @@ __global__ void __launch_bounds__(256) seg_reduce_kernel(const SegArgs a) {
 // waves per SIMD by their register counts), at least `min_tiles` tiles per wave. which: 0 head fwd,
 // 1 head bwd, 2 tail fwd, 3 tail bwd. PG_BLOCK_GRID="a,b,c,d" overrides the caps (tuning).
 int grid_blocks(int which, int N, int L) {
-  static int cap[4] = {0, 0, 0, 0};
-  if (cap[0] == 0) {
-    cap[0] = 2048; cap[1] = 768; cap[2] = 2048; cap[3] = 512;  // measured: head bwd 79.8 us at 512, 68.9 at 768
+  // immutable init-once tables (function-local static with an initialiser: thread-safe; the library
+  // is entered from the main thread and from the autograd thread)
+  struct Cfg { int cap[4]; int mt[2]; };
+  static const Cfg cfg = []() {
+    Cfg c = {{2048, 768, 2048, 512},  // measured: head bwd 79.8 us at 512, 68.9 at 768
+             {1, 2}};                 // tiles per wave below which the grid shrinks (forward, backward);
+                                      // measured at batch 64: (4, 8) 1.82 ms/step, (2, 4) 1.59, (1, 2) 1.53, (1, 1) 1.56
     if (const char* e = getenv("PG_BLOCK_GRID")) {
       int v[4];
       if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
-        for (int i = 0; i < 4; ++i) cap[i] = v[i];
+        for (int i = 0; i < 4; ++i) c.cap[i] = v[i];
     }
-  }
-  static int mt_cfg[2] = {0, 0};  // tiles per wave below which the grid shrinks: forward, backward
-  if (mt_cfg[0] == 0) {
-    mt_cfg[0] = 1; mt_cfg[1] = 2;  // measured at batch 64: (4, 8) 1.82 ms/step, (2, 4) 1.59, (1, 2) 1.53, (1, 1) 1.56
     if (const char* e = getenv("PG_BLOCK_MINTILES")) {
       int f = 0, b = 0;
-      if (sscanf(e, "%d,%d", &f, &b) == 2 && f > 0 && b > 0) { mt_cfg[0] = f; mt_cfg[1] = b; }
+      if (sscanf(e, "%d,%d", &f, &b) == 2 && f > 0 && b > 0) { c.mt[0] = f; c.mt[1] = b; }
     }
-  }
+    return c;
+  }();
+  const int* cap = cfg.cap;
+  const int* mt_cfg = cfg.mt;
   const int min_tiles = (which & 1) ? mt_cfg[1] : mt_cfg[0];
   const long tiles = (long)N * (L / 16);
   long b = (tiles + 4 * min_tiles - 1) / (4 * min_tiles);
@@ -637,12 +640,9 @@ PG_EXPORT int pg_gpt_block_tail_bwd(const float* o, const float* x, const float*
   hipStream_t st = (hipStream_t)stream;
   const size_t tr = (size_t)4 * (2 * HD + 2 * C) * TS + 64 * 64, rd = (size_t)4 * T_PART;
   const size_t shmem = (tr > rd ? tr : rd) * sizeof(float);  // 66.4 KB: above the 64 KB default
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail_bwd_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_bwd_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  (void)attr;  // thread-safe one-time opt-in
   hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)blocks), dim3(GB_THREADS), shmem, st, a);
   PG_LAUNCH_CHECK("pg_gpt_block_tail_bwd");
   SegArgs r = {};

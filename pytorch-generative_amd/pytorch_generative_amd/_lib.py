@@ -115,7 +115,16 @@ SIGNATURES = {
     "pg_sumsq_accum": (c_i, [c_f, c_z, c_f, c_s]),
     "pg_adam_prepare": (c_i, [c_f, c_s]),
     "pg_adam_step": (c_i, [c_f, c_f, c_f, c_f, c_z, c_f, c_flt, c_flt, c_flt, c_s]),
+    "pg_comm_unique_id": (c_i, [ctypes.c_char_p]),
+    "pg_comm_init": (c_i, [c_i, c_i, ctypes.c_char_p]),
+    "pg_comm_world": (c_i, []),
+    "pg_comm_rccl_version": (c_i, []),
+    "pg_allreduce_sum": (c_i, [c_f, c_z, c_i, c_s]),
+    "pg_broadcast": (c_i, [c_f, c_z, c_i, c_i, c_s]),
+    "pg_comm_destroy": (c_i, []),
 }
+COMM_ID_BYTES = 128
+DTYPE_F32 = 0
 
 _lib = None
 
@@ -150,6 +159,8 @@ def check(rc, what):
     msg = load().pg_last_error().decode("utf-8", "replace")
     if rc < 0:
         raise ValueError(f"{what}: {msg} (status {rc})")
+    if rc >= 1000:
+        raise RuntimeError(f"{what}: {msg}")
     raise RuntimeError(f"{what}: HIP error {rc}: {msg}")
 
 

@@ -7,7 +7,7 @@
 Code written against the reference's public surface (pytorch_generative/__init__.py:1-3,
 nn/__init__.py:3-13, models/__init__.py:3-24, models/<family>/<module>.reproduce, trainer.Trainer)
 then runs unmodified on the HIP operator path for the components this package covers; names of
-out-of-scope components (NADE, MADE, NICE, VQ-VAE, KDE, mixtures, `models.flow`) resolve to
+out-of-scope components (NADE, MADE, NICE, KDE, mixtures, `models.flow`) resolve to
 placeholders that raise on use.
 """
 
@@ -19,10 +19,8 @@ import pytorch_generative_amd as _pkg
 _OUT_OF_SCOPE_MODULES = {
     "pytorch_generative.models.flow": ("nice",),
     "pytorch_generative.models.autoregressive": ("nade", "made", "fvbn"),
-    "pytorch_generative.models.vae": ("vq_vae", "vq_vae_2"),
 }
-_OUT_OF_SCOPE_MODELS = ("NADE", "MADE", "FullyVisibleBeliefNetwork", "NICE", "VectorQuantizedVAE",
-                        "VectorQuantizedVAE2", "GaussianKernel", "ParzenWindowKernel",
+_OUT_OF_SCOPE_MODELS = ("NADE", "MADE", "FullyVisibleBeliefNetwork", "NICE", "GaussianKernel", "ParzenWindowKernel",
                         "KernelDensityEstimator", "BernoulliMixtureModel", "GaussianMixtureModel")
 
 
@@ -48,6 +46,9 @@ def install_alias(name="pytorch_generative"):
     pairs = {
         name: _pkg,
         f"{name}.nn": _pkg.nn,
+        f"{name}.nn.utils": _pkg.nn.utils,
+        f"{name}.nn.attention": _pkg.nn.attention,
+        f"{name}.nn.convolution": _pkg.nn.convolution,
         f"{name}.models": _pkg.models,
         f"{name}.models.base": _pkg.models.base,
         f"{name}.models.autoregressive": _pkg.models.autoregressive,

@@ -5,7 +5,9 @@ CIFAR-10 downloads. Neither torchvision nor a network exists on the MI355X boxes
 built for, and the training path only needs tensors of the right shape and value range, so the
 loaders here produce SYNTHETIC batches with the statistics SURVEY.md §8(d) fixes (binarised-MNIST
 shaped Bernoulli(0.1307) pixels; CIFAR shaped uniform 8-bit values / 255), generated on the device
-once per loader. Real data: pass any iterable of (x, y) batches as `debug_loader` to reproduce(),
+once per loader. Data parallel: the reference has no DistributedSampler — every rank shuffles the whole
+set with its own RNG (datasets.py:53-58) — so here every rank draws its OWN batches: the seed is
+`base seed + rank` ("seed 1234 + r"), never the same batches on all ranks. Real data: pass any iterable of (x, y) batches as `debug_loader` to reproduce(),
 or to Trainer directly.
 """
 
@@ -26,6 +28,11 @@ class SyntheticLoader:
                 x = torch.bernoulli(torch.full(shape, 0.1307), generator=g)
             elif kind == "uniform8":
                 x = torch.randint(0, 256, shape, generator=g).float() / 255
+            elif kind == "uniform8_normalized":  # transforms.Normalize of datasets.py:170-174
+                x = torch.randint(0, 256, shape, generator=g).float() / 255
+                mean = torch.tensor((0.4914, 0.4822, 0.4465)).view(1, 3, 1, 1)
+                std = torch.tensor((0.2023, 0.1994, 0.2010)).view(1, 3, 1, 1)
+                x = (x - mean) / std
             elif kind == "dequantized":
                 x = (torch.randint(0, 256, shape, generator=g).float() + torch.rand(shape, generator=g)) / 256
             else:
@@ -39,11 +46,18 @@ class SyntheticLoader:
         return len(self.batches)
 
 
+def _rank():
+    import torch.distributed as dist
+
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def _pair(shape, kind, train_batches, test_batches):
     warnings.warn("pytorch_generative_amd.datasets: no dataset download on this path — using synthetic "
                   f"{kind} batches of shape {tuple(shape)}")
-    return (SyntheticLoader(shape, train_batches, kind, seed=1234),
-            SyntheticLoader(shape, test_batches, kind, seed=4321))
+    r = _rank()  # per-rank batches (the loaders are built after Trainer / train.py initialised the group)
+    return (SyntheticLoader(shape, train_batches, kind, seed=1234 + r),
+            SyntheticLoader(shape, test_batches, kind, seed=4321 + r))
 
 
 def get_mnist_loaders(batch_size, dynamically_binarize=False, dequantize=False, resize_to_32=False,
@@ -59,6 +73,5 @@ def get_mnist_loaders(batch_size, dynamically_binarize=False, dequantize=False, 
 
 def get_cifar10_loaders(batch_size, normalize=False, train_batches=64, test_batches=8):
     """(train_loader, test_loader) of CIFAR-10-shaped synthetic batches (datasets.py:156-178)."""
-    if normalize:
-        raise ValueError("synthetic CIFAR-shaped batches are in [0, 1]; normalize=True is not provided")
-    return _pair((batch_size, 3, 32, 32), "uniform8", train_batches, test_batches)
+    return _pair((batch_size, 3, 32, 32), "uniform8_normalized" if normalize else "uniform8",
+                 train_batches, test_batches)

@@ -7,9 +7,20 @@ Adam, lr decay) is captured ONCE into a hipGraph and replayed per batch with sta
 Every kernel of libpg_hip.so is capture-safe by construction (no allocation, no sync, launches
 only on the stream it is given).
 
-With data parallelism the RCCL all-reduce of the flat gradient sits between two graphs
-(forward+backward | all-reduce | norm+Adam) so the collective itself stays an ordinary eager
-RCCL call on a side stream.
+With data parallelism the RCCL all-reduce of the flat gradient (`pg_allreduce_sum`, csrc/comm.hip: a
+direct librccl call on the step's stream) is captured INSIDE the same graph, between backward and
+the norm / Adam kernels: still one graph launch per step. Only the development transport (gloo
+through pinned host memory, two processes on one GPU) cannot be captured; there the step is split
+into two graphs (forward+backward | all-reduce | norm+Adam) around the eager collective.
+
+Warm-up iterations before the capture are real steps; with `preserve_state=True` everything they
+touched is rolled back: parameters, Adam moments, step / lr counters AND every module buffer (e.g. the
+VectorQuantizer's EMA codebook, which its forward updates in place).
+
+Python inside `forward_fn` / `loss_fn` runs during warm-up and capture only — NOT on every replay.
+Step-dependent host logic (annealing schedules, counters, `.item()`) must live outside the captured
+step; `trainer.Trainer` therefore uses the graph only when its `train_one_batch` hook is not
+overridden (or the caller opts in).
 """
 
 import torch
@@ -35,7 +46,8 @@ class GraphedTrainStep:
         if forward_fn is None:
             forward_fn = lambda x, y: loss_fn(x, model(x))  # noqa: E731
         self.forward_fn = forward_fn
-        self.split = reducer is not None and reducer.world > 1
+        self.reduce = reducer is not None and reducer.active
+        self.split = self.reduce and not reducer.capturable
         self.static_x = example_x.clone()
         self.static_y = None if example_y is None else example_y.clone()
         self.static_out = None
@@ -44,12 +56,13 @@ class GraphedTrainStep:
         if preserve_state:
             saved = [t.clone() for t in (optimizer.flat_param, optimizer.exp_avg, optimizer.exp_avg_sq,
                                          optimizer.state_block)]
+            saved_buffers = [(b, b.clone()) for b in model.buffers()]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup_iters):
                 self._fwd_bwd()
-                if self.split:
+                if self.reduce:
                     reducer.all_reduce()
                 self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
@@ -58,6 +71,8 @@ class GraphedTrainStep:
             for dst, src in zip((optimizer.flat_param, optimizer.exp_avg, optimizer.exp_avg_sq,
                                  optimizer.state_block), saved):
                 dst.copy_(src)
+            for b, src in saved_buffers:
+                b.copy_(src)
 
         # thread_local: RCCL's watchdog thread may touch the HIP runtime while we capture
         mode = dict(capture_error_mode="thread_local")
@@ -65,6 +80,8 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph_a, **mode):
             self.static_out = self._fwd_bwd()
             if not self.split:
+                if self.reduce:
+                    reducer.all_reduce()  # captured: an ordinary stream op of the C-ABI
                 self.opt.step()
         self.graph_b = None
         if self.split:

@@ -9,5 +9,8 @@ from pytorch_generative_amd.models.autoregressive.pixel_snail import PixelSNAIL
 from pytorch_generative_amd.models.vae.beta_vae import BetaVAE
 from pytorch_generative_amd.models.vae.vae import VAE
 from pytorch_generative_amd.models.vae.vd_vae import VeryDeepVAE
+from pytorch_generative_amd.models.vae.vq_vae import VectorQuantizedVAE
+from pytorch_generative_amd.models.vae.vq_vae_2 import VectorQuantizedVAE2
 
-__all__ = ["GatedPixelCNN", "ImageGPT", "PixelCNN", "PixelSNAIL", "VAE", "BetaVAE", "VeryDeepVAE"]
+__all__ = ["GatedPixelCNN", "ImageGPT", "PixelCNN", "PixelSNAIL", "VAE", "BetaVAE", "VeryDeepVAE",
+           "VectorQuantizedVAE", "VectorQuantizedVAE2"]

@@ -1,3 +1,3 @@
 """VAE family of the hot path (layout of pytorch_generative.models.vae)."""
 
-from pytorch_generative_amd.models.vae import beta_vae, vae, vaes, vd_vae  # noqa: F401
+from pytorch_generative_amd.models.vae import beta_vae, vae, vaes, vd_vae, vq_vae, vq_vae_2  # noqa: F401

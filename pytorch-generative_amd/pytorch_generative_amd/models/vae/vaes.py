@@ -47,6 +47,7 @@ from torch import nn  # noqa: E402
 
 from pytorch_generative_amd import nn as pg_nn  # noqa: E402
 from pytorch_generative_amd import ops  # noqa: E402
+from pytorch_generative_amd.nn import utils as nn_utils  # noqa: E402
 
 
 class ResidualBlock(nn.Module):
@@ -143,3 +144,17 @@ class Decoder(nn.Module):
             else:  # nn.ReLU marker
                 pending_relu = True
         return x
+
+
+class Quantizer(nn.Module):
+    """vaes.py:244-264: 1x1 convolution to the embedding width, then the VectorQuantizer."""
+
+    def __init__(self, in_channels, n_embeddings, embedding_dim):
+        super().__init__()
+        self._net = nn.Sequential(
+            pg_nn.Conv2d(in_channels=in_channels, out_channels=embedding_dim, kernel_size=1),
+            nn_utils.VectorQuantizer(n_embeddings, embedding_dim),
+        )
+
+    def forward(self, x):
+        return self._net[1](self._net[0](x))

@@ -8,6 +8,7 @@ from pytorch_generative_amd.nn.convolution import (
     GatedActivation,
     NCHWLayerNorm,
 )
+from pytorch_generative_amd.nn.utils import VectorQuantizer
 
 __all__ = [
     "CausalAttention",
@@ -17,4 +18,5 @@ __all__ = [
     "ConvTranspose2d",
     "GatedActivation",
     "NCHWLayerNorm",
+    "VectorQuantizer",
 ]

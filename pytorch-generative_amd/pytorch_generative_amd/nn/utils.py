@@ -1,15 +1,11 @@
-"""VectorQuantizer / Quantizer / VQ-VAE / VQ-VAE-2 on the HIP operator path — SURVEY.md §8(f) rank 4.
+"""VectorQuantizer on the HIP operator path (reference nn/utils.py:16-96) — SURVEY.md §8(f) rank 4.
 
-Mirrors reference nn/utils.py:16-96 (VectorQuantizer), models/vae/vaes.py:244-264 (Quantizer),
-models/vae/vq_vae.py:19-81 and models/vae/vq_vae_2.py:21-110: same constructor signatures, the same
-state_dict keys / shapes (buffers `_embedding`, `_cluster_size`, `_embedding_avg`), EMA update inside
-forward when training.
-
-STATUS: written at the end of round 2 after the GPU budget was spent. The kernels (csrc/vq.hip)
-compile for gfx950 but this module has NOT run on hardware yet; its parity tests
-(tests/test_gpu_f4.py, against the pinned oracle of oracle.ops.vector_quantize / oracle.models.vq_vae*)
-are opt-in (PG_TEST_F4=1) until it has. Only `use_ema=True` (the reference default and what the VQ-VAE
-models use) is implemented; the gradient-descent codebook raises.
+Same constructor signature, the same state_dict keys / shapes (buffers `_embedding`, `_cluster_size`,
+`_embedding_avg`), EMA codebook update inside forward when training. Kernels: csrc/vq.hip (assignment
+with the reference's distance form and first-minimum rule, EMA update, straight-through backward, MSE
+loss). Validated on MI355X against outputs of the reference (tests/golden/vq_*.pt, tests/test_gpu_f4.py).
+Only `use_ema=True` (the reference default and what the VQ-VAE models use) is implemented; the
+gradient-descent codebook raises. `ReZeroWrapper` (nn/utils.py:7-13) is not on the named path.
 """
 
 import torch
@@ -17,8 +13,6 @@ from torch import nn
 from torch.nn import init
 
 from pytorch_generative_amd import _lib, ops
-from pytorch_generative_amd import nn as pg_nn
-from pytorch_generative_amd.models.vae import vaes
 
 
 class _VectorQuantize(torch.autograd.Function):
@@ -117,74 +111,3 @@ class VectorQuantizer(nn.Module):
                                               self._decay, self.training)
         self.last_indices = idx
         return st, loss
-
-
-class Quantizer(nn.Module):
-    """vaes.py:244-264: 1x1 convolution to the embedding width, then the VectorQuantizer."""
-
-    def __init__(self, in_channels, n_embeddings, embedding_dim):
-        super().__init__()
-        self._net = nn.Sequential(
-            pg_nn.Conv2d(in_channels=in_channels, out_channels=embedding_dim, kernel_size=1),
-            VectorQuantizer(n_embeddings, embedding_dim),
-        )
-
-    def forward(self, x):
-        return self._net[1](self._net[0](x))
-
-
-class VectorQuantizedVAE(vaes.VariationalAutoEncoder):
-    """vq_vae.py:19-81."""
-
-    def __init__(self, in_channels=1, out_channels=1, hidden_channels=128, n_residual_blocks=2,
-                 residual_channels=32, n_embeddings=128, embedding_dim=16, sample_fn=None):
-        super().__init__(sample_fn)
-        self._encoder = vaes.Encoder(in_channels, hidden_channels, hidden_channels, n_residual_blocks,
-                                     residual_channels, stride=4)
-        self._quantizer = Quantizer(hidden_channels, n_embeddings, embedding_dim)
-        self._decoder = vaes.Decoder(embedding_dim, out_channels, hidden_channels, n_residual_blocks,
-                                     residual_channels, stride=4)
-
-    def forward(self, x):
-        quantized, quantization_loss = self._quantizer(self._encoder(x))
-        return self._decoder(quantized), quantization_loss
-
-    def _sample(self, n_samples):
-        raise NotImplementedError("VQ-VAE does not support sampling.")
-
-
-class VectorQuantizedVAE2(vaes.VariationalAutoEncoder):
-    """vq_vae_2.py:21-110."""
-
-    def __init__(self, in_channels=1, out_channels=1, hidden_channels=128, n_residual_blocks=2,
-                 residual_channels=32, n_embeddings=128, embedding_dim=16, sample_fn=None):
-        super().__init__(sample_fn)
-        enc = dict(hidden_channels=hidden_channels, n_residual_blocks=n_residual_blocks,
-                   residual_channels=residual_channels, stride=2)
-        self._encoder_b = vaes.Encoder(in_channels=in_channels, out_channels=hidden_channels, **enc)
-        self._encoder_t = vaes.Encoder(in_channels=hidden_channels, out_channels=hidden_channels, **enc)
-        self._quantizer_t = Quantizer(hidden_channels, n_embeddings, embedding_dim)
-        self._quantizer_b = Quantizer(hidden_channels, n_embeddings, embedding_dim)
-        self._decoder_t = vaes.Decoder(in_channels=embedding_dim, out_channels=hidden_channels, **enc)
-        self._conv = pg_nn.Conv2d(in_channels=hidden_channels, out_channels=embedding_dim, kernel_size=1)
-        self._decoder_b = vaes.Decoder(in_channels=2 * embedding_dim, out_channels=out_channels, **enc)
-
-    def forward(self, x):
-        encoded_b = self._encoder_b(x)
-        encoded_t = self._encoder_t(encoded_b)
-        quantized_t, vq_loss_t = self._quantizer_t(encoded_t)
-        quantized_b, vq_loss_b = self._quantizer_b(encoded_b)
-        decoded_t = self._decoder_t(quantized_t)
-        xhat = self._decoder_b(torch.cat((self._conv(decoded_t), quantized_b), dim=1))
-        # 0.5 * (vq_b + vq_t) + mse(decoded_t, encoded_b), vq_vae_2.py:110 (gradients to both arguments)
-        return xhat, (vq_loss_b + vq_loss_t) * 0.5 + mse_loss(decoded_t, encoded_b)
-
-    def _sample(self, n_samples):
-        raise NotImplementedError("VQ-VAE-2 does not support sampling.")
-
-
-def vq_loss(x, _, preds):
-    """loss_fn of vq_vae.reproduce (vq_vae.py:127-136)."""
-    recon, quantization_loss = preds
-    recon_loss = mse_loss(recon, x)
-    return {"vq_loss": quantization_loss, "reconstruction_loss": recon_loss, "loss": recon_loss + quantization_loss}

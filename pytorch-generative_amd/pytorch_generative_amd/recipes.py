@@ -57,3 +57,21 @@ def binarized_mnist(batch_size):
 
 def binarized_mnist_32(batch_size):
     return datasets.get_mnist_loaders(batch_size, dynamically_binarize=True, resize_to_32=True)
+
+
+def cifar10(batch_size):
+    return datasets.get_cifar10_loaders(batch_size, normalize=True)
+
+
+def vq_loss(vq_weight):
+    """loss_fn of the VQ-VAE recipes (vq_vae.py:127-136, vq_vae_2.py:160-169):
+    {"vq_loss", "reconstruction_loss", "loss" = MSE + vq_weight * quantization loss}."""
+    from pytorch_generative_amd.nn import utils as nn_utils
+
+    def loss_fn(x, _, preds):
+        recon, quantization_loss = preds
+        recon_loss = nn_utils.mse_loss(recon, x)
+        return {"vq_loss": quantization_loss, "reconstruction_loss": recon_loss,
+                "loss": recon_loss + vq_weight * quantization_loss}
+
+    return loss_fn

@@ -5,17 +5,26 @@ Contract kept from the reference (pytorch_generative/trainer.py): the constructo
 backward, global grad norm with optional clip / skip, optimizer.step, lr_scheduler.step), the
 overridable `train_one_batch` / `eval_one_batch` hooks, example-weighted evaluation averages, and
 the on-disk checkpoint `trainer_state_{epoch}.ckpt` with keys model / optimizer / step / epoch /
-examples_processed / time_taken (/ lr_scheduler), written by rank 0 only (:98-148) — reference
-checkpoints restore here and vice versa.
+examples_processed / time_taken (/ lr_scheduler), written by rank 0 only (:98-148). A checkpoint
+written by the reference's single-process Trainer restores here (tested against one written by the
+reference itself); reference multi-GPU checkpoints carry DDP's "module." key prefix, which is stripped
+on load. The other direction: checkpoints written here restore into the reference when the optimizer
+state is converted (`FlatAdam.state_dict()` has `torch.optim.Adam`'s layout) — recipes whose lr decay
+runs on the device (`FlatAdam(lr_decay=...)`, no `lr_scheduler` object) also write an equivalent
+`MultiplicativeLR` state under "lr_scheduler" so that the reference's `restore_checkpoint` finds the key.
 
 How a step runs here:
   * with `optim.FlatAdam` the whole step (zero_grad .. Adam, incl. the clip) is captured into a
     hipGraph per input shape (graph.GraphedTrainStep) and replayed: one launch instead of
-    hundreds; only the final metric read-back touches the host (every `metrics_every` steps);
+    hundreds; only the final metric read-back touches the host (every `metrics_every` steps).
+    A captured step runs the Python of `train_one_batch` / `loss_fn` ONLY while it is captured, not
+    on every batch as the reference does: a Trainer subclass that overrides `train_one_batch`
+    (step-dependent host logic: annealing, counters, `.item()`) therefore runs eager launches unless
+    it passes `graph="force"`; a capture that fails falls back to eager launches with a warning;
   * `skip_grad_norm` needs the norm on the host before the update, and stock torch optimizers have
     no flat buffer: both run as eager kernel launches;
   * `n_gpus > 1`: one process per GPU (launched by train.py / torchrun), this process pinned to
-    `device_id`, ONE flat RCCL all-reduce per step between the two halves of the graph.
+    `device_id`, ONE flat RCCL all-reduce per step (`pg_allreduce_sum`), captured inside the graph.
 TensorBoard is used when it is importable; otherwise metrics are only returned to the caller.
 """
 
@@ -107,7 +116,9 @@ class Trainer:
         metrics_every=1,
     ):
         """Arguments as the reference Trainer (trainer.py:40-76). Extensions (keyword only):
-        graph: capture FlatAdam steps into hipGraphs (default); metrics_every: read the step
+        graph: True (default) captures FlatAdam steps into hipGraphs unless `train_one_batch` is
+        overridden by a subclass; "force" captures even then (the hook's Python then runs at capture
+        time only); False = eager launches. metrics_every: read the step
         metrics back to the host every N steps (1 = the reference's per-step logging)."""
         self.loss_fn = loss_fn
         self.train_loader, self.eval_loader = train_loader, eval_loader
@@ -127,6 +138,9 @@ class Trainer:
         self.model, self.optimizer, self.lr_scheduler = model, optimizer, lr_scheduler
 
         self._reducer = None
+        # rank 0 writes checkpoints (the reference uses device_id == 0 for that, trainer.py:99; the
+        # rank is what is meant, and the two differ when ranks are pinned to one device for testing)
+        self._is_main = (dist.get_rank() == 0) if (n_gpus > 1 and dist.is_initialized()) else True
         if n_gpus > 1:
             if not self._flat:
                 raise RuntimeError("multi-GPU training requires pytorch_generative_amd.optim.FlatAdam")
@@ -136,7 +150,9 @@ class Trainer:
             self._reducer.broadcast_parameters(src=0)
         if self._flat:
             optimizer.set_max_norm(clip_grad_norm or skip_grad_norm)
-        self._use_graph = bool(graph) and self._flat and not skip_grad_norm
+        hook_overridden = type(self).train_one_batch is not Trainer.train_one_batch
+        self._use_graph = (bool(graph) and self._flat and not skip_grad_norm
+                           and (graph == "force" or not hook_overridden))
         self._graphs = {}
         self._metrics_every = max(1, int(metrics_every))
 
@@ -166,7 +182,7 @@ class Trainer:
         return os.path.join(self.log_dir, name)
 
     def _save_checkpoint(self):
-        if self.device_id != 0 or self._epoch % self.save_checkpoint_epochs:
+        if not self._is_main or self._epoch % self.save_checkpoint_epochs:
             return
         payload = dict(
             model=self.model.state_dict(),
@@ -178,6 +194,14 @@ class Trainer:
         )
         if self.lr_scheduler is not None:
             payload["lr_scheduler"] = self.lr_scheduler.state_dict()
+        elif self._flat and self.optimizer._lr_decay != 1.0:
+            # device-side per-batch decay: the state a MultiplicativeLR(optimizer, lambda _: decay)
+            # (e.g. image_gpt.py:156) would hold after `step` calls, so the reference finds its key
+            payload["lr_scheduler"] = {
+                "base_lrs": [float(self.optimizer.defaults["lr"])], "last_epoch": self._step, "verbose": False,
+                "_step_count": self._step + 1, "_get_lr_called_within_step": False,
+                "_last_lr": [self.optimizer.current_lr()], "lr_lambdas": [None],
+            }
         torch.save(payload, self._path(_ckpt_name(self._epoch)))
 
     def _latest_epoch(self):
@@ -192,9 +216,12 @@ class Trainer:
         epoch = epoch or self._latest_epoch()
         print(f"Restoring trainer state from checkpoint {_ckpt_name(epoch)}.")
         state = torch.load(self._path(_ckpt_name(epoch)), map_location=self.device, weights_only=False)
-        self.model.load_state_dict(state["model"])
+        model_state = state["model"]
+        if model_state and all(k.startswith("module.") for k in model_state):  # written under DDP
+            model_state = {k[len("module."):]: v for k, v in model_state.items()}
+        self.model.load_state_dict(model_state)
         self.optimizer.load_state_dict(state["optimizer"])
-        if self.lr_scheduler is not None:
+        if self.lr_scheduler is not None and "lr_scheduler" in state:
             self.lr_scheduler.load_state_dict(state["lr_scheduler"])
         self._step, self._epoch = state["step"], state["epoch"]
         self._examples_processed, self._time_taken = state["examples_processed"], state["time_taken"]
@@ -222,11 +249,18 @@ class Trainer:
         if g is None:
             if len(self._graphs) >= 4:  # e.g. ragged batch sizes: do not hoard graphs
                 return None
-            g = pg_graph.GraphedTrainStep(
-                self.model, self.optimizer, None, x, reducer=self._reducer, example_y=y,
-                forward_fn=lambda xx, yy: _as_metrics(self.train_one_batch(xx, yy)),
-                preserve_state=True,
-            )
+            try:
+                g = pg_graph.GraphedTrainStep(
+                    self.model, self.optimizer, None, x, reducer=self._reducer, example_y=y,
+                    forward_fn=lambda xx, yy: _as_metrics(self.train_one_batch(xx, yy)),
+                    preserve_state=True,
+                )
+            except Exception as e:  # e.g. a hook that synchronises: run this Trainer eagerly from now on
+                warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
+                              "falling back to eager kernel launches")
+                torch.cuda.synchronize()
+                self._use_graph = False
+                return None
             self._graphs[key] = g
         return g
 

@@ -6,8 +6,8 @@ launcher made to work).
 
 `--gpus N > 1` starts N worker processes; worker r pins GPU r, joins a `nccl` (= RCCL) process
 group on 127.0.0.1 and runs the model module's reproduce(..., n_gpus=N, device_id=r): every rank
-draws its own batches, gradients are summed with one flat all-reduce per step, rank 0 writes the
-checkpoints. (The reference's launcher hides all but one GPU from every worker and passes its
+draws its own batches (loader seeds are offset by the rank), gradients are summed with one flat RCCL
+all-reduce per step (captured inside the step's hipGraph), rank 0 writes the checkpoints. (The reference's launcher hides all but one GPU from every worker and passes its
 arguments in the wrong order, so `--gpus > 1` raises there — SURVEY.md §3.4; the parent here also
 does not fall through into a second, single-GPU run.)
 """
@@ -27,17 +27,32 @@ MODEL_DICT = {
     "pixel_snail": autoregressive.pixel_snail,
     "vae": vae.vae,
     "vd_vae": vae.vd_vae,
+    "vq_vae": vae.vq_vae,
+    "vq_vae_2": vae.vq_vae_2,
 }
 
 
 def _worker(rank, model, epochs, batch_size, logdir, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(rank)
-    torch.distributed.init_process_group(backend="nccl", world_size=world, rank=rank,
-                                         device_id=torch.device("cuda", rank))
+    # development hooks (1-GPU box): PG_FORCE_DEVICE pins every rank to one GPU, PG_DIST_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); PG_TRAIN_DUMP=<dir> makes every rank save
+    # its final parameters there (tests/test_gpu_dp.py compares the ranks)
+    device = int(os.environ.get("PG_FORCE_DEVICE", rank))
+    backend = os.environ.get("PG_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        torch.distributed.init_process_group(backend="nccl", world_size=world, rank=rank,
+                                             device_id=torch.device("cuda", device))
+    else:
+        torch.distributed.init_process_group(backend=backend, world_size=world, rank=rank)
     try:
-        MODEL_DICT[model].reproduce(epochs, batch_size, logdir, n_gpus=world, device_id=rank)
+        t = MODEL_DICT[model].reproduce(epochs, batch_size, logdir, n_gpus=world, device_id=device)
+        dump = os.environ.get("PG_TRAIN_DUMP")
+        if dump:
+            torch.save({"params": {k: v.detach().cpu() for k, v in t.model.named_parameters()},
+                        "step": t._step, "first_batch": next(iter(t.train_loader))[0].cpu()},
+                       os.path.join(dump, f"rank{rank}.pt"))
     finally:
         torch.distributed.destroy_process_group()
 

@@ -3,8 +3,16 @@
 Both ranks share the box's single MI355X (device 0) and talk over gloo; everything else is the
 production path: optim.FlatAdam, parallel.FlatGradAllReduce (broadcast + one flat all-reduce),
 graph.GraphedTrainStep in its two-graph data-parallel form. usage:
-    RANK=r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_worker.py <mode> <out.pt>
+    RANK=r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_worker.py <mode> <out.pt> [model]
 mode "same": every rank trains on the full batches; "shard": rank r on its half of each batch.
+model "igpt" (default) or "gated": a GatedPixelCNN, whose last layer's `_vstack_1x1` / `_link` ... never
+receive a gradient — their slice of the flat buffer must stay zero through the
+all-reduce and leave the parameters untouched.
+
+Also: `python tests/dp_worker.py rccl1 <out.pt>` — ONE process, no torch.distributed: a real RCCL
+communicator of world size 1 (RCCL refuses two ranks on one device, so this is what a 1-GPU box can
+run of the production transport): init, broadcast, all-reduce captured INSIDE the step's hipGraph,
+replay, destroy; the result must be bit-identical to the step without a reducer.
 """
 
 import os
@@ -17,15 +25,19 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def build(dev, seed):
+def build(dev, seed, kind="igpt"):
     import pytorch_generative_amd as pg
     from pytorch_generative_amd import optim
 
     torch.manual_seed(seed)
-    model = pg.models.ImageGPT(1, 1, in_size=8, n_transformer_blocks=2, n_attention_heads=4,
-                               n_embedding_channels=16).to(dev)
-    with torch.no_grad():
-        model._pos.normal_(0, 0.1)
+    if kind == "gated":
+        model = pg.models.GatedPixelCNN(in_channels=1, out_channels=1, n_gated=2, gated_channels=16,
+                                        head_channels=8).to(dev)
+    else:
+        model = pg.models.ImageGPT(1, 1, in_size=8, n_transformer_blocks=2, n_attention_heads=4,
+                                   n_embedding_channels=16).to(dev)
+        with torch.no_grad():
+            model._pos.normal_(0, 0.1)
     model.train()
     return model, optim.FlatAdam(model.parameters(), lr=5e-3, lr_decay=0.999)
 
@@ -35,15 +47,52 @@ def batches(n_steps=3, b=8):
     return [torch.bernoulli(torch.full((b, 1, 8, 8), 0.3), generator=g) for _ in range(n_steps)]
 
 
+def rccl_world1(out):
+    from pytorch_generative_amd import _lib, graph, ops, parallel
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    loss_fn = lambda x, preds: ops.bce_with_logits_sum_mean(preds, x)  # noqa: E731
+    data = [b.to(dev) for b in batches()]
+    lib = _lib.load()
+    assert lib.pg_comm_rccl_version() > 0 and lib.pg_comm_world() == 0
+    model, opt = build(dev, seed=0)
+    red = parallel.FlatGradAllReduce(opt, transport="rccl")
+    assert lib.pg_comm_world() == 1 and red.capturable and red.active
+    red.broadcast_parameters(src=0)
+    g0 = opt.flat_grad.clone().normal_()
+    opt.flat_grad.copy_(g0)
+    red.all_reduce()  # eager, on the current stream
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat_grad, g0), "a world of one must reduce to the identity"
+    step = graph.GraphedTrainStep(model, opt, loss_fn, data[0], reducer=red, preserve_state=True)
+    assert step.reduce and not step.split and step.graph_b is None  # the collective is INSIDE graph_a
+    losses = [float(step(b)) for b in data]
+    torch.cuda.synchronize()
+    model2, opt2 = build(dev, seed=0)
+    step2 = graph.GraphedTrainStep(model2, opt2, loss_fn, data[0], preserve_state=True)
+    losses2 = [float(step2(b)) for b in data]
+    torch.cuda.synchronize()
+    same = torch.equal(opt.flat_param, opt2.flat_param)
+    del step
+    red.close()
+    assert lib.pg_comm_world() == 0
+    torch.save({"same": same, "losses": losses, "losses_plain": losses2,
+                "rccl_version": lib.pg_comm_rccl_version()}, out)
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
+    kind = sys.argv[3] if len(sys.argv) > 3 else "igpt"
+    if mode == "rccl1":
+        return rccl_world1(out)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pytorch_generative_amd import graph, ops, parallel
 
-    model, opt = build(dev, seed=rank)  # different seeds: the broadcast must make them equal
+    model, opt = build(dev, seed=rank, kind=kind)  # different seeds: the broadcast must make them equal
     red = parallel.FlatGradAllReduce(opt)
     red.broadcast_parameters(src=0)
     loss_fn = lambda x, preds: ops.bce_with_logits_sum_mean(preds, x)  # noqa: E731

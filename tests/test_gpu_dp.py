@@ -18,12 +18,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 
-def _single_gpu_reference():
+def _single_gpu_reference(kind="igpt"):
     import dp_worker
     from pytorch_generative_amd import graph, ops
 
     dev = torch.device("cuda", 0)
-    model, opt = dp_worker.build(dev, seed=0)
+    model, opt = dp_worker.build(dev, seed=0, kind=kind)
     loss_fn = lambda x, preds: ops.bce_with_logits_sum_mean(preds, x)  # noqa: E731
     data = dp_worker.batches()
     step = graph.GraphedTrainStep(model, opt, loss_fn, data[0].to(dev), preserve_state=True)
@@ -32,10 +32,10 @@ def _single_gpu_reference():
     return {k: v.detach().cpu() for k, v in model.named_parameters()}, losses, opt.current_lr()
 
 
-def _run_world2(mode, out):
-    port = 29600 + os.getpid() % 300 + (0 if mode == "same" else 1)
+def _run_world2(mode, out, kind="igpt"):
+    port = 29600 + os.getpid() % 300 + (0 if mode == "same" else 1) + (2 if kind == "gated" else 0)
     env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), mode, out],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), mode, out, kind],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
     logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
@@ -43,10 +43,20 @@ def _run_world2(mode, out):
     return torch.load(out, map_location="cpu", weights_only=False)
 
 
-@pytest.mark.parametrize("mode", ["same", "shard"])
-def test_two_ranks_equal_one_gpu(tmp_path, mode):
-    want, want_losses, want_lr = _single_gpu_reference()
-    got = _run_world2(mode, str(tmp_path / f"dp_{mode}.pt"))
+@pytest.mark.parametrize("mode,kind", [("same", "igpt"), ("shard", "igpt"), ("shard", "gated")])
+def test_two_ranks_equal_one_gpu(tmp_path, mode, kind):
+    want, want_losses, want_lr = _single_gpu_reference(kind)
+    got = _run_world2(mode, str(tmp_path / f"dp_{mode}.pt"), kind)
+    if kind == "gated":  # parameters that never receive a gradient stay exactly where the broadcast put them
+        import dp_worker
+
+        m0, _ = dp_worker.build(torch.device("cuda", 0), seed=0, kind="gated")
+        never = [k for k, p in m0.named_parameters() if "_gated_layers.1._vstack_1x1" in k
+                 or "_gated_layers.1._link" in k or "_gated_layers.1._hstack_residual" in k]
+        assert never
+        init = dict(m0.named_parameters())
+        frozen = [k for k in never if torch.equal(got["params"][k], init[k].detach().cpu())]
+        assert frozen, "no never-gradient parameter found unchanged"
     assert got["step"] == 3.0 and abs(got["lr"] - want_lr) < 1e-12
     for k, w in want.items():
         g = got["params"][k]
@@ -64,3 +74,48 @@ def test_two_ranks_equal_one_gpu(tmp_path, mode):
         assert abs(mean - w) <= 1e-5 * abs(w), (mode, i, per_rank, w)
         if mode == "same":
             assert max(per_rank) - min(per_rank) <= 1e-5 * abs(w)  # fp32 atomic order of the loss sum
+
+
+def test_rccl_world_of_one_captured_in_the_step_graph(tmp_path):
+    """The production transport on the one GPU this box has: a real RCCL communicator (world size 1)
+    created through the C-ABI, its all-reduce captured inside the step's hipGraph next to the live
+    communicator, replayed, destroyed (tests/dp_worker.py rccl_world1)."""
+    out = str(tmp_path / "rccl1.pt")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "dp_worker.py"), "rccl1", out], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-4000:]
+    got = torch.load(out, map_location="cpu", weights_only=False)
+    assert got["rccl_version"] >= 20000
+    assert got["same"], "the step with the captured world-1 all-reduce differs from the plain step"
+    for a, b in zip(got["losses"], got["losses_plain"]):
+        assert abs(a - b) <= 2e-6 * abs(b)
+
+
+def test_train_py_two_workers_through_trainer(tmp_path):
+    """`train.py --gpus 2` end to end on one GPU (PG_FORCE_DEVICE=0, gloo): the spawned workers run the
+    model module's reproduce() -> recipes.run -> Trainer(n_gpus=2) -> GraphedTrainStep + FlatGradAllReduce.
+    Ranks draw DIFFERENT batches (loader seeds offset by the rank) and must end with IDENTICAL
+    parameters; only rank 0 writes checkpoints."""
+    root = os.path.dirname(HERE)
+    dump = tmp_path / "dump"
+    dump.mkdir()
+    logdir = tmp_path / "log"
+    env = dict(os.environ, PG_FORCE_DEVICE="0", PG_DIST_BACKEND="gloo", PG_TRAIN_DUMP=str(dump),
+               PYTHONPATH=os.path.join(root, "pytorch-generative_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("WORLD_SIZE", None)
+    port = 29900 + os.getpid() % 90
+    p = subprocess.run([sys.executable, os.path.join(root, "pytorch-generative_amd", "train.py"), "--model",
+                        "gated_pixel_cnn", "--gpus", "2", "--epochs", "1", "--batch-size", "2", "--logdir",
+                        str(logdir), "--port", str(port)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-4000:]
+    r0 = torch.load(dump / "rank0.pt", map_location="cpu", weights_only=False)
+    r1 = torch.load(dump / "rank1.pt", map_location="cpu", weights_only=False)
+    assert r0["step"] == r1["step"] and r0["step"] > 0
+    assert not torch.equal(r0["first_batch"], r1["first_batch"]), "both ranks drew the same data"
+    for k, v in r0["params"].items():
+        assert torch.equal(v, r1["params"][k]), f"ranks diverged on {k}"
+        assert torch.isfinite(v).all()
+    assert sorted(os.listdir(logdir)) == ["trainer_state_1.ckpt"] or "trainer_state_1.ckpt" in os.listdir(logdir)

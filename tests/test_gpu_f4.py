@@ -1,20 +1,13 @@
-"""SURVEY.md §8(f) rank 4 on the GPU: VectorQuantizer / VQ-VAE / VQ-VAE-2 of
-pytorch_generative_amd/experimental/vq.py against the golden vectors of the reference
-(tests/golden/vq_*.pt, the same files that pin the oracle in tests/test_oracle_golden.py).
-
-OPT-IN (PG_TEST_F4=1): the kernels behind this module (csrc/vq.hip) were written after round 2's GPU
-budget was spent and have not run on hardware yet; until they have, these tests stay out of the
-default `-m gpu` tier."""
-
-import os
+"""SURVEY.md §8(f) rank 4 on the GPU: `nn.VectorQuantizer`, `models.VectorQuantizedVAE` / `VectorQuantizedVAE2`
+against the golden vectors of the reference (tests/golden/vq_*.pt, the same files that pin the oracle in
+tests/test_oracle_golden.py). First run on MI355X in round 3 (green); part of the default `-m gpu` tier."""
 
 import pytest
 import torch
 
 import _util
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("PG_TEST_F4") != "1", reason="opt-in: PG_TEST_F4=1")]
+pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 
@@ -30,10 +23,10 @@ def dev():
 
 @pytest.mark.parametrize("case", ["ema_train", "ema_eval"])
 def test_vector_quantizer_matches_reference_golden(dev, case):
-    from pytorch_generative_amd.experimental import vq
+    import pytorch_generative_amd as pg
 
     g = _util.load_golden("vq_quantizer")["cases"][case]
-    m = vq.VectorQuantizer(n_embeddings=12, embedding_dim=8).to(dev)
+    m = pg.nn.VectorQuantizer(n_embeddings=12, embedding_dim=8).to(dev)
     m.load_state_dict(g["before"])
     m.train(g["training"])
     x = g["x"].to(dev).requires_grad_(True)
@@ -51,10 +44,11 @@ def test_vector_quantizer_matches_reference_golden(dev, case):
 @pytest.mark.parametrize("name,ctor", [("vq_vae_small", "VectorQuantizedVAE"),
                                        ("vq_vae_2_small", "VectorQuantizedVAE2")])
 def test_vq_vae_models_match_reference_golden(dev, name, ctor):
-    from pytorch_generative_amd.experimental import vq
+    import pytorch_generative_amd as pg
+    from pytorch_generative_amd.nn import utils as vq
 
     g = _util.load_golden(name)
-    model = getattr(vq, ctor)(**g["kwargs"]).to(dev)
+    model = getattr(pg.models, ctor)(**g["kwargs"]).to(dev)
     model.load_state_dict(g["state0"])
     model.train()
     x = g["x"].to(dev)

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 REF_TESTS = "/root/reference/pytorch_generative/models/tests.py"
 IN_SCOPE = {
     "IntegrationTests": ["test_PixelCNN", "test_GatedPixelCNN", "test_PixelSnail", "test_ImageGPT",
-                         "test_VAE", "test_BetaVAE", "test_VeryDeepVAE"],
+                         "test_VAE", "test_BetaVAE", "test_VeryDeepVAE", "test_VectorQuantizedVAE", "test_VectorQuantizedVAE2"],
     "MultipleChannelsTests": ["test_PixelCNN", "test_GatedPixelCNN", "test_PixelSNAIL", "test_ImageGPT",
                               "test_VAE", "test_VeryDeepVAE"],
     "MiscTests": ["test_sampling_after_load"],
@@ -72,17 +72,18 @@ class _DummyLoader:
         return iter([self._batch])
 
 
-@pytest.mark.parametrize("family,module,size", [
-    ("autoregressive", "pixel_cnn", 28), ("autoregressive", "gated_pixel_cnn", 28),
-    ("autoregressive", "pixel_snail", 28), ("autoregressive", "image_gpt", 28),
-    ("vae", "vae", 32), ("vae", "beta_vae", 32), ("vae", "vd_vae", 32),
+@pytest.mark.parametrize("family,module,size,channels", [
+    ("autoregressive", "pixel_cnn", 28, 1), ("autoregressive", "gated_pixel_cnn", 28, 1),
+    ("autoregressive", "pixel_snail", 28, 1), ("autoregressive", "image_gpt", 28, 1),
+    ("vae", "vae", 32, 1), ("vae", "beta_vae", 32, 1), ("vae", "vd_vae", 32, 1),
+    ("vae", "vq_vae", 28, 3), ("vae", "vq_vae_2", 28, 3),  # tests.py:70-74
 ])
-def test_integration_reproduce(pg_alias, tmp_path, family, module, size):
+def test_integration_reproduce(pg_alias, tmp_path, family, module, size, channels):
     import pytorch_generative as pg  # the alias
 
     mod = getattr(getattr(pg.models, family), module)
     with pytest.warns(UserWarning, match="n_gpus=0"):
-        t = mod.reproduce(n_epochs=1, log_dir=str(tmp_path), n_gpus=0, debug_loader=_DummyLoader(1, size))
+        t = mod.reproduce(n_epochs=1, log_dir=str(tmp_path), n_gpus=0, debug_loader=_DummyLoader(channels, size))
     assert t._epoch == 1 and t._step == 1
     assert os.path.exists(os.path.join(tmp_path, "trainer_state_1.ckpt"))
     assert all(torch.isfinite(p).all() for p in t.model.parameters())
