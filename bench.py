@@ -41,18 +41,21 @@ LN2 = 0.6931471805599453
 
 
 def _attn_flops_per_pair(dk, dv):
-    """Algorithmic FLOPs per allowed (query, key) pair of the three attention kernels:
-    fwd QK^T + PV; dQ recomputes QK^T, dP = dO V^T, dQ = dS K; dK/dV recomputes QK^T, dP, dV = P^T dO,
-    dK = dS^T Q."""
-    return {"fwd": 2 * dk + 2 * dv, "dq": 4 * dk + 2 * dv, "dkv": 4 * dk + 4 * dv}
+    """ALGORITHMIC FLOPs per allowed (query, key) pair (no recomputation counted twice): forward
+    QK^T + PV; backward S, dP = dO V^T, dV = P^T dO, dK = dS^T Q, dQ = dS K once each = 6 dk + 4 dv
+    (for d_k = d_v this is SURVEY.md §8(d)'s "3.5 x forward"). The fused backward kernel (d_k = d_v = 4)
+    executes exactly this; the two-kernel backward executes S and dP twice (dq: 4 dk + 2 dv, dkv:
+    4 dk + 4 dv) but is priced on the same algorithmic work split over its two launches."""
+    return {"fwd": 2 * dk + 2 * dv, "bwd": 6 * dk + 4 * dv, "dq": 4 * dk + 2 * dv, "dkv": 4 * dk + 4 * dv}
 
 
 def _causal_gflop_per_img(dense_total, dense_attn, heads, L, dk, dv, blocks, strict):
     """SURVEY.md §8(d) counts attention as dense L^2 at 3.5x forward; the kernels only touch the
-    allowed pairs (and recompute more in backward). Returns the per-image training GFLOP with the
-    attention core counted on the causal triangle."""
+    allowed pairs. Returns the per-image training GFLOP with the attention core counted on the causal
+    triangle, algorithmic (forward + backward once each, no recomputation)."""
     pairs = heads * (L * (L - 1) / 2 if strict else L * (L + 1) / 2)
-    attn = blocks * pairs * sum(_attn_flops_per_pair(dk, dv).values()) / 1e9
+    per = _attn_flops_per_pair(dk, dv)
+    attn = blocks * pairs * (per["fwd"] + per["bwd"]) / 1e9
     return dense_total - dense_attn + attn
 
 
@@ -266,6 +269,8 @@ def attention_kernel_roofline(batch, device, heads, dk, dv, hw, strict):
     ms = {"fwd": _event_time(fwd, stream),
           "dq": _event_time(lambda: bwd(lib.pg_causal_attn_bwd_dq), stream),
           "dkv": _event_time(lambda: bwd(lib.pg_causal_attn_bwd_dkv), stream)}
+    if dk == 4 and dv == 4 and lib.pg_attn_fused_bwd(-1) == 1:  # one fused launch (attn_bwd_m44_kernel)
+        ms["bwd"] = _event_time(lambda: bwd(lib.pg_causal_attn_bwd), stream)
     pairs = batch * heads * (L * (L - 1) / 2 if strict else L * (L + 1) / 2)
     per = _attn_flops_per_pair(dk, dv)
     return {k: {"launch_ms": ms[k], "flop_per_launch": pairs * per[k],
@@ -329,17 +334,23 @@ def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
     return {"launch_ms": ms, "flop_per_launch": flop, "tflops": flop / ms / 1e9}
 
 
-def measured_traffic(batch):
-    """HBM bytes per launch of the headline's dominant kernel from the committed PMC profile
-    (collected in separate rocprofv3 --pmc passes, see profiles/README.md); None when no profile
-    matches this batch."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+def measured_traffic(batch, kernel):
+    """HBM bytes per launch of the headline's dominant kernel from the committed PMC profiles
+    (collected in separate rocprofv3 --pmc passes, see profiles/README.md); None when no committed
+    profile holds this kernel at this batch."""
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
-            if t.get("per_gpu_batch") == batch:
-                return t.get("attn_bwd_dkv_bytes_per_launch")
-        except (OSError, ValueError):
+            if t.get("per_gpu_batch") != batch:
+                continue
+            per = t.get("kernels", {})
+            for k, v in per.items():
+                if kernel in k and "hbm_read_bytes" in v:
+                    return v["hbm_read_bytes"] + v["hbm_write_bytes"]
+            if kernel.startswith("attn_dkv") and "attn_bwd_dkv_bytes_per_launch" in t:
+                return t["attn_bwd_dkv_bytes_per_launch"]
+        except (OSError, ValueError, AttributeError):
             pass
     return None
 
@@ -363,15 +374,34 @@ def _physical_cores():
         return None
 
 
-def cpu_baseline(batch=32, budget_s=30.0):
+def _cpu_step_timer(forward, state0, x, lr, **fwd_kw):
+    """Returns timed(threads, n_steps) -> (seconds per oracle train step after one warm-up step, loss)."""
+    from oracle import train as otrain
+
+    def timed(threads, n_steps):
+        torch.set_num_threads(threads)
+        state = {k: v.clone() for k, v in state0.items()}
+        opt_state = otrain.new_opt_state()
+        ts = []
+        for _ in range(n_steps + 1):
+            t0 = time.perf_counter()
+            _, loss, grads = otrain.loss_and_grads(forward, state, x, **fwd_kw)
+            otrain.adam_step_(state, grads, opt_state, lr=lr)
+            ts.append(time.perf_counter() - t0)
+        return sum(ts[1:]) / n_steps, float(loss)
+
+    return timed
+
+
+def cpu_baseline(batch=32, point_cap_s=20.0):
     """The oracle's restatement of the same ImageGPT training step on the host cores (kind 'port':
     the reference is Python and cannot travel to the GPU box; the oracle dispatches the same torch
     CPU primitives — oneDNN / MKL — in the same order). Bounded sample: a thread sweep over
-    {physical cores, 32, 16} (1 warm-up + 2 timed steps each), then 5 timed steps at the best
-    setting, at batch 32 (the survey's probe batch; the reference default 64 gives the same
-    images/s within noise but doubles the sample's wall time)."""
+    {16, 32, 64, physical cores} with 1 warm-up + 1 timed step per point (a point whose step exceeds
+    `point_cap_s` ends the sweep), then 3 timed steps at the best setting, at batch 32 (the survey's
+    probe batch; the reference default 64 gives the same images/s within noise but doubles the
+    sample's wall time)."""
     from oracle import models as omodels
-    from oracle import train as otrain
 
     import pytorch_generative_amd as pg
 
@@ -382,38 +412,54 @@ def cpu_baseline(batch=32, budget_s=30.0):
     x = synthetic_batch(batch, 0)
     logical, physical = os.cpu_count(), _physical_cores()
     default_threads = torch.get_num_threads()
-
-    def timed(threads, n_steps):
-        torch.set_num_threads(threads)
-        state = {k: v.clone() for k, v in state0.items()}
-        opt_state = otrain.new_opt_state()
-        ts = []
-        for _ in range(n_steps + 1):
-            t0 = time.perf_counter()
-            _, loss, grads = otrain.loss_and_grads(omodels.image_gpt, state, x, n_heads=4)
-            otrain.adam_step_(state, grads, opt_state, lr=w["lr"])
-            ts.append(time.perf_counter() - t0)
-        return sum(ts[1:]) / n_steps, float(loss)
-
-    t_start = time.perf_counter()
+    timed = _cpu_step_timer(omodels.image_gpt, state0, x, w["lr"], n_heads=4)
     sweep = {}
-    # small thread counts first: at this model size (16 channels) the per-op work is tiny and 128
-    # threads measured SLOWER than 16 (oversubscription); the sweep stops when its time budget is spent
-    for threads in sorted({t for t in (16, 32, physical or logical) if t and t <= logical}):
-        if sweep and time.perf_counter() - t_start > budget_s * 0.5:
+    for threads in sorted({t for t in (16, 32, 64, physical or logical) if t and t <= logical}):
+        sweep[threads] = timed(threads, 1)[0]
+        if sweep[threads] > point_cap_s:
             break
-        sweep[threads] = timed(threads, 2)[0]
     best = min(sweep, key=sweep.get)
-    dt, loss = timed(best, 5)
+    dt, loss = timed(best, 3)
     torch.set_num_threads(default_threads)
     return {
         "value": batch / dt, "unit": "images/s", "cores": best, "cores_logical": logical,
         "cores_physical": physical, "kind": "port", "torch": torch.__version__,
         "ms_per_step": dt * 1e3, "loss_after": loss,
         "thread_sweep_ms_per_step": {str(k): v * 1e3 for k, v in sweep.items()},
-        "sample": f"oracle train step (torch-CPU fp32, ImageGPT 8/4/16), batch {batch}, 5 timed steps after "
-                  f"1 warm-up at {best} threads (best of a sweep over {sorted(sweep)})",
+        "sample": f"oracle train step (torch-CPU fp32, ImageGPT 8/4/16), batch {batch}, 3 timed steps after "
+                  f"1 warm-up at {best} threads (best of a sweep over {sorted(sweep)} threads, 1 timed step each)",
     }
+
+
+def cpu_baseline_pixel_snail(threads, batch=8):
+    """The oracle's PixelSNAIL (configs[3]) training step on the host cores at `threads` threads (the
+    best setting of the ImageGPT sweep): 1 warm-up + 2 timed steps at batch 8."""
+    from oracle import models as omodels
+
+    import pytorch_generative_amd as pg
+
+    w = WORKLOADS["pixel_snail"]
+    torch.manual_seed(0)
+    model = pg.models.PixelSNAIL(**w["kw"])
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = synthetic_batch(batch, 0, w["chw"])
+    default_threads = torch.get_num_threads()
+    dt, loss = _cpu_step_timer(omodels.pixel_snail, state0, x, w["lr"])(threads, 2)
+    torch.set_num_threads(default_threads)
+    return {"value": batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "ms_per_step": dt * 1e3, "loss_after": loss,
+            "sample": f"oracle train step (torch-CPU fp32, PixelSNAIL cfg3), batch {batch}, 2 timed steps after "
+                      f"1 warm-up at {threads} threads"}
+
+
+# fp32-compute / HBM ceilings per GPU in images/s (BASELINE.md §3 = SURVEY.md §8(d)) for the compact records
+CEILINGS = {"pixel_cnn": 163e3, "gated_pixel_cnn": 7.4e3, "beta_vae": 100e3, "vd_vae": 14.3e3}
+OTHER_CONFIGS = [  # (record key, workload, per-GPU batch, BASELINE.json config)
+    ("pixel_cnn", "pixel_cnn", 1024, "configs[0]"),
+    ("gated_pixel_cnn", "gated_pixel_cnn", 512, "configs[2]"),
+    ("beta_vae", "beta_vae", 1024, "configs[4]"),
+    ("vd_vae", "vd_vae", 512, "configs[4]"),
+]
 
 
 def main():
@@ -463,9 +509,17 @@ def main():
     extras = {}
     if not args.no_extras:
         extras["imagegpt_b64"] = run("image_gpt", 64)
-        snail = run("pixel_snail", args.snail_batch, steps=max(10, args.steps // 2))
+        snail = run("pixel_snail", args.snail_batch)
         snail["reference_default_batch_128"] = run("pixel_snail", 128)
         extras["pixel_snail"] = snail
+        others = {}
+        for key, name, batch, cfg in OTHER_CONFIGS:  # compact driver-run records of the other BASELINE configs
+            r = run(name, batch, steps=max(5, args.steps // 4))
+            others[key] = {"baseline_config": cfg, "images_per_s": r["images_per_s"], "ms_per_step": r["ms_per_step"],
+                           "per_gpu_batch": batch, "launch": r["launch"],
+                           "frac_of_fp32_compute_ceiling": r["images_per_s"] / env.world / CEILINGS[key],
+                           "loss_nats_per_image": r["loss_nats_per_image"]}
+        extras["other_configs"] = others
 
     if env.rank == 0:
         out = {
@@ -499,21 +553,30 @@ def main():
         if "pixel_snail" in extras:
             out["pixel_snail"] = {"workload": WORKLOAD_TEXT["pixel_snail"] + "; " + STEP_TEXT,
                                   "unit": "images/s", "dtype": "f32", **extras["pixel_snail"]}
+        if "other_configs" in extras:
+            out["other_configs"] = {"what": "the other BASELINE.json configurations, same step definition, 1/4 of "
+                                            "the headline's timed steps each; ceilings: BASELINE.md §3", "unit": "images/s",
+                                    **extras["other_configs"]}
         if env.world == 1:
             r = attention_kernel_roofline(args.batch, env.device, 4, 4, 4, 28, False)
+            dom = "bwd" if "bwd" in r else "dkv"
             out["roofline"] = {
                 "bound": "mfma",  # fp32: matrix peak == vector peak == 157.3 TF on gfx950; the
-                                  # kernel is fp32-MFMA + v_exp issue bound
-                "kernel": "attn_dkv_m44_kernel (pg_causal_attn_bwd_dkv)",
-                "achieved": r["dkv"]["tflops"],
+                                  # kernel is 4x4x1-MFMA + v_exp issue bound
+                "kernel": "attn_bwd_m44_kernel (pg_causal_attn_bwd: dQ, dK, dV fused)" if dom == "bwd"
+                          else "attn_dkv_m44_kernel (pg_causal_attn_bwd_dkv)",
+                "achieved": r[dom]["tflops"],
                 "peak": FP32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": r["dkv"]["tflops"] / FP32_PEAK_TFLOPS,
-                "traffic": measured_traffic(args.batch),
-                "launch_ms": r["dkv"]["launch_ms"],
-                "flop_per_launch": r["dkv"]["flop_per_launch"],
-                "other_kernels": {"attn_fwd_m44_kernel": r["fwd"], "attn_dq_m44_kernel": r["dq"]},
-                # whole step; attention counted on the causal triangle (what the kernels execute)
+                "frac": r[dom]["tflops"] / FP32_PEAK_TFLOPS,
+                "traffic": measured_traffic(args.batch, "attn_bwd_m44_kernel" if dom == "bwd" else "attn_dkv_m44_kernel"),
+                "launch_ms": r[dom]["launch_ms"],
+                "flop_per_launch": r[dom]["flop_per_launch"],
+                "flop_accounting": "algorithmic: 6 d_k + 4 d_v = 40 FLOP per allowed (query, key) pair, every product once",
+                "other_kernels": {"attn_fwd_m44_kernel": r["fwd"],
+                                  "two_kernel_backward (PG_ATTN_FUSED_BWD=0)": {"attn_dq_m44_kernel": r["dq"],
+                                                                                "attn_dkv_m44_kernel": r["dkv"]}},
+                # whole step; attention counted on the causal triangle, algorithmic (no recomputation)
                 "step_tflops": head["step_tflops"],
                 "step_frac": head["step_frac_of_fp32_peak"],
                 "step_tflops_dense_attention_count": head["step_tflops_dense_attention_count"],
@@ -541,6 +604,8 @@ def main():
                 }
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
+                if "pixel_snail" in out:
+                    out["pixel_snail"]["cpu_baseline"] = cpu_baseline_pixel_snail(out["cpu_baseline"]["cores"])
         print(json.dumps(out), flush=True)
     if env.world > 1:
         dist.destroy_process_group()

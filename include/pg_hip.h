@@ -168,7 +168,9 @@ int pg_nchw_layernorm_bwd_res(const float* x, const float* gamma, const float* m
 int pg_causal_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse2,
                        int N, int heads, int L, int dk, int dv, long q_bs, long k_bs, long v_bs,
                        long o_bs, int strict, void* stream);
-/* dq/dk/dv written (not accumulated). delta: (N, heads, L) workspace. */
+/* dq/dk/dv written (not accumulated). delta: (N, heads, L) workspace. For d_k = d_v = 4 this is ONE
+ * fused launch (attention_mfma.hip attn_bwd_m44_kernel: S, dP and exp2 evaluated once per pair; delta
+ * is then not written); otherwise the two launches below. */
 int pg_causal_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                        const float* d_o, const float* lse2, float* delta, float* dq, float* dk,
                        float* dv, int N, int heads, int L, int dk_dim, int dv_dim, long q_bs,
@@ -187,6 +189,12 @@ int pg_causal_attn_bwd_dkv(const float* q, const float* k, const float* v, const
                            float* dv, int N, int heads, int L, int dk_dim, int dv_dim, long q_bs,
                            long k_bs, long v_bs, long o_bs, long do_bs, long dq_bs, long dk_bs,
                            long dv_bs, int strict, void* stream);
+
+/* Process-wide switch of the fused backward: enable = 1 / 0 sets it and returns the previous value,
+ * enable < 0 only queries. The fused kernel sums dQ over key blocks in a timing-dependent order (last-bit
+ * run-to-run differences in dQ); pg_attn_fused_bwd(0) selects the bit-reproducible two-kernel backward.
+ * Initial value: 1, or the environment's PG_ATTN_FUSED_BWD at load time. */
+int pg_attn_fused_bwd(int enable);
 
 /* (N,2,H,W) pixel-coordinate encoding, nn/attention.py:37-57 (torch.arange(-.5,.5,1/h)). */
 int pg_image_positional_encoding(float* out, int N, int H, int W, void* stream);

@@ -597,6 +597,10 @@ int attn_bwd_impl(int which_mask, const float* q, const float* k, const float* v
   a.dq_bs = dq_bs; a.dk_bs = dk_bs; a.dv_bs = dv_bs;
   a.scale = 1.f / sqrtf((float)dk_dim);
   a.scale2 = a.scale * 1.44269504088896340736f;
+  if (which_mask == 3 && use_mfma_attention() && pg_attn_mfma_launch(PG_ATTN_BWD, a, (hipStream_t)stream) == 1) {
+    PG_LAUNCH_CHECK("pg_causal_attn_bwd(fused)");  // dQ, dK, dV in one pass (attention_mfma.hip)
+    return 0;
+  }
   if (which_mask & 1) {
     rc = launch_any(K_DQ, a, (hipStream_t)stream);
     PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: unsupported head dims");

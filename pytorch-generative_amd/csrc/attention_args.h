@@ -22,7 +22,7 @@ struct PgAttnArgs {
   unsigned char blist[8][16];
 };
 
-enum { PG_ATTN_FWD = 0, PG_ATTN_DQ = 1, PG_ATTN_DKV = 2 };
+enum { PG_ATTN_FWD = 0, PG_ATTN_DQ = 1, PG_ATTN_DKV = 2, PG_ATTN_BWD = 3 /* fused dQ + dK + dV (d_k = d_v = 4) */ };
 
 // attention_mfma.hip. Returns 1 if the matrix-core path took the launch, 0 if the shape is not
 // covered (caller uses the VALU kernels); launch errors are left for PG_LAUNCH_CHECK.

@@ -688,6 +688,303 @@ __global__ void __launch_bounds__(512) attn_dkv_m44_kernel(const PgAttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ backward, fused
+// dQ, dK and dV in ONE pass over the allowed (query, key) pairs (round 3). The two-kernel backward above
+// evaluates S, dP and exp2 twice (once per orientation: 24 + 32 = 56 FLOP and 2 exp per pair); here a
+// pair costs 40 FLOP and 1 exp. Orientation = the dK/dV kernel's (owner = 64-key block, queries
+// stream, tile D layout lane (key j, g), VGPR r <-> query 4g+r), so dV += P^T dO and dK += dS^T Q
+// accumulate in registers as before. dQ += dS K contracts over KEYS, which live on the lane axis of
+// that layout: each 16x16 dS tile is transposed through a per-wave 1 KB LDS scratch (one
+// ds_write_b128 + four ds_read_b32), then the transposed tile's registers are the A operands of four
+// more 4x4x1 MFMAs against resident K^T values (the partial products of a wave's four key groups for
+// one 16-query tile add up in ONE accumulator). Per 16-query x 64-key step that accumulator is summed
+// over the four lane groups through the same scratch (one ds_write_b128, four ds_read_b32: lane l then
+// owns output l = (channel, query)) and deposited into a per-workgroup dQ plane in LDS; the planes
+// are written to HBM once at the end. The deposit is NOT ds_add_f32: measured on MI355X
+// (tools/exp/lds_atomic_ubench.hip) an LDS fp32 atomic add costs 194 cycles per wave-instruction per CU
+// whatever its addresses (ds_add_u32: 4.7, a plain read + write: 11) — with four of them per step the
+// first version of this kernel ran 2.05 ms against 0.99 ms for the two kernels it replaces. Instead a
+// lane takes the slot's content with an integer exchange (old = xchg(slot, 0); x += old), puts the sum
+// back (old2 = xchg(slot, x)) and, if another wave deposited in between (old2 != 0), carries old2 into
+// another round: nothing is ever lost, no lock, two integer-speed atomics in the common case.
+// (dQ's summation order over key blocks varies from run to run in the last bit; dK / dV stay
+// bit-reproducible. PG_ATTN_FUSED_BWD=0 selects the two-kernel path.)
+//   scratch layout (both directions conflict free under the per-instruction banking of
+//   MI355X_MICROARCH.md §LDS: ds_write_b128 = 8-lane groups, ds_read_b32 = 32-lane groups, 32 banks):
+//   element (key k, query q) of the 16 x 16 tile lives in 16-byte slot 16 G + ((k + 2 G) & 15),
+//   G = q >> 2, at dword q & 3. A writing lane (key k, lane group G) stores its four queries as one
+//   slot; a reading lane (query q, lane group g') takes keys g' + 4 s, s = 0..3 — for one s the 32
+//   lanes of a read group cover slots (g' + 4 s + 2 G) & 7 = all eight residues — and the resident
+//   K^T values are laid out in that key order.
+// S runs on the bf16x3 MFMA with -lse2 folded into the contraction (32-byte query rows
+// [qh qm | ql c_h c_m c_l 0] against resident key operands [kh kh], [km km], [kh 1 1 1 0], [kl 0]
+// for lane groups 0..3: qh.kh + qm.kh + qh.km + qm.km + ql.kh + qh.kl + c), dP on the fp32 16x16x4
+// tile with -delta in the C operand; delta = sum_j dO O is computed while staging (no delta tensor).
+// LDS: 21 planes of Lp floats + 8 KB scratch = 79.4 KB at L = 784: two 8-wave workgroups per CU.
+// Measured on MI355X at N = 1024, 4 heads, L = 784 (tools/exp/attn_bwd_ab.py, gpurun_out r3c): the two
+// kernels above 465 + 544 = 1010 us, this kernel 752 us (all results within 1e-6 of theirs). Ablation
+// (PG_ATTN_BWD_DBG): without the deposit 723, also without the transposition 701, also without the dQ
+// MFMAs 629. Variants built and measured, then removed: key groups all four at a time 953 us and
+// register prefetch of the next tile's fragments 1092 us (both spill at 128 registers); 6-wave
+// workgroups with up to 168 registers (3 waves per SIMD, no spills) 1257-1266 us.
+__device__ __forceinline__ bf16x8 resident_operand_k(const float (&x)[4], int kg) {
+  bf16x8 v;
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    const Split3 s = split3(x[dd]);
+    v[dd] = kg == 1 ? s.m : (kg == 3 ? s.l : s.h);
+    v[4 + dd] = kg == 0 ? s.h : (kg == 1 ? s.m : (__bf16)0.f);
+  }
+  if (kg == 2) { v[4] = v[5] = v[6] = (__bf16)1.f; }
+  return v;
+}
+
+__device__ __forceinline__ void put_row32(bf16x8* __restrict__ w1, bf16x8* __restrict__ w2, int row,
+                                          const float (&y)[4], float c) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    const Split3 s = split3(y[dd]);
+    a[dd] = s.h; a[4 + dd] = s.m;
+    b[dd] = s.l;
+  }
+  const Split3 cc = split3(c);
+  b[4] = cc.h; b[5] = cc.m; b[6] = cc.l; b[7] = (__bf16)0.f;
+  w1[row] = a;
+  w2[row] = b;
+}
+
+__global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a) {
+  constexpr int TG = 2;  // key groups processed together (see the variants measured below)
+  extern __shared__ float4 lds4[];
+  const int Lp = a.lp;
+  bf16x8* qw1 = reinterpret_cast<bf16x8*>(lds4);          // [Lp] [qh qm]      (16-byte stride: conflict-free
+  bf16x8* qw2 = qw1 + Lp;                                 // [Lp] [ql c 0]      ds_read_b128 fragment reads)
+  float* qt = reinterpret_cast<float*>(lds4) + 8 * Lp;    // Q^T  [4][Lp]
+  float* gt = qt + 4 * Lp;                                // dO^T [4][Lp]
+  float* ndel = gt + 4 * Lp;                              // -delta [Lp]
+  float* dqa = ndel + Lp;                                 // dQ accumulators [4][Lp]
+  const Ids d = ids();
+  float* scr = dqa + 4 * Lp + d.wave * 256;               // this wave's 16 x 16 transposition scratch
+  const int qi = d.qi, g = d.g, jc = d.jc;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int L = a.L;
+  const int NB = (L + 63) >> 6;
+
+  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
+  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
+  const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * 4 * L;
+  const float* op = a.o + (size_t)n * a.o_bs + (size_t)h * 4 * L;
+  const float* gp = a.d_o + (size_t)n * a.do_bs + (size_t)h * 4 * L;
+  float* dqp = a.dq + (size_t)n * a.dq_bs + (size_t)h * 4 * L;
+  float* dkp = a.dk + (size_t)n * a.dk_bs + (size_t)h * 4 * L;
+  float* dvp = a.dv + (size_t)n * a.dv_bs + (size_t)h * 4 * L;
+  const size_t row = ((size_t)n * a.heads + h) * L;
+
+  const int r1 = 64 * NB;
+  const int nmine = a.bcount[d.wave];  // this wave's key blocks: a.blist[wave][0..nmine)
+  // q, dO -> planes + 32-byte rows, delta, zeroed dQ planes: one pass, all global loads of an iteration first
+  for (int m0 = 0; m0 < r1; m0 += 2 * blockDim.x) {
+    float qx[2][4], gx[2][4], ox[2][4], lx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * blockDim.x + threadIdx.x;
+      load_row4(qx[u], qp, L, m);
+      load_row4(gx[u], gp, L, m);
+      load_row4(ox[u], op, L, m);
+      lx[u] = a.lse2_in[row + (m < L ? m : L - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u * blockDim.x + threadIdx.x;
+      if (m < r1) {
+        float dl = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          qt[dd * Lp + m] = qx[u][dd];
+          gt[dd * Lp + m] = gx[u][dd];
+          dqa[dd * Lp + m] = 0.f;
+          dl = fmaf(gx[u][dd], ox[u][dd], dl);
+        }
+        put_row32(qw1, qw2, m, qx[u], m < L ? -lx[u] : NEG_BIG);
+        ndel[m] = -dl;
+      }
+    }
+  }
+  __syncthreads();
+  const int q_end = ((L + 15) >> 4) << 4;
+  // streamed score operand of this lane: lane groups 0, 1, 3 read [qh qm], group 2 reads [ql c]
+  const bf16x8* qbase = (g == 2 ? qw2 : qw1) + qi;
+  // transposition scratch: this lane writes its key's row (permuted), reads column qi of rows 4g..4g+3
+  float* scr_w = scr + 4 * (16 * g + ((qi + 2 * g) & 15));
+  const float* scr_r[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl)
+    scr_r[sl] = scr + 4 * (16 * (qi >> 2) + ((g + 4 * sl + 2 * (qi >> 2)) & 15)) + (qi & 3);
+  const int dbg = a.kt;  // ablation switches (PG_ATTN_BWD_DBG), 0 in production: 1 no atomics, 2 no transposition, 4 no dQ MFMAs
+  float* red_w = scr + 64 * g + 16 * jc + d.qb4;
+  const float* red_r = scr + d.lane;
+  unsigned int* dq_slot = reinterpret_cast<unsigned int*>(dqa + (d.lane >> 4) * Lp + (d.lane & 15));
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int it = 0; it < nmine; ++it) {
+    const int blk = a.blist[d.wave][it];
+    const int kb0 = 64 * blk;
+    const int ngrp = min(4, (L - kb0 + 15) >> 4);
+
+    float vf[4];
+    bf16x8 bk[4];
+    f32x4 kq[4];  // K^T values of the transposed tile's registers: kq[t][s] = K[kb0 + 16 t + g + 4 s][jc]
+    f32x4 acck[4], accv[4];
+    int kidx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      kidx[t] = kb0 + 16 * t + qi;
+      const bool ok = kidx[t] < L;
+      vf[t] = ok ? vp[(size_t)g * L + kidx[t]] : 0.f;
+      float k4[4];
+      load_row4(k4, kp, L, kidx[t]);
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) k4[dd] *= a.scale2;
+      bk[t] = resident_operand_k(k4, g);
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        const int kk = kb0 + 16 * t + g + 4 * sl;
+        const float kv = kp[(size_t)jc * L + (kk < L ? kk : L - 1)];
+        kq[t][sl] = kk < L ? kv : 0.f;
+      }
+      acck[t] = zero4;
+      accv[t] = zero4;
+    }
+
+    // One 16-query tile against key groups [0, TMAX]: P = exp2(S - lse), dS = P * (dP - delta),
+    // dV += P^T dO, dK += dS^T Q, dQ += dS K. MASK: group TMAX is on its diagonal.
+    struct Frag { float ga; bf16x8 qa8; f32x4 cd, qq, gq; };
+    auto frag = [&](int q0t) {
+      Frag f;
+      f.qa8 = qbase[q0t];
+      f.ga = gt[g * Lp + q0t + qi];
+      f.cd = *reinterpret_cast<const f32x4*>(ndel + q0t + 4 * g);
+      f.qq = *reinterpret_cast<const f32x4*>(qt + jc * Lp + q0t + 4 * g);
+      f.gq = *reinterpret_cast<const f32x4*>(gt + jc * Lp + q0t + 4 * g);
+      return f;
+    };
+    auto step = [&](int q0t, const Frag& f, auto TMAX_, auto MASK_) {
+      constexpr int TMAX = decltype(TMAX_)::value;
+      constexpr bool MASK = decltype(MASK_)::value;
+      f32x4 dqacc = zero4;
+      // TG key groups at a time: their score / exp / product chains are independent, and the LDS round
+      // trip of one tile's transposition runs under the dV / dK MFMAs of the next (a wave's LDS
+      // operations execute in order: a tile's reads are queued before the next tile's write, so ONE
+      // scratch tile per wave suffices and no wait sits between a write and its reads)
+#pragma unroll
+      for (int t0 = 0; t0 <= TMAX; t0 += TG) {
+        f32x4 s[TG], dp[TG], ds[TG];
+        float p[TG][4], dst[TG][4];
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+          const int t = t0 + u;
+          if (t <= TMAX) {
+            s[u] = MFMA16B(f.qa8, bk[t], zero4);
+            dp[u] = MFMA16(f.ga, vf[t], f.cd);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+          const int t = t0 + u;
+          if (t <= TMAX) {
+            const bool cut = MASK && t == TMAX;
+            const int lowest = cut ? kidx[t] + a.strict - (q0t + 4 * g) : 0;  // query 4g+r allowed iff r >= lowest
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              p[u][r] = (!cut || r >= lowest) ? ex2(s[u][r]) : 0.f;
+              ds[u][r] = p[u][r] * dp[u][r];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u <= TG; ++u) {
+          const int t = t0 + u;
+          if (u < TG && t <= TMAX) {
+            if (!(dbg & 2)) {
+              *reinterpret_cast<f32x4*>(scr_w) = ds[u];
+              asm volatile("" ::: "memory");
+#pragma unroll
+              for (int sl = 0; sl < 4; ++sl) dst[u][sl] = *scr_r[sl];
+              asm volatile("" ::: "memory");
+            } else {
+#pragma unroll
+              for (int sl = 0; sl < 4; ++sl) dst[u][sl] = ds[u][sl];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              accv[t] = MFMA4(p[u][r], f.gq[r], accv[t]);
+              acck[t] = MFMA4(ds[u][r], f.qq[r], acck[t]);
+            }
+          }
+          if (u > 0 && t - 1 <= TMAX) {  // dQ of the previous tile: its transposed values have had a tile's time
+            if (!(dbg & 4)) {
+#pragma unroll
+              for (int sl = 0; sl < 4; ++sl) dqacc = MFMA4(dst[u - 1][sl], kq[t - 1][sl], dqacc);
+            } else {
+#pragma unroll
+              for (int sl = 0; sl < 4; ++sl) dqacc[sl] += dst[u - 1][sl];
+            }
+          }
+        }
+      }
+      // D_b[i'][j'] of block (g, qb): query q0t + 4 qb + i', channel jc — partial over this lane group's keys
+      if (!(dbg & 1)) {
+        // sum over the four lane groups through the scratch (the last tile's transposed values have been
+        // consumed: LDS operations of a wave execute in order), then lane l owns output (channel l >> 4,
+        // query q0t + (l & 15))
+        *reinterpret_cast<f32x4*>(red_w) = dqacc;
+        asm volatile("" ::: "memory");
+        float x = (red_r[0] + red_r[64]) + (red_r[128] + red_r[192]);
+        asm volatile("" ::: "memory");
+        unsigned int* slot = dq_slot + q0t;
+        for (;;) {
+          x += __uint_as_float(atomicExch(slot, 0u));
+          const unsigned int back = atomicExch(slot, __float_as_uint(x));
+          if (__uint_as_float(back) == 0.f) break;  // the slot was empty: deposited
+          x = __uint_as_float(back);                // another wave's deposit came in between: carry it on
+        }
+      } else {
+        accv[0] += dqacc;  // keep the values alive
+      }
+    };
+    // the block's own 64 queries: tile u meets key groups t <= u, group u on its diagonal
+    step(kb0, frag(kb0), I<0>{}, B<true>{});
+    if (ngrp > 1) step(kb0 + 16, frag(kb0 + 16), I<1>{}, B<true>{});
+    if (ngrp > 2) step(kb0 + 32, frag(kb0 + 32), I<2>{}, B<true>{});
+    if (ngrp > 3) step(kb0 + 48, frag(kb0 + 48), I<3>{}, B<true>{});
+    // every later query tile: all four key groups, no masks. (No register prefetch of the next tile's
+    // fragments: at 128 registers it spills; the other three waves of the SIMD cover the LDS latency.)
+    for (int q0t = kb0 + 64; q0t < q_end; q0t += 16) step(q0t, frag(q0t), I<3>{}, B<false>{});
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < ngrp) {
+        float k4[4], v4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          k4[i] = gsum(acck[t][i]) * a.scale;
+          v4[i] = gsum(accv[t][i]);
+        }
+        if (g == 0) {
+          store_rows4(dkp + (size_t)jc * L, L, kb0 + 16 * t + d.qb4, a.vec, k4[0], k4[1], k4[2], k4[3]);
+          store_rows4(dvp + (size_t)jc * L, L, kb0 + 16 * t + d.qb4, a.vec, v4[0], v4[1], v4[2], v4[3]);
+        }
+      }
+    }
+  }
+  __syncthreads();  // every wave's dQ contributions are in the planes
+  for (int i = threadIdx.x; i < 4 * L; i += blockDim.x) {
+    const int dd = i / L, m = i - dd * L;
+    dqp[(size_t)dd * L + m] = dqa[dd * Lp + m] * a.scale;
+  }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -712,7 +1009,25 @@ static void attn_waves(int* w) {
 
 int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st);  // attention_k4.hip
 
+// process-wide switch of the fused backward (default: on, or PG_ATTN_FUSED_BWD=0/1 at load time);
+// pg_attn_fused_bwd(0) selects the two-kernel backward, whose results are bit-reproducible
+#include <atomic>
+static std::atomic<int>& fused_bwd_flag() {
+  static std::atomic<int> flag([]() { const char* e = getenv("PG_ATTN_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }());
+  return flag;
+}
+static bool pg_attn_fused_bwd_enabled() { return fused_bwd_flag().load(std::memory_order_relaxed) != 0; }
+PG_EXPORT int pg_attn_fused_bwd(int enable) {
+  if (enable < 0) return fused_bwd_flag().load(std::memory_order_relaxed);
+  return fused_bwd_flag().exchange(enable ? 1 : 0, std::memory_order_relaxed);
+}
+
 int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
+  if (which == PG_ATTN_BWD) {
+    // fused backward: d_k = d_v = 4 only; PG_ATTN_FUSED_BWD=0 keeps the two-kernel backward (A/B, and
+    // bit-reproducible dQ: the fused kernel sums dQ over key blocks with fp32 LDS atomics)
+    if (!pg_attn_fused_bwd_enabled() || a0.dk_dim != 4 || a0.dv_dim != 4) return 0;
+  }
   if (a0.dk_dim == 4 && a0.dv_dim != 4) return pg_attn_k4_launch(which, a0, st);
   if (a0.dk_dim != 4 || a0.dv_dim != 4) return 0;
   PgAttnArgs a = a0;
@@ -723,12 +1038,19 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   // dK/dV score tile on the bf16x3 MFMA (default; PG_ATTN_DKV_BF16=0 selects the all-fp32 variant:
   // measured 0.534-0.545 ms vs 0.515-0.521 ms per launch at batch 1024)
   static const bool dkv_bf16 = []() { const char* e = getenv("PG_ATTN_DKV_BF16"); return !(e && e[0] == '0'); }();
-  const size_t planes = which == PG_ATTN_DKV ? (dkv_bf16 ? 18 : 10) : (which == PG_ATTN_DQ ? 20 : 12);
-  const size_t shmem = planes * (size_t)a.lp * sizeof(float) + 16;
-  if (shmem > 160 * 1024) return 0;
+  const size_t planes = which == PG_ATTN_BWD ? 21
+                        : which == PG_ATTN_DKV ? (dkv_bf16 ? 18 : 10) : (which == PG_ATTN_DQ ? 20 : 12);
   int wcfg[3];
   attn_waves(wcfg);
-  int W = wcfg[which];
+  static const int bwd_waves = []() {
+    const char* e = getenv("PG_ATTN_BWD_WAVES");
+    const int v = e ? atoi(e) : 8;
+    return v >= 1 && v <= 8 ? v : 8;
+  }();
+  int W = which == PG_ATTN_BWD ? bwd_waves : wcfg[which];
+  // fused backward: + 1 KB of transposition scratch per wave
+  const size_t shmem = planes * (size_t)a.lp * sizeof(float) + (which == PG_ATTN_BWD ? 8 * 1024 : 16);
+  if (shmem > 160 * 1024) return 0;
   if (which == PG_ATTN_DKV && dkv_bf16 && !getenv("PG_ATTN_WAVES")) W = 8;
   // few (n, head) units (the reference's default batch 64 x 4 heads = one workgroup per CU): the launch
   // lasts as long as its most loaded wave, so the forward kernel also spreads its 13 query blocks over
@@ -741,7 +1063,7 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int w = 0; w < 8; ++w) a.bcount[w] = 0;
   for (int rank = NB - 1; rank >= 0; --rank) {
-    const int blk = which == PG_ATTN_DKV ? NB - 1 - rank : rank;
+    const int blk = (which == PG_ATTN_DKV || which == PG_ATTN_BWD) ? NB - 1 - rank : rank;
     int best = 0;
     for (int w = 1; w < W; ++w)
       if (load[w] < load[best] && a.bcount[w] < 16) best = w;
@@ -754,17 +1076,24 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
     a.vec = a.vec && aligned16(a.o_out) && a.o_bs % 4 == 0;
   else if (which == PG_ATTN_DQ)
     a.vec = a.vec && aligned16(a.dq) && a.dq_bs % 4 == 0;
-  else
+  else  // dK/dV and the fused backward (whose dQ planes are written with scalar stores)
     a.vec = a.vec && aligned16(a.dk) && aligned16(a.dv) && a.dk_bs % 4 == 0 && a.dv_bs % 4 == 0;
   dim3 grid(1u, (unsigned)a.heads, (unsigned)a.N);
   dim3 block((unsigned)(64 * W));
+  if (which == PG_ATTN_BWD) {
+    static const int bwd_dbg = []() { const char* e = getenv("PG_ATTN_BWD_DBG"); return e ? atoi(e) : 0; }();
+    a.kt = bwd_dbg;
+  }
   const void* fn = which == PG_ATTN_FWD  ? reinterpret_cast<const void*>(attn_fwd_m44_kernel)
+                   : which == PG_ATTN_BWD ? reinterpret_cast<const void*>(attn_bwd_m44_kernel)
                    : which == PG_ATTN_DQ ? reinterpret_cast<const void*>(attn_dq_m44_kernel)
                    : dkv_bf16            ? reinterpret_cast<const void*>(attn_dkv_m44_kernel<true>)
                                          : reinterpret_cast<const void*>(attn_dkv_m44_kernel<false>);
   if (shmem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (which == PG_ATTN_FWD)
     hipLaunchKernelGGL(attn_fwd_m44_kernel, grid, block, shmem, st, a);
+  else if (which == PG_ATTN_BWD)
+    hipLaunchKernelGGL(attn_bwd_m44_kernel, grid, block, shmem, st, a);
   else if (which == PG_ATTN_DQ)
     hipLaunchKernelGGL(attn_dq_m44_kernel, grid, block, shmem, st, a);
   else if (dkv_bf16)

@@ -816,6 +816,15 @@ class _CausalAttentionQKV(torch.autograd.Function):
         return dqkv, None, None, None, None
 
 
+def set_deterministic(on=True):
+    """Bit-reproducible gradients (on) or the fastest kernels (off, the default). The only kernel whose
+    result depends on timing is the fused attention backward for d_k = d_v = 4 (dQ is summed over key
+    blocks in arrival order: last-bit differences run to run); `on` selects the two-kernel backward.
+    Returns the previous setting."""
+    prev = _lib.load().pg_attn_fused_bwd(0 if on else 1)
+    return prev == 0
+
+
 def causal_attention_qkv(qkv, n_heads, embed_channels, value_channels, mask_center):
     """causal_attention on the merged [q | k | v] tensor."""
     return _CausalAttentionQKV.apply(qkv, n_heads, embed_channels, value_channels, bool(mask_center))

@@ -124,6 +124,7 @@ class Trainer:
         self.train_loader, self.eval_loader = train_loader, eval_loader
         self.clip_grad_norm, self.skip_grad_norm = clip_grad_norm, skip_grad_norm
         self.log_dir = log_dir or tempfile.mkdtemp()
+        os.makedirs(self.log_dir, exist_ok=True)  # the reference's SummaryWriter creates it (trainer.py:87)
         self.sample_epochs, self.save_checkpoint_epochs = sample_epochs, save_checkpoint_epochs
 
         self.device = self._resolve_device(model, n_gpus, device_id)

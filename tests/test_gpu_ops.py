@@ -183,6 +183,33 @@ def test_causal_attention_core(dev, case):
     _util.assert_close(kvg.grad[:, e:], kvo.grad[:, e:], TOL, "attn dv")
 
 
+@pytest.mark.parametrize("case", [(3, 2, 28, 28, True), (1, 3, 7, 9, False), (1, 1, 32, 32, False),
+                                  (1, 2, 36, 36, True), (40, 4, 28, 28, False)],
+                         ids=lambda c: "-".join(str(int(v)) for v in c))
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_bwd", "two_kernel_bwd"])
+def test_attention_m44_backward_paths(dev, case, fused):
+    """d_k = d_v = 4: the fused backward (dQ, dK, dV in one pass, attn_bwd_m44_kernel) and the two-kernel
+    backward (ops.set_deterministic) against the oracle; the batch-40 case has several workgroups per
+    CU and every wave of a workgroup depositing into the same dQ planes."""
+    from pytorch_generative_amd import ops
+
+    n, heads, h, w, strict = case
+    e = v = heads * 4
+    q, kv, d_o = _rand(n, e, h, w, seed=1), _rand(n, e + v, h, w, seed=2), _rand(n, v, h, w, seed=3)
+    qo, kvo = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    oops.causal_attention_core(qo, kvo[:, :e], kvo[:, e:], heads, strict).backward(d_o)
+    was = ops.set_deterministic(not fused)
+    try:
+        qg, kvg = q.to(dev).requires_grad_(True), kv.to(dev).requires_grad_(True)
+        ops.causal_attention(qg, kvg, heads, e, v, strict).backward(d_o.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_deterministic(was)
+    _util.assert_close(qg.grad, qo.grad, TOL, "attn dq")
+    _util.assert_close(kvg.grad[:, :e], kvo.grad[:, :e], TOL, "attn dk")
+    _util.assert_close(kvg.grad[:, e:], kvo.grad[:, e:], TOL, "attn dv")
+
+
 def test_attention_large_scores_stay_finite(dev):
     """Online-softmax rescale branch: a spike late in the key sequence forces the running max to
     jump; compare with the oracle on the same data."""
