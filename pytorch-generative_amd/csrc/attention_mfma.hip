@@ -723,8 +723,8 @@ __global__ void __launch_bounds__(512) attn_dkv_m44_kernel(const PgAttnArgs a) {
 // LDS: 21 planes of Lp floats + 8 KB scratch = 79.4 KB at L = 784: two 8-wave workgroups per CU.
 // Measured on MI355X at N = 1024, 4 heads, L = 784 (tools/exp/attn_bwd_ab.py, gpurun_out r3c): the two
 // kernels above 465 + 544 = 1010 us, this kernel 752 us (all results within 1e-6 of theirs). Ablation
-// (PG_ATTN_BWD_DBG): without the deposit 723, also without the transposition 701, also without the dQ
-// MFMAs 629. Variants built and measured, then removed: key groups all four at a time 953 us and
+// (runtime switches since removed: they split the step into basic blocks): without the deposit 723,
+// also without the transposition 701, also without the dQ MFMAs 629. Variants built and measured, then removed: key groups all four at a time 953 us and
 // register prefetch of the next tile's fragments 1092 us (both spill at 128 registers); 6-wave
 // workgroups with up to 168 registers (3 waves per SIMD, no spills) 1257-1266 us.
 __device__ __forceinline__ bf16x8 resident_operand_k(const float (&x)[4], int kg) {
@@ -754,10 +754,13 @@ __device__ __forceinline__ void put_row32(bf16x8* __restrict__ w1, bf16x8* __res
   w2[row] = b;
 }
 
+// LPC: the LDS plane stride as a compile-time constant (848 = 28 x 28 images, 1040 = 32 x 32; 0 = runtime
+// a.lp): every plane pointer then is ONE lane base + an immediate offset instead of a register each
+template <int LPC>
 __global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a) {
   constexpr int TG = 2;  // key groups processed together (see the variants measured below)
   extern __shared__ float4 lds4[];
-  const int Lp = a.lp;
+  const int Lp = LPC > 0 ? LPC : a.lp;
   bf16x8* qw1 = reinterpret_cast<bf16x8*>(lds4);          // [Lp] [qh qm]      (16-byte stride: conflict-free
   bf16x8* qw2 = qw1 + Lp;                                 // [Lp] [ql c 0]      ds_read_b128 fragment reads)
   float* qt = reinterpret_cast<float*>(lds4) + 8 * Lp;    // Q^T  [4][Lp]
@@ -821,7 +824,6 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a
 #pragma unroll
   for (int sl = 0; sl < 4; ++sl)
     scr_r[sl] = scr + 4 * (16 * (qi >> 2) + ((g + 4 * sl + 2 * (qi >> 2)) & 15)) + (qi & 3);
-  const int dbg = a.kt;  // ablation switches (PG_ATTN_BWD_DBG), 0 in production: 1 no atomics, 2 no transposition, 4 no dQ MFMAs
   float* red_w = scr + 64 * g + 16 * jc + d.qb4;
   const float* red_r = scr + d.lane;
   unsigned int* dq_slot = reinterpret_cast<unsigned int*>(dqa + (d.lane >> 4) * Lp + (d.lane & 15));
@@ -907,16 +909,11 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a
         for (int u = 0; u <= TG; ++u) {
           const int t = t0 + u;
           if (u < TG && t <= TMAX) {
-            if (!(dbg & 2)) {
-              *reinterpret_cast<f32x4*>(scr_w) = ds[u];
-              asm volatile("" ::: "memory");
+            *reinterpret_cast<f32x4*>(scr_w) = ds[u];
+            asm volatile("" ::: "memory");
 #pragma unroll
-              for (int sl = 0; sl < 4; ++sl) dst[u][sl] = *scr_r[sl];
-              asm volatile("" ::: "memory");
-            } else {
-#pragma unroll
-              for (int sl = 0; sl < 4; ++sl) dst[u][sl] = ds[u][sl];
-            }
+            for (int sl = 0; sl < 4; ++sl) dst[u][sl] = *scr_r[sl];
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               accv[t] = MFMA4(p[u][r], f.gq[r], accv[t]);
@@ -924,18 +921,13 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a
             }
           }
           if (u > 0 && t - 1 <= TMAX) {  // dQ of the previous tile: its transposed values have had a tile's time
-            if (!(dbg & 4)) {
 #pragma unroll
-              for (int sl = 0; sl < 4; ++sl) dqacc = MFMA4(dst[u - 1][sl], kq[t - 1][sl], dqacc);
-            } else {
-#pragma unroll
-              for (int sl = 0; sl < 4; ++sl) dqacc[sl] += dst[u - 1][sl];
-            }
+            for (int sl = 0; sl < 4; ++sl) dqacc = MFMA4(dst[u - 1][sl], kq[t - 1][sl], dqacc);
           }
         }
       }
       // D_b[i'][j'] of block (g, qb): query q0t + 4 qb + i', channel jc — partial over this lane group's keys
-      if (!(dbg & 1)) {
+      {
         // sum over the four lane groups through the scratch (the last tile's transposed values have been
         // consumed: LDS operations of a wave execute in order), then lane l owns output (channel l >> 4,
         // query q0t + (l & 15))
@@ -950,8 +942,6 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a
           if (__uint_as_float(back) == 0.f) break;  // the slot was empty: deposited
           x = __uint_as_float(back);                // another wave's deposit came in between: carry it on
         }
-      } else {
-        accv[0] += dqacc;  // keep the values alive
       }
     };
     // the block's own 64 queries: tile u meets key groups t <= u, group u on its diagonal
@@ -979,10 +969,9 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a
     }
   }
   __syncthreads();  // every wave's dQ contributions are in the planes
-  for (int i = threadIdx.x; i < 4 * L; i += blockDim.x) {
-    const int dd = i / L, m = i - dd * L;
-    dqp[(size_t)dd * L + m] = dqa[dd * Lp + m] * a.scale;
-  }
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd)
+    for (int m = threadIdx.x; m < L; m += blockDim.x) dqp[(size_t)dd * L + m] = dqa[dd * Lp + m] * a.scale;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1080,20 +1069,22 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
     a.vec = a.vec && aligned16(a.dk) && aligned16(a.dv) && a.dk_bs % 4 == 0 && a.dv_bs % 4 == 0;
   dim3 grid(1u, (unsigned)a.heads, (unsigned)a.N);
   dim3 block((unsigned)(64 * W));
-  if (which == PG_ATTN_BWD) {
-    static const int bwd_dbg = []() { const char* e = getenv("PG_ATTN_BWD_DBG"); return e ? atoi(e) : 0; }();
-    a.kt = bwd_dbg;
-  }
   const void* fn = which == PG_ATTN_FWD  ? reinterpret_cast<const void*>(attn_fwd_m44_kernel)
-                   : which == PG_ATTN_BWD ? reinterpret_cast<const void*>(attn_bwd_m44_kernel)
+                   : which == PG_ATTN_BWD ? (a.lp == 848 ? reinterpret_cast<const void*>(attn_bwd_m44_kernel<848>)
+                                             : a.lp == 1040 ? reinterpret_cast<const void*>(attn_bwd_m44_kernel<1040>)
+                                                            : reinterpret_cast<const void*>(attn_bwd_m44_kernel<0>))
                    : which == PG_ATTN_DQ ? reinterpret_cast<const void*>(attn_dq_m44_kernel)
                    : dkv_bf16            ? reinterpret_cast<const void*>(attn_dkv_m44_kernel<true>)
                                          : reinterpret_cast<const void*>(attn_dkv_m44_kernel<false>);
   if (shmem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (which == PG_ATTN_FWD)
     hipLaunchKernelGGL(attn_fwd_m44_kernel, grid, block, shmem, st, a);
+  else if (which == PG_ATTN_BWD && a.lp == 848)
+    hipLaunchKernelGGL(attn_bwd_m44_kernel<848>, grid, block, shmem, st, a);
+  else if (which == PG_ATTN_BWD && a.lp == 1040)
+    hipLaunchKernelGGL(attn_bwd_m44_kernel<1040>, grid, block, shmem, st, a);
   else if (which == PG_ATTN_BWD)
-    hipLaunchKernelGGL(attn_bwd_m44_kernel, grid, block, shmem, st, a);
+    hipLaunchKernelGGL(attn_bwd_m44_kernel<0>, grid, block, shmem, st, a);
   else if (which == PG_ATTN_DQ)
     hipLaunchKernelGGL(attn_dq_m44_kernel, grid, block, shmem, st, a);
   else if (dkv_bf16)

@@ -112,6 +112,11 @@ class Conv2d(nn.Conv2d):
             if out_act is not None or in_post is not None:
                 raise ValueError("Conv2d: fused output activations are not available for stride 2")
             return self._forward_down2(x, in_act, res)
+        if (out_pre_scaled or in_post is not None) and not self.mfma_ok(x, crop):
+            # the two halves of a fused activation between two convolutions only exist on the matrix-core
+            # path; the caller must have checked mfma_ok() on BOTH convolutions (fail here, not in backward)
+            raise ValueError("Conv2d: out_pre_scaled / in_post need the matrix-core path for this shape "
+                             "(check mfma_ok first)")
         if out_act is not None and not out_pre_scaled and not self.mfma_ok(x, crop):
             # shapes the matrix-core path does not take: same result from separate kernels
             y = ops.conv2d_taps(x, self.weight, self.bias, self._conv_spec(), out_hw=crop,

@@ -259,6 +259,13 @@ class _ConvTaps(torch.autograd.Function):
         _, cout, oh, ow = dy.shape
         dx = dw = db = None
         fmt_t = _use_mfma(lib, cout, cin, spec, (ih, iw), ow) if need_dx else 0
+        # the producer of x skipped its activation derivative on the promise that THIS data gradient's
+        # epilogue applies it (out_pre_scaled / in_post protocol): only the matrix-core epilogue can
+        if in_post != ACT_NONE and ctx.in_act != ACT_NONE:
+            raise ValueError("conv2d: in_act and in_post cannot both be set (one epilogue derivative)")
+        if in_post != ACT_NONE and need_dx and not fmt_t:
+            raise RuntimeError("conv2d: in_post needs the matrix-core data gradient (shape not covered): "
+                               "the activation derivative of the producer would be dropped")
         if fmt_t:
             # matrix-core data gradient; act'(x) of a fused input activation in its epilogue (one
             # exp / erf per output element is noise next to the MFMA work of the tile)
