@@ -92,6 +92,18 @@ int pg_conv2d_mfma(const float* in, const float* wfrag, const float* bias, const
                    float* out, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
                    const int* tap_dr, const int* tap_dc, int in_act, const float* dact_src,
                    int dact, int out_act, int fmt, void* stream);
+/* The same with the full epilogue of the bf16x3 format:
+ *   out = out_act(conv + bias) * act'(dact_src) + res + res2
+ * (the derivative BEFORE the residuals). In a data gradient res / res2 are the pass-through gradients
+ * of skip connections on the convolution's input (autograd's gradient-sum `add` kernels, fused);
+ * res_bs / res2_bs: their batch strides in floats (0 = dense Cout * OH * OW), so that a residual may
+ * be a channel slice of a wider tensor (the slice of a concatenation's gradient). fmt = PG_CONV_FMT_F32
+ * accepts only res2 = NULL, dense res and not (res and dact_src) together. */
+int pg_conv2d_mfma_ex(const float* in, const float* wfrag, const float* bias, const float* res,
+                      float* out, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
+                      const int* tap_dr, const int* tap_dc, int in_act, const float* dact_src,
+                      int dact, int out_act, int fmt, const float* res2, long res_bs, long res2_bs,
+                      void* stream);
 /* Two arithmetic back ends share this entry point; they differ in the weight-fragment FORMAT:
  *   PG_CONV_FMT_F32: v_mfma_f32_16x16x4_f32 on fp32 fragments (csrc/conv_mfma.hip);
  *   PG_CONV_FMT_B3:  every fp32 product as six v_mfma_f32_16x16x32_bf16 on exact three-way bf16
@@ -370,6 +382,13 @@ int pg_vq_bwd(const float* x, const float* q, const float* d_st, const float* g_
 int pg_mse_fwd(const float* a, const float* b, float* loss, size_t n, void* stream);
 int pg_mse_bwd(const float* a, const float* b, const float* g_loss, float* da, float* db, size_t n,
                void* stream);
+
+/* dst[r * dst_stride + i] (+)= src[r * src_stride + i] for r < rows, i < row_len (strides in floats).
+ * The channel concatenation in front of a merged projection (nn/attention.py:139-143
+ * torch.cat((x, extra_x), dim=1): a row = the channels of one image) and the assembly / gradient split
+ * of that projection's merged weight. accumulate != 0 adds into dst. */
+int pg_copy_rows(const float* src, float* dst, long rows, long row_len, long src_stride,
+                 long dst_stride, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Data-parallel exchange step: replaces DistributedDataParallel's gradient

@@ -41,8 +41,10 @@ struct B3Args {
   const float* wfrag;
   const float* bias;
   const float* res;
+  const float* res2;      // second residual operand (data gradients with two pass-through gradients)
   const float* dact_src;
   float* out;
+  long res_bs, res2_bs;   // batch strides of res / res2 in floats (a channel slice of a wider tensor)
   int N, Cin, IH, IW, Cout, OH, OW, T;
   int TR, tiles_per_img, tile_h, tile_w, min_dr, min_dc;
   int CIB, cgs, groups, ksteps;   // channels per chunk, CIB / 8, cgs * T, ceil(groups / 4)
@@ -292,14 +294,16 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
     if (step + 2 < nsteps) PG_B3_ISSUE(step + 2)
     const bool last_chunk = (step + 1) % nchunk == 0;
     if (last_chunk && !(a.dbg & 8)) {
-      // ---- epilogue (as conv_mfma.hip): + bias, out_act, + res, * act'(dact_src); per-wave
-      // transposition scratch of its own (the tiles already hold the next step)
+      // ---- epilogue: v = out_act(acc + bias) * act'(dact_src) + res + res2; per-wave transposition
+      // scratch of its own (the tiles already hold the next step). The derivative comes BEFORE the
+      // residuals: in a data gradient res / res2 are pass-through gradients of the same tensor (skip
+      // connections), which the activation derivative of the convolution's own input does not touch.
       const int n_img = n_first + tl * nstep;
       const size_t so = so_rel + (size_t)n_img * a.Cout * L;
       float* ep = lds + a.ep_off + wave_all * (16 * EPS);
       const int cvalid = a.Cout - co0;
       float* outp = a.out + so;
-      const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
+      const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr, has_res2 = a.res2 != nullptr;
 #define PG_B3_TILE_BODY(M)                                                                       \
   _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
   _Pragma("unroll") for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[M][n][r]; \
@@ -327,8 +331,12 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
           PG_B3_TILE_STORE(m)
         }
       } else {
-        const float* op1 = (has_res ? a.res : a.dact_src) + so;
-        const float* op2 = (has_res && has_ds) ? a.dact_src + so : nullptr;
+        // first operand stream (the derivative's source if there is one, else res): requested for two
+        // tiles before any store; the remaining streams per tile
+        const float* res_p = has_res ? a.res + so_rel + (size_t)n_img * a.res_bs : nullptr;
+        const float* res2_p = has_res2 ? a.res2 + so_rel + (size_t)n_img * a.res2_bs : nullptr;
+        const float* op1 = has_ds ? a.dact_src + so : res_p;
+        const float* op2 = has_ds ? res_p : nullptr;  // res as a later stream only behind a derivative
         constexpr int MH = MT > 2 ? 2 : MT;
         float ov[MH][16];
         const int dsel = has_ds ? a.dact : PG_ACT_NONE;
@@ -344,39 +352,47 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
               }
           }
           PG_B3_TILE_BODY(m)
-          float sv[16];
-          if (has_res) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] += ov[m % MH][c];
-            if (op2) {
-#pragma unroll
-              for (int c = 0; c < 16; ++c) {
-                const int cc = m * 16 + c;
-                sv[c] = op2[(size_t)(cc < cvalid ? cc : 0) * L];
-              }
-            }
-          } else {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) sv[c] = ov[m % MH][c];
-          }
           switch (dsel) {
             case PG_ACT_RELU:
 #pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_RELU);
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m % MH][c], PG_ACT_RELU);
               break;
             case PG_ACT_ELU:
 #pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU);
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m % MH][c], PG_ACT_ELU);
               break;
             case PG_ACT_GELU:
 #pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m % MH][c], PG_ACT_GELU);
               break;
             case PG_ACT_ELU_OUT:
 #pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU_OUT);
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m % MH][c], PG_ACT_ELU_OUT);
               break;
-            default: break;
+            default:  // no derivative: the preloaded stream is res
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] += ov[m % MH][c];
+              break;
+          }
+          if (op2) {
+            float sv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              const int cc = m * 16 + c;
+              sv[c] = op2[(size_t)(cc < cvalid ? cc : 0) * L];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] += sv[c];
+          }
+          if (res2_p) {
+            float sv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              const int cc = m * 16 + c;
+              sv[c] = res2_p[(size_t)(cc < cvalid ? cc : 0) * L];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] += sv[c];
           }
           PG_B3_TILE_STORE(m)
         }
@@ -585,9 +601,13 @@ int pg_b3_pack2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout, 
 int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const float* res, float* out,
                int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
                const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
-               hipStream_t st) {
+               const float* res2, long res_bs, long res2_bs, hipStream_t st) {
   B3Args a;
   a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
+  PG_REQUIRE(res2 == nullptr || res != nullptr, PG_EINVAL, "pg_conv2d_mfma(bf16x3): res2 without res");
+  a.res2 = res2;
+  a.res_bs = res_bs > 0 ? res_bs : (long)Cout * OH * OW;
+  a.res2_bs = res2_bs > 0 ? res2_bs : (long)Cout * OH * OW;
   a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW; a.T = T;
   a.in_act = in_act; a.dact = dact; a.out_act = out_act;
   { const char* e = getenv("PG_B3_DBG"); a.dbg = e ? atoi(e) : 0; }

@@ -467,7 +467,7 @@ int pg_b3_pack2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout, 
 int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const float* res, float* out,
                int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
                const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
-               hipStream_t st);
+               const float* res2, long res_bs, long res2_bs, hipStream_t st);
 
 // The matrix-core path pays off once both channel extents fill MFMA tiles; tiny contractions
 // (the 1- / 3-channel image convolutions, 4-channel query projections) stay on conv_direct.hip.
@@ -541,6 +541,16 @@ PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* b
                              int Cout, int OH, int OW, int T, const int* tap_dr,
                              const int* tap_dc, int in_act, const float* dact_src, int dact,
                              int out_act, int fmt, void* stream) {
+  return pg_conv2d_mfma_ex(in, wfrag, bias, res, out, N, Cin, IH, IW, Cout, OH, OW, T, tap_dr, tap_dc, in_act,
+                           dact_src, dact, out_act, fmt, nullptr, 0, 0, stream);
+}
+
+PG_EXPORT int pg_conv2d_mfma_ex(const float* in, const float* wfrag, const float* bias,
+                                const float* res, float* out, int N, int Cin, int IH, int IW,
+                                int Cout, int OH, int OW, int T, const int* tap_dr,
+                                const int* tap_dc, int in_act, const float* dact_src, int dact,
+                                int out_act, int fmt, const float* res2, long res_bs, long res2_bs,
+                                void* stream) {
   PG_REQUIRE(in && wfrag && out && tap_dr && tap_dc, PG_EINVAL, "pg_conv2d_mfma: null pointer");
   PG_REQUIRE(fmt == PG_CONV_FMT_F32 || fmt == PG_CONV_FMT_B3, PG_EINVAL, "pg_conv2d_mfma: bad format %d", fmt);
   PG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, PG_EINVAL,
@@ -555,7 +565,11 @@ PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* b
   hipStream_t st = (hipStream_t)stream;
   if (fmt == PG_CONV_FMT_B3)
     return pg_b3_conv(in, wfrag, bias, res, out, N, Cin, IH, IW, Cout, OH, OW, T, tap_dr, tap_dc, in_act,
-                      dact_src, dact, out_act, st);
+                      dact_src, dact, out_act, res2, res_bs, res2_bs, st);
+  PG_REQUIRE(res2 == nullptr && (res_bs == 0 || res_bs == (long)Cout * OH * OW), PG_ESHAPE,
+             "pg_conv2d_mfma_ex: a second / strided residual needs the bf16x3 format");
+  PG_REQUIRE(!(res && dact_src), PG_ESHAPE,
+             "pg_conv2d_mfma_ex: residual + activation derivative together need the bf16x3 format");
   MfArgs a;
   a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
   a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW; a.T = T;

@@ -465,3 +465,50 @@ PG_EXPORT int pg_bce_logits_bwd(const float* z, const float* x, const float* gsc
   PG_LAUNCH_CHECK("pg_bce_logits_bwd");
   return 0;
 }
+
+// ---- strided row copy ---------------------------------------------------------------------------
+// dst[r * dst_stride + i] (+)= src[r * src_stride + i], r < rows, i < row_len. One kernel for the
+// channel concatenation in front of PixelSNAIL's merged [q | k | v] projection (reference
+// nn/attention.py:139-143: torch.cat((x, extra_x), dim=1); a row = the channels of one image) and for
+// assembling / splitting that projection's merged weight (rows of different widths).
+namespace {
+__global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows,
+                                 long row_len, long src_stride, long dst_stride, int accumulate, int vec) {
+  const long per = vec ? row_len / 4 : row_len;
+  const long total = rows * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / per, c = i - r * per;
+    if (vec) {
+      const float4 v = *reinterpret_cast<const float4*>(src + r * src_stride + 4 * c);
+      float4* d = reinterpret_cast<float4*>(dst + r * dst_stride + 4 * c);
+      if (accumulate) {
+        const float4 o = *d;
+        *d = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+      } else {
+        *d = v;
+      }
+    } else {
+      float* d = dst + r * dst_stride + c;
+      *d = accumulate ? *d + src[r * src_stride + c] : src[r * src_stride + c];
+    }
+  }
+}
+}  // namespace
+
+PG_EXPORT int pg_copy_rows(const float* src, float* dst, long rows, long row_len, long src_stride,
+                           long dst_stride, int accumulate, void* stream) {
+  PG_REQUIRE(src && dst, PG_EINVAL, "pg_copy_rows: null pointer");
+  PG_REQUIRE(rows >= 0 && row_len >= 0 && src_stride >= row_len && dst_stride >= row_len, PG_EINVAL,
+             "pg_copy_rows: bad extents");
+  if (rows == 0 || row_len == 0) return 0;
+  const int vec = (row_len % 4 == 0 && src_stride % 4 == 0 && dst_stride % 4 == 0 &&
+                   (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) ? 1 : 0;
+  const long total = rows * (vec ? row_len / 4 : row_len);
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     rows, row_len, src_stride, dst_stride, accumulate, vec);
+  PG_LAUNCH_CHECK("pg_copy_rows");
+  return 0;
+}
+

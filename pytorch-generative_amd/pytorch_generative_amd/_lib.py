@@ -35,6 +35,11 @@ SIGNATURES = {
         [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_f, c_i,
          c_i, c_i, c_s],
     ),
+    "pg_conv2d_mfma_ex": (
+        c_i,
+        [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_f, c_i,
+         c_i, c_i, c_f, c_l, c_l, c_s],
+    ),
     "pg_conv_mfma_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "pg_conv_frag_floats": (c_z, [c_i, c_i, c_i, c_i]),
     "pg_pack_conv_weight_frag": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_i, c_s]),
@@ -116,6 +121,7 @@ SIGNATURES = {
     "pg_adam_prepare": (c_i, [c_f, c_s]),
     "pg_adam_step": (c_i, [c_f, c_f, c_f, c_f, c_z, c_f, c_flt, c_flt, c_flt, c_s]),
     "pg_attn_fused_bwd": (c_i, [c_i]),
+    "pg_copy_rows": (c_i, [c_f, c_f, c_l, c_l, c_l, c_l, c_i, c_s]),
     "pg_comm_unique_id": (c_i, [ctypes.c_char_p]),
     "pg_comm_init": (c_i, [c_i, c_i, ctypes.c_char_p]),
     "pg_comm_world": (c_i, []),

@@ -14,9 +14,9 @@ from pytorch_generative_amd import ops
 from pytorch_generative_amd.models import base
 
 
-def _elu_conv_elu(conv, x, res=None):
+def _elu_conv_elu(conv, x, res=None, n_skip=0):
     """elu(conv(elu(x))) (+ res): both activations and the add are fused into the convolution."""
-    return conv(x, in_act="elu", out_act="elu", res=res)
+    return conv(x, in_act="elu", out_act="elu", res=res, n_skip=n_skip)
 
 
 class ResidualBlock(nn.Module):
@@ -32,18 +32,24 @@ class ResidualBlock(nn.Module):
         )
         self._activation = pg_nn.GatedActivation(activation_fn=nn.Identity())
 
-    def forward(self, x):
+    def forward(self, x, extra_skip=False):
+        """extra_skip=True (extension) also returns one more pass-through alias of x (for the block's
+        final residual): x then has a single autograd consumer — the first convolution — whose data
+        gradient adds the skip gradients in its epilogue."""
         _, _, h, w = x.shape
+        k = 2 if extra_skip else 1
         # reference: elu(conv(elu(x)))[:, :, :h, :w] -> conv[:, :, :h, :w] -> gate -> + x
         if self._input_conv.mfma_ok(x, (h, w)) and self._output_conv.mfma_ok(x, (h, w)):
             # the inner ELU lives in the first convolution's epilogue; its derivative (from the
             # stored output) in the second convolution's data-gradient epilogue
-            out = self._input_conv(x, crop=(h, w), in_act="elu", out_act="elu", out_pre_scaled=True)
+            out, *xs = self._input_conv(x, crop=(h, w), in_act="elu", out_act="elu", out_pre_scaled=True,
+                                        n_skip=k)
             out = self._output_conv(out, crop=(h, w), in_post="elu")
         else:
-            out = self._input_conv(x, crop=(h, w), in_act="elu")
+            out, *xs = self._input_conv(x, crop=(h, w), in_act="elu", n_skip=k)
             out = self._output_conv(out, crop=(h, w), in_act="elu")
-        return self._activation(out, res=x)
+        y = self._activation(out, res=xs[0])
+        return (y, xs[1]) if extra_skip else y
 
 
 class PixelSNAILBlock(nn.Module):
@@ -77,12 +83,23 @@ class PixelSNAILBlock(nn.Module):
     def forward(self, x, input_img, *, add_input=False):
         """add_input=True (extension) returns x + block(x): the model loop's residual
         (pixel_snail.py:186) fused into the block's last convolution."""
-        res = self._residual(x)
+        # every tensor with several readers goes through the FIRST reader's convolution with pass-through
+        # aliases for the others: no gradient-sum kernels in backward (ops.conv2d_taps, n_skip)
+        blocks = list(self._residual)
+        x_skip = None
+        res = x
+        for i, rb in enumerate(blocks):
+            if i == 0 and add_input:
+                res, x_skip = rb(res, extra_skip=True)
+            else:
+                res = rb(res)
+        if add_input and x_skip is None:
+            x_skip = x
+        r_out, res_skip = _elu_conv_elu(self._residual_out, res, n_skip=1)
         pos = pg_nn.image_positional_encoding(input_img.shape, res.device)
-        attn = self._attention((pos, res), input_img)  # cat(pos, res[, img]) happens inside, once
-        res = _elu_conv_elu(self._residual_out, res)
-        both = _elu_conv_elu(self._attention_out, attn, res=res)  # elu(conv(elu(attn))) + res
-        return _elu_conv_elu(self._out, both, res=x if add_input else None)
+        attn = self._attention((pos, res_skip), input_img)  # cat(pos, res[, img]) happens inside, once
+        both = _elu_conv_elu(self._attention_out, attn, res=r_out)  # elu(conv(elu(attn))) + res
+        return _elu_conv_elu(self._out, both, res=x_skip if add_input else None)
 
 
 class PixelSNAIL(base.AutoregressiveModel):

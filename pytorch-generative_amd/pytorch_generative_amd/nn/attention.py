@@ -103,12 +103,9 @@ class CausalAttention(nn.Module):
             # [q | k | v] in one tensor — one concatenation, one projection, one data gradient and
             # one weight gradient instead of two each plus the sum of the two input gradients.
             # The parameters keep the reference's shapes; the merged weight is rebuilt per step
-            # (40 x 69 values for PixelSNAIL) and its gradient flows back through the cat / pad.
-            x_all = torch.cat(parts + [extra_x], dim=1)
-            cin_q, cin_kv = self._q.weight.shape[1], self._kv.weight.shape[1]
-            wq = torch.nn.functional.pad(self._q.weight.flatten(1), (0, cin_kv - cin_q))
-            w = torch.cat((wq, self._kv.weight.flatten(1)), dim=0).view(-1, cin_kv, 1, 1)
-            b = torch.cat((self._q.bias, self._kv.bias))
+            # (40 x 69 values for PixelSNAIL) and its gradient is split back row block by row block.
+            x_all = ops.concat_channels(parts + [extra_x])  # HIP copy; its backward hands out slice views
+            w, b = ops.merge_qkv_weight(self._q, self._kv)  # gradients go straight into the parameters' sinks
             qkv = ops.conv2d_taps(x_all, w, b, self._kv._conv_spec())
             out = ops.causal_attention_qkv(
                 qkv, self._n_heads, self._embed_channels, self._out_channels, self._mask_center

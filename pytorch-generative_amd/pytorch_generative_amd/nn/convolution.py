@@ -104,7 +104,15 @@ class Conv2d(nn.Conv2d):
         return y
 
     def forward(self, x, *, crop=None, in_act=None, res=None, out_act=None, out_pre_scaled=False,
-                in_post=None):
+                in_post=None, n_skip=0):
+        """n_skip > 0 (extension) returns (y, x_1, .., x_n): pass-through aliases of x for the skip
+        connections that also read x, see ops.conv2d_taps."""
+        if n_skip:
+            ctx = ops.RowDecode.current
+            if ctx is not None or self._down2 or not x.requires_grad:
+                y = self.forward(x, crop=crop, in_act=in_act, res=res, out_act=out_act,
+                                 out_pre_scaled=out_pre_scaled, in_post=in_post)
+                return (y,) + (x,) * n_skip
         ctx = ops.RowDecode.current
         if ctx is not None:
             return self._row_forward(ctx, x, crop, in_act, res, out_act)
@@ -122,11 +130,12 @@ class Conv2d(nn.Conv2d):
             y = ops.conv2d_taps(x, self.weight, self.bias, self._conv_spec(), out_hw=crop,
                                 in_act=_ACTS[in_act], weight_param=self.weight, bias_param=self.bias)
             y = ops._Act.apply(y, _ACTS[out_act])
-            return y if res is None else ops.add(y, res)
+            y = y if res is None else ops.add(y, res)
+            return (y,) + (x,) * n_skip if n_skip else y
         return ops.conv2d_taps(
             x, self.weight, self.bias, self._conv_spec(), out_hw=crop, in_act=_ACTS[in_act],
             res=res, weight_param=self.weight, bias_param=self.bias, out_act=_ACTS[out_act],
-            out_pre_scaled=out_pre_scaled, in_post=_ACTS[in_post],
+            out_pre_scaled=out_pre_scaled, in_post=_ACTS[in_post], n_skip=n_skip,
         )
 
     def _forward_down2(self, x, in_act, res):

@@ -179,7 +179,7 @@ def _pack(lib, weight, spec, transpose):
 class _ConvTaps(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, res, spec, out_hw, in_act, gw, gb, out_act=ACT_NONE,
-                out_pre_scaled=False, in_post=ACT_NONE):
+                out_pre_scaled=False, in_post=ACT_NONE, n_skip=0):
         lib = _lib.load()
         x = _chk(x, "conv2d.x")
         weight = _chk(weight, "conv2d.weight")
@@ -232,15 +232,21 @@ class _ConvTaps(torch.autograd.Function):
         ctx.spec, ctx.in_act, ctx.has_bias, ctx.has_res = spec, in_act, bias is not None, res is not None
         ctx.gw, ctx.gb = gw, gb
         ctx.out_act, ctx.out_pre_scaled, ctx.in_post = out_act, out_pre_scaled, in_post
+        ctx.n_skip = n_skip
+        if n_skip:
+            # pass-through aliases of x for skip connections: their consumers' gradients come back to THIS
+            # node's backward and are added in the data gradient's epilogue (no gradient-sum kernel)
+            return (out,) + tuple(x.view_as(x) for _ in range(n_skip))
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *d_skips):
         need = ctx.needs_input_grad
-        return _ConvTaps.backward_impl(ctx, dy, need[0], need[1], ctx.has_bias and need[2]) + (None, None, None)
+        return _ConvTaps.backward_impl(ctx, dy, need[0], need[1], ctx.has_bias and need[2],
+                                       d_skips=d_skips) + (None, None, None, None)
 
     @staticmethod
-    def backward_impl(ctx, dy, need_dx, need_w, need_b):
+    def backward_impl(ctx, dy, need_dx, need_w, need_b, d_skips=()):
         lib = _lib.load()
         x, weight = ctx.saved_tensors[:2]
         spec = ctx.spec
@@ -275,14 +281,28 @@ class _ConvTaps(torch.autograd.Function):
             dx = torch.empty_like(x)
             dact = ctx.in_act if ctx.in_act != ACT_NONE else (ACT_ELU_OUT if in_post == ACT_ELU else ACT_NONE)
             fuse = dact != ACT_NONE
+            # pass-through gradients of skip connections on x: up to two ride in the epilogue of the
+            # bf16x3 kernel (dx = dgrad * act' + skip1 + skip2); a skip may be a channel slice of a wider
+            # gradient (batch-strided)
+            skips = [g for g in d_skips if g is not None]
+            fused_skips = []
+            if fmt_t == CONV_FMT_B3:
+                while skips and len(fused_skips) < 2:
+                    g = skips.pop(0)
+                    fused_skips.append(g if _dense_per_image(g) else _chk(g, "conv2d.d_skip"))
+            r1 = fused_skips[0] if fused_skips else None
+            r2 = fused_skips[1] if len(fused_skips) > 1 else None
             _lib.check(
-                lib.pg_conv2d_mfma(
-                    dy.data_ptr(), wfrag_t.data_ptr(), 0, 0, dx.data_ptr(), n, cout, oh, ow, cin,
+                lib.pg_conv2d_mfma_ex(
+                    dy.data_ptr(), wfrag_t.data_ptr(), 0, _p(r1), dx.data_ptr(), n, cout, oh, ow, cin,
                     ih, iw, len(spec.fwd_taps), spec.f_ndr, spec.f_ndc, ACT_NONE,
-                    x.data_ptr() if fuse else 0, dact, ACT_NONE, fmt_t, _stream(),
+                    x.data_ptr() if fuse else 0, dact, ACT_NONE, fmt_t, _p(r2),
+                    r1.stride(0) if r1 is not None else 0, r2.stride(0) if r2 is not None else 0, _stream(),
                 ),
                 "pg_conv2d_mfma(dgrad)",
             )
+            for g in skips:  # more than two, or not the bf16x3 format
+                dx = add(dx, _chk(g, "conv2d.d_skip"))
         elif need_dx:
             wpk_t = _pack(lib, weight, spec, transpose=True)
             dx = torch.empty_like(x)
@@ -304,6 +324,9 @@ class _ConvTaps(torch.autograd.Function):
                                    ctx.in_act, _stream()),
                     "pg_act_bwd",
                 )
+            for g in d_skips:
+                if g is not None:
+                    dx = add(dx, _chk(g, "conv2d.d_skip"))
         if need_w or need_b:
             gw, gb = ctx.gw, ctx.gb
             if gw is None:
@@ -329,7 +352,22 @@ class _ConvTaps(torch.autograd.Function):
                 ),
                 "pg_conv2d_wgrad",
             )
+        if not need_dx and any(g is not None for g in d_skips):
+            raise RuntimeError("conv2d: skip outputs of an input that needs no gradient received gradients")
         return dx, dw, db, dres, None, None, None, None, None
+
+
+CONV_FMT_F32, CONV_FMT_B3 = 1, 2  # include/pg_hip.h PG_CONV_FMT_*
+
+
+def _dense_per_image(t):
+    """True if every image of the (N, C, H, W) tensor is a dense (C, H, W) block and the data is fp32 on
+    the GPU: the batch stride may be larger than C*H*W (a channel slice of a wider tensor)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
+        return False
+    _, c, h, w = t.shape
+    st = t.stride()
+    return st[3] == 1 and st[2] == w and st[1] == h * w and st[0] >= c * h * w and t.data_ptr() % 16 == 0
 
 
 # A/B switches for measurements (PG_FUSE_PAIR=0 / PG_FUSE_LNSKIP=0 select the unfused graphs)
@@ -412,13 +450,18 @@ def conv_mfma_ok(x, weight, spec, out_hw=None):
 
 def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
                 weight_param=None, bias_param=None, out_act=ACT_NONE, out_pre_scaled=False,
-                in_post=ACT_NONE):
+                in_post=ACT_NONE, n_skip=0):
     """y = out_act(conv(in_act(x)) + bias) (+ res), cropped to out_hw (defaults to the full extent).
 
     out_act (matrix-core path only): activation fused into the epilogue; its backward recovers act'
     from the output (ELU / ReLU). out_pre_scaled=True declares that the ONLY consumer of y hands back
     a gradient already multiplied by act'(y) — the consumer is a convolution called with
-    in_post=<that activation>, which applies the factor in its data-gradient epilogue."""
+    in_post=<that activation>, which applies the factor in its data-gradient epilogue.
+
+    n_skip > 0 returns (y, x_1, ..., x_n): pass-through aliases of x for the skip connections that also
+    read x (residual adds, later concatenations). Using them instead of x makes this op x's ONLY consumer,
+    so autograd never sums gradients for x: the skip gradients arrive in this op's backward and are added
+    in the data-gradient kernel's epilogue."""
     if out_hw is None:
         out_hw = spec.full_out(x.shape[2], x.shape[3])
     # outputs beyond the "full" extent read only zero padding; allow up to one kernel's worth
@@ -428,7 +471,7 @@ def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
         raise ValueError(f"conv2d: requested output {out_hw} exceeds the full extent {full}")
     return _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act,
                            _sink(weight_param), _sink(bias_param), out_act, bool(out_pre_scaled),
-                           in_post)
+                           in_post, int(n_skip))
 
 
 # --------------------------------------------------------------------------------------------
@@ -821,6 +864,92 @@ class _CausalAttentionQKV(torch.autograd.Function):
             "pg_causal_attn_bwd",
         )
         return dqkv, None, None, None, None
+
+
+class _ConcatChannels(torch.autograd.Function):
+    """torch.cat(tensors, dim=1) of (N, C_i, H, W) tensors on pg_copy_rows; the gradients handed back are
+    channel-slice VIEWS of the incoming gradient (no copies): the convolution they flow into adds them in
+    its data-gradient epilogue (n_skip protocol) or reads them with their batch stride."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        lib = _lib.load()
+        parts = [_chk(t, "concat.part") for t in tensors]
+        n, _, h, w = parts[0].shape
+        L = h * w
+        ctot = sum(int(t.shape[1]) for t in parts)
+        out = torch.empty((n, ctot, h, w), device=parts[0].device, dtype=torch.float32)
+        off = 0
+        for t in parts:
+            if tuple(t.shape[0:1] + t.shape[2:]) != (n, h, w):
+                raise ValueError("concat_channels: batch / spatial shape mismatch")
+            c = int(t.shape[1])
+            _lib.check(lib.pg_copy_rows(t.data_ptr(), out.data_ptr() + 4 * off * L, n, c * L, c * L, ctot * L, 0,
+                                        _stream()), "pg_copy_rows")
+            off += c
+        ctx.sizes = [int(t.shape[1]) for t in parts]
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        grads, off = [], 0
+        for i, c in enumerate(ctx.sizes):
+            grads.append(dy.narrow(1, off, c) if ctx.needs_input_grad[i] else None)
+            off += c
+        return tuple(grads)
+
+
+def concat_channels(tensors):
+    return _ConcatChannels.apply(*tensors)
+
+
+class _MergeQKVWeight(torch.autograd.Function):
+    """Merged weight / bias of the [q | k | v] projection over cat(x, extra_x) (nn/attention.py:139-143):
+    q's rows (E, Cq) zero-padded to Ckv columns on top of kv's rows (E + V, Ckv). Backward adds the two
+    row blocks of the merged gradient straight into the parameters' gradient sinks (or returns them)."""
+
+    @staticmethod
+    def forward(ctx, wq, bq, wkv, bkv, sinks):
+        lib = _lib.load()
+        eq, cq = int(wq.shape[0]), int(wq.shape[1])
+        ekv, ckv = int(wkv.shape[0]), int(wkv.shape[1])
+        w = torch.zeros((eq + ekv, ckv, 1, 1), device=wq.device, dtype=torch.float32)
+        b = torch.empty(eq + ekv, device=wq.device, dtype=torch.float32)
+        st = _stream()
+        _lib.check(lib.pg_copy_rows(wq.data_ptr(), w.data_ptr(), eq, cq, cq, ckv, 0, st), "pg_copy_rows")
+        _lib.check(lib.pg_copy_rows(wkv.data_ptr(), w.data_ptr() + 4 * eq * ckv, 1, ekv * ckv, ekv * ckv,
+                                    ekv * ckv, 0, st), "pg_copy_rows")
+        _lib.check(lib.pg_copy_rows(bq.data_ptr(), b.data_ptr(), 1, eq, eq, eq, 0, st), "pg_copy_rows")
+        _lib.check(lib.pg_copy_rows(bkv.data_ptr(), b.data_ptr() + 4 * eq, 1, ekv, ekv, ekv, 0, st), "pg_copy_rows")
+        ctx.dims, ctx.sinks = (eq, cq, ekv, ckv), sinks
+        return w, b
+
+    @staticmethod
+    def backward(ctx, dw, db):
+        lib = _lib.load()
+        eq, cq, ekv, ckv = ctx.dims
+        dw, db = _chk(dw, "qkv.dw"), _chk(db, "qkv.db")
+        st = _stream()
+        outs = []
+        for i, (src, rows, rl, sstride) in enumerate((
+                (dw.data_ptr(), eq, cq, ckv), (db.data_ptr(), 1, eq, eq),
+                (dw.data_ptr() + 4 * eq * ckv, 1, ekv * ckv, ekv * ckv), (db.data_ptr() + 4 * eq, 1, ekv, ekv))):
+            sink = ctx.sinks[i]
+            if sink is not None:  # accumulate into the flat gradient buffer (FlatAdam protocol)
+                _lib.check(lib.pg_copy_rows(src, sink.data_ptr(), rows, rl, sstride, rl, 1, st), "pg_copy_rows")
+                outs.append(None)
+            else:
+                g = torch.empty(rows * rl, device=dw.device, dtype=torch.float32)
+                _lib.check(lib.pg_copy_rows(src, g.data_ptr(), rows, rl, sstride, rl, 0, st), "pg_copy_rows")
+                outs.append(g)
+        gwq, gbq, gwkv, gbkv = outs
+        return (None if gwq is None else gwq.view(eq, cq, 1, 1), gbq,
+                None if gwkv is None else gwkv.view(ekv, ckv, 1, 1), gbkv, None)
+
+
+def merge_qkv_weight(q_conv, kv_conv):
+    sinks = (_sink(q_conv.weight), _sink(q_conv.bias), _sink(kv_conv.weight), _sink(kv_conv.bias))
+    return _MergeQKVWeight.apply(q_conv.weight, q_conv.bias, kv_conv.weight, kv_conv.bias, sinks)
 
 
 def set_deterministic(on=True):
