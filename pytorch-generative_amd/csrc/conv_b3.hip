@@ -113,7 +113,10 @@ __device__ __forceinline__ void split8t(const float (&x)[8], u32x4& h, u32x4& m,
 // 128 -> 256 59 -> 56 us; GatedPixelCNN 4.27 -> 4.54 k img/s at batch 512. Both halves of a gate input
 // also meet in one workgroup. (A float4 "vector epilogue" variant was measured in the same call and
 // dropped: 136.6 vs 133 us on the 2x2 64 -> 64, slower combined with CG = 2 — it spilled registers.)
-template <int MT, int NT, int CG>
+// MS ("multi-stream epilogue"): v * act'(dact_src) + res + res2 with pipelined operand requests — its
+// own instantiation, because the three operand buffers cost registers that the common kernels (at 256
+// already) must not pay: with the code shared, the plain forward launch went from 136 to 185 us.
+template <int MT, int NT, int CG, bool MS = false>
 __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kernel(const B3Args a) {
   constexpr int THREADS = B3_THREADS * CG;
   constexpr int XS = CG == 1 ? B3_XS : (B3_XS + 1) / 2;  // the tile's slots over twice the threads
@@ -331,12 +334,78 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
           PG_B3_TILE_STORE(m)
         }
       } else {
-        // first operand stream (the derivative's source if there is one, else res): requested for two
-        // tiles before any store; the remaining streams per tile
-        const float* res_p = has_res ? a.res + so_rel + (size_t)n_img * a.res_bs : nullptr;
-        const float* res2_p = has_res2 ? a.res2 + so_rel + (size_t)n_img * a.res2_bs : nullptr;
-        const float* op1 = has_ds ? a.dact_src + so : res_p;
-        const float* op2 = has_ds ? res_p : nullptr;  // res as a later stream only behind a derivative
+        if constexpr (MS) {
+        // Up to three operand streams (derivative source, res, res2). Loads and stores share vmcnt and
+        // retire in order, so a load issued behind a tile's stores waits for them: the operands of tile
+        // m + 1 are therefore requested BEFORE the stores of tile m (single buffer: right after tile
+        // m's values have been used); the wait in front of their use then covers the loads only.
+        const float* st0 = has_ds ? a.dact_src + so : nullptr;
+        const float* st1 = has_res ? a.res + so_rel + (size_t)n_img * a.res_bs : nullptr;
+        const float* st2 = has_res2 ? a.res2 + so_rel + (size_t)n_img * a.res2_bs : nullptr;
+        const int dsel = has_ds ? a.dact : PG_ACT_NONE;
+        // half tiles (8 channels) at a time: 24 operand registers instead of 48 (the kernel is at its
+        // register limit; with whole-tile buffers this instantiation spilled 33 dwords)
+        float o0[8], o1[8], o2[8];
+#define PG_B3_REQUEST(M, H)                                                                \
+  _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                          \
+    const int cc = (M) * 16 + (H) * 8 + c;                                                 \
+    const size_t off_ = (size_t)(cc < cvalid ? cc : 0) * L;                                \
+    if (st0) o0[c] = st0[off_];                                                            \
+    if (st1) o1[c] = st1[off_];                                                            \
+    if (st2) o2[c] = st2[off_];                                                            \
+  }
+        PG_B3_REQUEST(0, 0)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          PG_B3_TILE_BODY(m)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            switch (dsel) {
+              case PG_ACT_RELU:
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_RELU);
+                break;
+              case PG_ACT_ELU:
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_ELU);
+                break;
+              case PG_ACT_GELU:
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_GELU);
+                break;
+              case PG_ACT_ELU_OUT:
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_ELU_OUT);
+                break;
+              default: break;
+            }
+            if (st1) {
+#pragma unroll
+              for (int c = 0; c < 8; ++c) v[hh * 8 + c] += o1[c];
+            }
+            if (st2) {
+#pragma unroll
+              for (int c = 0; c < 8; ++c) v[hh * 8 + c] += o2[c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (hh == 0) { PG_B3_REQUEST(m, 1) }
+            else if (m + 1 < MT) { PG_B3_REQUEST(m + 1, 0) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (sok) {
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                const int cc = m * 16 + hh * 8 + c;
+                if (cc < cvalid) outp[(size_t)cc * L] = v[hh * 8 + c];
+              }
+            }
+          }
+        }
+#undef PG_B3_REQUEST
+        } else {
+          // one or two operand streams as measured in round 2: the first one requested for two tiles
+          // before any store, a derivative source behind a residual per tile (res + res -> * act')
+        const float* op1 = (has_res ? a.res : a.dact_src) + so;
+        const float* op2 = (has_res && has_ds) ? a.dact_src + so : nullptr;
         constexpr int MH = MT > 2 ? 2 : MT;
         float ov[MH][16];
         const int dsel = has_ds ? a.dact : PG_ACT_NONE;
@@ -352,49 +421,42 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
               }
           }
           PG_B3_TILE_BODY(m)
+          float sv[16];
+          if (has_res) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] += ov[m % MH][c];
+            if (op2) {
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                const int cc = m * 16 + c;
+                sv[c] = op2[(size_t)(cc < cvalid ? cc : 0) * L];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sv[c] = ov[m % MH][c];
+          }
           switch (dsel) {
             case PG_ACT_RELU:
 #pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m % MH][c], PG_ACT_RELU);
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_RELU);
               break;
             case PG_ACT_ELU:
 #pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m % MH][c], PG_ACT_ELU);
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU);
               break;
             case PG_ACT_GELU:
 #pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m % MH][c], PG_ACT_GELU);
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
               break;
             case PG_ACT_ELU_OUT:
 #pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(ov[m % MH][c], PG_ACT_ELU_OUT);
+              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU_OUT);
               break;
-            default:  // no derivative: the preloaded stream is res
-#pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] += ov[m % MH][c];
-              break;
-          }
-          if (op2) {
-            float sv[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-              const int cc = m * 16 + c;
-              sv[c] = op2[(size_t)(cc < cvalid ? cc : 0) * L];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] += sv[c];
-          }
-          if (res2_p) {
-            float sv[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-              const int cc = m * 16 + c;
-              sv[c] = res2_p[(size_t)(cc < cvalid ? cc : 0) * L];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] += sv[c];
+            default: break;
           }
           PG_B3_TILE_STORE(m)
+        }
         }
       }
 #undef PG_B3_TILE_BODY
@@ -518,17 +580,17 @@ int b3_rows(int T, int OH, int OW, int hr, int hc) {
   return (OH + nt_rows - 1) / nt_rows;
 }
 
-template <int MT, int CG = 1>
+template <int MT, int CG = 1, bool MS = false>
 void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
   // the LDS opt-in is set once per instantiation by a function-local static initialiser: thread-safe
   // (the library is entered from the main thread and from the autograd thread)
 #define PG_B3_L(NTV)                                                                                  \
   {                                                                                                   \
     static const hipError_t attr_##NTV = hipFuncSetAttribute(                                         \
-        reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV, CG>),                                   \
+        reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV, CG, MS>),                               \
         hipFuncAttributeMaxDynamicSharedMemorySize, CG == 1 ? 80 * 1024 : 160 * 1024);                \
     (void)attr_##NTV;                                                                                 \
-    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV, CG>), grid, dim3(B3_THREADS * CG), shmem, st, a);     \
+    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV, CG, MS>), grid, dim3(B3_THREADS * CG), shmem, st, a); \
   }
   switch (nt) {
     case 1: PG_B3_L(1) break;
@@ -648,9 +710,20 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   long gx = (want / a.tiles_per_img) * a.tiles_per_img;
   if (gx > (long)N * a.tiles_per_img) gx = (long)N * a.tiles_per_img;
   dim3 grid((unsigned)gx, (unsigned)chunks_y);
+  // multi-stream epilogue (two residuals, residual + derivative, batch-strided residual): own instantiations
+  const bool ms = res2 != nullptr || (res != nullptr && dact_src != nullptr) ||
+                  (res != nullptr && a.res_bs != (long)Cout * OH * OW);
+  PG_REQUIRE(!ms || pl.MT == 4, PG_ESHAPE,
+             "pg_conv2d_mfma_ex(bf16x3): the multi-stream epilogue is instantiated for >= 64 output channels");
   if (CG == 2) {
-    b3_launch<4, 2>(a, nt, grid, shmem, st);
+    if (ms) b3_launch<4, 2, true>(a, nt, grid, shmem, st);
+    else b3_launch<4, 2>(a, nt, grid, shmem, st);
     PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, wide)");
+    return 0;
+  }
+  if (ms) {
+    b3_launch<4, 1, true>(a, nt, grid, shmem, st);
+    PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, multi-stream epilogue)");
     return 0;
   }
   switch (pl.MT) {

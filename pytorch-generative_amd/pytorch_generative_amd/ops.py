@@ -286,7 +286,7 @@ class _ConvTaps(torch.autograd.Function):
             # gradient (batch-strided)
             skips = [g for g in d_skips if g is not None]
             fused_skips = []
-            if fmt_t == CONV_FMT_B3:
+            if fmt_t == CONV_FMT_B3 and cin >= 64:  # the multi-stream epilogue exists for >= 64 output channels
                 while skips and len(fused_skips) < 2:
                     g = skips.pop(0)
                     fused_skips.append(g if _dense_per_image(g) else _chk(g, "conv2d.d_skip"))
@@ -358,6 +358,7 @@ class _ConvTaps(torch.autograd.Function):
 
 
 CONV_FMT_F32, CONV_FMT_B3 = 1, 2  # include/pg_hip.h PG_CONV_FMT_*
+FUSE_SKIP = os.environ.get("PG_FUSE_SKIP", "1") != "0"  # A/B: 0 = plain fan-out, autograd sums the gradients
 
 
 def _dense_per_image(t):
@@ -469,6 +470,10 @@ def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
     full = spec.full_out(x.shape[2], x.shape[3])
     if out_hw[0] > full[0] + spec.kh or out_hw[1] > full[1] + spec.kw or min(out_hw) < 1:
         raise ValueError(f"conv2d: requested output {out_hw} exceeds the full extent {full}")
+    if n_skip and not FUSE_SKIP:
+        y = _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act, _sink(weight_param),
+                            _sink(bias_param), out_act, bool(out_pre_scaled), in_post, 0)
+        return (y,) + (x,) * int(n_skip)
     return _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act,
                            _sink(weight_param), _sink(bias_param), out_act, bool(out_pre_scaled),
                            in_post, int(n_skip))
