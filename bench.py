@@ -65,6 +65,10 @@ WORKLOADS = {
                                                n_attention_heads=4, n_embedding_channels=16),
                       chw=(1, 28, 28), lr=5e-3, decay=0.999977, gflop=1.223, mbytes=26.2,
                       gflop_causal=_causal_gflop_per_img(1.223, 1.10, 4, 784, 4, 4, 8, False)),
+    # the reference's own reproduce() hyper-parameters (image_gpt.py:147-154): 64 embed / 2 heads -> d = 32
+    "image_gpt_repro": dict(ctor="ImageGPT", kw=dict(in_channels=1, out_channels=1, in_size=28, n_transformer_blocks=8,
+                                                     n_attention_heads=2, n_embedding_channels=64),
+                            chw=(1, 28, 28), lr=5e-3, decay=0.999977, gflop=0.0, mbytes=0.0),
     "pixel_snail": dict(ctor="PixelSNAIL", kw=dict(in_channels=3, out_channels=3, n_channels=64,
                                                    n_pixel_snail_blocks=8, n_residual_blocks=2,
                                                    attention_key_channels=4, attention_value_channels=32),

@@ -1,5 +1,9 @@
-// attention_k4.hip — causal attention core for d_k = 4, d_v = 16*DVT (PixelSNAIL: 1 head, d_k 4,
-// d_v 32, strict mask, L = 1024) on the fp32 matrix cores, gfx950.
+// attention_k4.hip — causal attention core for d_k = 4*DKT, d_v = 16*DVT on the fp32 matrix cores,
+// gfx950: PixelSNAIL (1 head, d_k 4, d_v 32, strict mask, L = 1024) and, since round 3, ImageGPT at the
+// reference's reproduce() shape (image_gpt.py:147-154: 64 embedding channels / 2 heads -> d_k = d_v =
+// 32, L = 784). For d_k >= 16 the score tile is a chain of DKT MFMAs over the channel quads and dQ / dK
+// are MFMA accumulations like P.V / dV; for d_k = 4 they stay on the VALU (M = 4 would waste 75 % of a
+// tile). L must be a multiple of 16; a wave's last 16-row groups may lie beyond L (skipped).
 //
 // Replaces the body of CausalAttention.forward after the projections (reference
 // nn/attention.py:147-160: q k^T / sqrt(d_k), masked_fill, softmax, masked_fill(0), @ v) as
@@ -64,15 +68,15 @@ __device__ __forceinline__ float xor_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <int DVT, int QB>
+template <int DKT, int DVT, int QB>
 __global__ void __launch_bounds__(64) attn_fwd_k4_kernel(const PgAttnArgs a) {
-  const int L = a.L, NB = L / (16 * QB);
+  const int L = a.L, NB = (L + 16 * QB - 1) / (16 * QB);
   const K4Map mp = k4_map(a.N * a.heads, NB);
   if (mp.unit < 0) return;
   const int n = mp.unit / a.heads, h = mp.unit - n * a.heads;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
-  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
-  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
+  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * (4 * DKT) * L;
+  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * (4 * DKT) * L;
   const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * (16 * DVT) * L;
   float* op = a.o_out + (size_t)n * a.o_bs + (size_t)h * (16 * DVT) * L;
   float* lp = a.lse2_out + ((size_t)n * a.heads + h) * L;
@@ -82,25 +86,38 @@ __global__ void __launch_bounds__(64) attn_fwd_k4_kernel(const PgAttnArgs a) {
     const int b = pass == 0 ? mp.b0 : mp.b1;
     if (b < 0) break;
     const int q0 = b * (16 * QB);
-    const int nkt = (q0 + 16 * QB - strict + 15) >> 4;  // key tiles this block can see
-    float qf[QB];
+    const int qlast = min(q0 + 16 * QB, L);             // groups at or beyond L are skipped
+    const int nkt = (qlast - strict + 15) >> 4;         // key tiles this block can see
+    float qf[QB][DKT];
 #pragma unroll
-    for (int qg = 0; qg < QB; ++qg) qf[qg] = qp[g * L + q0 + 16 * qg + j] * a.scale2;
+    for (int qg = 0; qg < QB; ++qg)
+#pragma unroll
+      for (int c = 0; c < DKT; ++c)
+        qf[qg][c] = qp[(size_t)(4 * c + g) * L + min(q0 + 16 * qg + j, L - 1)] * a.scale2;
 
     // ---- pass 1: row maxima (score MFMA only)
     float mx[QB];
 #pragma unroll
     for (int qg = 0; qg < QB; ++qg) mx[qg] = NEG_BIG;
     {
-      float kf = kp[g * L + j];
+      float kf[DKT];
+#pragma unroll
+      for (int c = 0; c < DKT; ++c) kf[c] = kp[(size_t)(4 * c + g) * L + j];
       for (int kt = 0; kt < nkt; ++kt) {
         const int key0 = kt << 4;
-        const float kf_n = (kt + 1 < nkt) ? kp[g * L + key0 + 16 + j] : 0.f;
+        float kf_n[DKT];
+        {
+          const int kn = (kt + 1 < nkt) ? key0 + 16 : key0;
+#pragma unroll
+          for (int c = 0; c < DKT; ++c) kf_n[c] = kp[(size_t)(4 * c + g) * L + kn + j];
+        }
 #pragma unroll
         for (int qg = 0; qg < QB; ++qg) {
           const int qq0 = q0 + 16 * qg;
-          if (key0 + strict > qq0 + 15) continue;  // every key of the tile is masked for this group
-          f32x4 s = MFMA4(kf, qf[qg], (f32x4{0.f, 0.f, 0.f, 0.f}));
+          if (key0 + strict > qq0 + 15 || qq0 >= L) continue;  // every key of the tile is masked for this group
+          f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < DKT; ++c) s = MFMA4(kf[c], qf[qg][c], s);
           if (key0 + 15 + strict > qq0) {  // diagonal tile
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -108,7 +125,8 @@ __global__ void __launch_bounds__(64) attn_fwd_k4_kernel(const PgAttnArgs a) {
           }
           mx[qg] = fmaxf(mx[qg], fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
         }
-        kf = kf_n;
+#pragma unroll
+        for (int c = 0; c < DKT; ++c) kf[c] = kf_n[c];
       }
     }
     float negm[QB];
@@ -128,18 +146,21 @@ __global__ void __launch_bounds__(64) attn_fwd_k4_kernel(const PgAttnArgs a) {
 #pragma unroll
       for (int t = 0; t < DVT; ++t) O[qg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-      float kf = kp[g * L + j];
+      float kf[DKT];
+#pragma unroll
+      for (int c = 0; c < DKT; ++c) kf[c] = kp[(size_t)(4 * c + g) * L + j];
       float4 vf[DVT];
 #pragma unroll
       for (int t = 0; t < DVT; ++t)
         vf[t] = *reinterpret_cast<const float4*>(vp + (size_t)(16 * t + j) * L + 4 * g);
       for (int kt = 0; kt < nkt; ++kt) {
         const int key0 = kt << 4;
-        float kf_n = 0.f;
+        float kf_n[DKT];
         float4 vf_n[DVT];
         {
           const int kn = (kt + 1 < nkt) ? key0 + 16 : key0;  // clamped prefetch of the next tile
-          kf_n = kp[g * L + kn + j];
+#pragma unroll
+          for (int c = 0; c < DKT; ++c) kf_n[c] = kp[(size_t)(4 * c + g) * L + kn + j];
 #pragma unroll
           for (int t = 0; t < DVT; ++t)
             vf_n[t] = *reinterpret_cast<const float4*>(vp + (size_t)(16 * t + j) * L + kn + 4 * g);
@@ -147,8 +168,10 @@ __global__ void __launch_bounds__(64) attn_fwd_k4_kernel(const PgAttnArgs a) {
 #pragma unroll
         for (int qg = 0; qg < QB; ++qg) {
           const int qq0 = q0 + 16 * qg;
-          if (key0 + strict > qq0 + 15) continue;
-          f32x4 s = MFMA4(kf, qf[qg], (f32x4{negm[qg], negm[qg], negm[qg], negm[qg]}));
+          if (key0 + strict > qq0 + 15 || qq0 >= L) continue;
+          f32x4 s = f32x4{negm[qg], negm[qg], negm[qg], negm[qg]};
+#pragma unroll
+          for (int c = 0; c < DKT; ++c) s = MFMA4(kf[c], qf[qg][c], s);
           float p[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r]);
@@ -166,7 +189,8 @@ __global__ void __launch_bounds__(64) attn_fwd_k4_kernel(const PgAttnArgs a) {
             O[qg][t] = MFMA4(vf[t].w, p[3], O[qg][t]);
           }
         }
-        kf = kf_n;
+#pragma unroll
+        for (int c = 0; c < DKT; ++c) kf[c] = kf_n[c];
 #pragma unroll
         for (int t = 0; t < DVT; ++t) vf[t] = vf_n[t];
       }
@@ -174,6 +198,7 @@ __global__ void __launch_bounds__(64) attn_fwd_k4_kernel(const PgAttnArgs a) {
     // ---- normalise and write O^T[dv = 16t + 4g + r][query j], lse2
 #pragma unroll
     for (int qg = 0; qg < QB; ++qg) {
+      if (q0 + 16 * qg >= L) continue;
       const float lt = xor_sum(l[qg]);
       const float inv = lt > 0.f ? 1.f / lt : 0.f;
       const int qi = q0 + 16 * qg + j;
@@ -187,36 +212,40 @@ __global__ void __launch_bounds__(64) attn_fwd_k4_kernel(const PgAttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ dQ (+ delta)
-template <int DVT, int QB>
+template <int DKT, int DVT, int QB>
 __global__ void __launch_bounds__(64) attn_dq_k4_kernel(const PgAttnArgs a) {
-  const int L = a.L, NB = L / (16 * QB);
+  const int L = a.L, NB = (L + 16 * QB - 1) / (16 * QB);
   const K4Map mp = k4_map(a.N * a.heads, NB);
   if (mp.unit < 0) return;
   const int n = mp.unit / a.heads, h = mp.unit - n * a.heads;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
-  constexpr int DV = 16 * DVT, NS = 4 * DVT;  // dv K steps of 4
-  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
-  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
+  constexpr int DK = 4 * DKT, DV = 16 * DVT, NS = 4 * DVT;  // dv K steps of 4
+  constexpr int DKM = DKT >= 4 ? DKT / 4 : 1;               // 16-channel MFMA tiles of dQ (d_k >= 16)
+  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * DK * L;
+  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * DK * L;
   const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * DV * L;
   const float* op = a.o + (size_t)n * a.o_bs + (size_t)h * DV * L;
   const float* dop = a.d_o + (size_t)n * a.do_bs + (size_t)h * DV * L;
   const float* lp = a.lse2_in + ((size_t)n * a.heads + h) * L;
   float* dlt = a.delta + ((size_t)n * a.heads + h) * L;
-  float* dqp = a.dq + (size_t)n * a.dq_bs + (size_t)h * 4 * L;
+  float* dqp = a.dq + (size_t)n * a.dq_bs + (size_t)h * DK * L;
   const int strict = a.strict;
 
   for (int pass = 0; pass < 2; ++pass) {
     const int b = pass == 0 ? mp.b0 : mp.b1;
     if (b < 0) break;
     const int q0 = b * (16 * QB);
-    const int nkt = (q0 + 16 * QB - strict + 15) >> 4;
-    float qf[QB], nl[QB], dl[QB];
+    const int qlast = min(q0 + 16 * QB, L);
+    const int nkt = (qlast - strict + 15) >> 4;
+    float qf[QB][DKT], nl[QB], dl[QB];
     float dof[QB][NS];  // B[k = dv][j = query] of dP^T = V dO^T: dO^T[dv = 4s + g][query j]
-    float dq[QB][4];
+    float dq[QB][4];    // d_k = 4: VALU accumulation
+    f32x4 dqm[QB][DKM];  // d_k >= 16: dQ^T[channel 16t + 4g + r][query j]
 #pragma unroll
     for (int qg = 0; qg < QB; ++qg) {
-      const int qi = q0 + 16 * qg + j;
-      qf[qg] = qp[g * L + qi] * a.scale2;
+      const int qi = min(q0 + 16 * qg + j, L - 1);
+#pragma unroll
+      for (int c = 0; c < DKT; ++c) qf[qg][c] = qp[(size_t)(4 * c + g) * L + qi] * a.scale2;
       float acc = 0.f;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -224,33 +253,52 @@ __global__ void __launch_bounds__(64) attn_dq_k4_kernel(const PgAttnArgs a) {
         acc = fmaf(dof[qg][s], op[(size_t)(4 * s + g) * L + qi], acc);
       }
       dl[qg] = xor_sum(acc);  // delta_j = sum_dv dO O
-      if (g == 0) dlt[qi] = dl[qg];
+      if (g == 0 && q0 + 16 * qg < L) dlt[qi] = dl[qg];
       nl[qg] = -lp[qi];
 #pragma unroll
       for (int d = 0; d < 4; ++d) dq[qg][d] = 0.f;
+#pragma unroll
+      for (int t = 0; t < DKM; ++t) dqm[qg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float kf = kp[g * L + j];
-    float vfa[NS];  // A[i = key][k = dv] of dP^T: V^T[dv = 4s + g][key j]
-    float4 kr[4];   // K[d][keys 4g..4g+3] for the VALU dQ accumulation
+    float kf[DKT];
+    float vfa[NS];    // A[i = key][k = dv] of dP^T: V^T[dv = 4s + g][key j]
+    float4 kr[DKT >= 4 ? DKM : 4];  // d_k = 4: K[d][keys 4g..4g+3]; d_k >= 16: K^T row 16t + j, keys 4g..4g+3
+#pragma unroll
+    for (int c = 0; c < DKT; ++c) kf[c] = kp[(size_t)(4 * c + g) * L + j];
 #pragma unroll
     for (int s = 0; s < NS; ++s) vfa[s] = vp[(size_t)(4 * s + g) * L + j];
+    if constexpr (DKT >= 4) {
 #pragma unroll
-    for (int d = 0; d < 4; ++d) kr[d] = *reinterpret_cast<const float4*>(kp + d * L + 4 * g);
+      for (int t = 0; t < DKM; ++t) kr[t] = *reinterpret_cast<const float4*>(kp + (size_t)(16 * t + j) * L + 4 * g);
+    } else {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) kr[d] = *reinterpret_cast<const float4*>(kp + d * L + 4 * g);
+    }
     for (int kt = 0; kt < nkt; ++kt) {
       const int key0 = kt << 4;
       const int kn = (kt + 1 < nkt) ? key0 + 16 : key0;
-      const float kf_n = kp[g * L + kn + j];
+      float kf_n[DKT];
       float vfa_n[NS];
-      float4 kr_n[4];
+      float4 kr_n[DKT >= 4 ? DKM : 4];
+#pragma unroll
+      for (int c = 0; c < DKT; ++c) kf_n[c] = kp[(size_t)(4 * c + g) * L + kn + j];
 #pragma unroll
       for (int s = 0; s < NS; ++s) vfa_n[s] = vp[(size_t)(4 * s + g) * L + kn + j];
+      if constexpr (DKT >= 4) {
 #pragma unroll
-      for (int d = 0; d < 4; ++d) kr_n[d] = *reinterpret_cast<const float4*>(kp + d * L + kn + 4 * g);
+        for (int t = 0; t < DKM; ++t)
+          kr_n[t] = *reinterpret_cast<const float4*>(kp + (size_t)(16 * t + j) * L + kn + 4 * g);
+      } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) kr_n[d] = *reinterpret_cast<const float4*>(kp + d * L + kn + 4 * g);
+      }
 #pragma unroll
       for (int qg = 0; qg < QB; ++qg) {
         const int qq0 = q0 + 16 * qg;
-        if (key0 + strict > qq0 + 15) continue;  // every key of the tile is masked for this group
-        f32x4 s4 = MFMA4(kf, qf[qg], (f32x4{nl[qg], nl[qg], nl[qg], nl[qg]}));
+        if (key0 + strict > qq0 + 15 || qq0 >= L) continue;  // every key of the tile is masked for this group
+        f32x4 s4 = f32x4{nl[qg], nl[qg], nl[qg], nl[qg]};
+#pragma unroll
+        for (int c = 0; c < DKT; ++c) s4 = MFMA4(kf[c], qf[qg][c], s4);
         f32x4 dp = f32x4{-dl[qg], -dl[qg], -dl[qg], -dl[qg]};
 #pragma unroll
         for (int s = 0; s < NS; ++s) dp = MFMA4(vfa[s], dof[qg][s], dp);
@@ -262,46 +310,67 @@ __global__ void __launch_bounds__(64) attn_dq_k4_kernel(const PgAttnArgs a) {
           for (int r = 0; r < 4; ++r)
             if (key0 + 4 * g + r + strict > qq0 + j) ds[r] = 0.f;
         }
+        if constexpr (DKT >= 4) {  // dQ^T[16 channels][query] += K^T[16 channels x 4 keys] dS^T[4 keys x 16]
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-          dq[qg][d] += (ds[0] * kr[d].x + ds[1] * kr[d].y) + (ds[2] * kr[d].z + ds[3] * kr[d].w);
+          for (int t = 0; t < DKM; ++t) {
+            dqm[qg][t] = MFMA4(kr[t].x, ds[0], dqm[qg][t]);
+            dqm[qg][t] = MFMA4(kr[t].y, ds[1], dqm[qg][t]);
+            dqm[qg][t] = MFMA4(kr[t].z, ds[2], dqm[qg][t]);
+            dqm[qg][t] = MFMA4(kr[t].w, ds[3], dqm[qg][t]);
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            dq[qg][d] += (ds[0] * kr[d].x + ds[1] * kr[d].y) + (ds[2] * kr[d].z + ds[3] * kr[d].w);
+        }
       }
-      kf = kf_n;
+#pragma unroll
+      for (int c = 0; c < DKT; ++c) kf[c] = kf_n[c];
 #pragma unroll
       for (int s = 0; s < NS; ++s) vfa[s] = vfa_n[s];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) kr[d] = kr_n[d];
+      for (int d = 0; d < (DKT >= 4 ? DKM : 4); ++d) kr[d] = kr_n[d];
     }
-    // lanes (0..3, j) hold partial sums over their keys; lane (g, j) writes channel d = g
 #pragma unroll
     for (int qg = 0; qg < QB; ++qg) {
-      float mine = 0.f;
+      if (q0 + 16 * qg >= L) continue;
+      if constexpr (DKT >= 4) {
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const float t = xor_sum(dq[qg][d]);
-        if (d == g) mine = t;
+        for (int t = 0; t < DKM; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            dqp[(size_t)(16 * t + 4 * g + r) * L + q0 + 16 * qg + j] = dqm[qg][t][r] * a.scale;
+      } else {
+        // lanes (0..3, j) hold partial sums over their keys; lane (g, j) writes channel d = g
+        float mine = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float t = xor_sum(dq[qg][d]);
+          if (d == g) mine = t;
+        }
+        dqp[g * L + q0 + 16 * qg + j] = mine * a.scale;
       }
-      dqp[g * L + q0 + 16 * qg + j] = mine * a.scale;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------ dK, dV
-template <int DVT, int QB>
+template <int DKT, int DVT, int QB>
 __global__ void __launch_bounds__(64) attn_dkv_k4_kernel(const PgAttnArgs a) {
-  const int L = a.L, NB = L / (16 * QB);
+  const int L = a.L, NB = (L + 16 * QB - 1) / (16 * QB);
   const K4Map mp = k4_map(a.N * a.heads, NB);
   if (mp.unit < 0) return;
   const int n = mp.unit / a.heads, h = mp.unit - n * a.heads;
   const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
-  constexpr int DV = 16 * DVT, NS = 4 * DVT;
-  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
-  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
+  constexpr int DK = 4 * DKT, DV = 16 * DVT, NS = 4 * DVT;
+  constexpr int DKM = DKT >= 4 ? DKT / 4 : 1;
+  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * DK * L;
+  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * DK * L;
   const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * DV * L;
   const float* dop = a.d_o + (size_t)n * a.do_bs + (size_t)h * DV * L;
   const float* lp = a.lse2_in + ((size_t)n * a.heads + h) * L;
   const float* dlt = a.delta + ((size_t)n * a.heads + h) * L;
-  float* dkp = a.dk + (size_t)n * a.dk_bs + (size_t)h * 4 * L;
+  float* dkp = a.dk + (size_t)n * a.dk_bs + (size_t)h * DK * L;
   float* dvp = a.dv + (size_t)n * a.dv_bs + (size_t)h * DV * L;
   const int strict = a.strict;
   const int nqt = L >> 4;
@@ -311,49 +380,60 @@ __global__ void __launch_bounds__(64) attn_dkv_k4_kernel(const PgAttnArgs a) {
     const int bb = pass == 0 ? mp.b0 : mp.b1;
     if (bb < 0) break;
     const int k0 = (NB - 1 - bb) * (16 * QB);
-    float kfb[QB];     // B[k = d][j = key] of S = Q K^T, per 16-key group
-    float vfb[QB][NS]; // B[k = dv][j = key] of dP = dO V^T
+    float kfb[QB][DKT];  // B[k = d][j = key] of S = Q K^T, per 16-key group
+    float vfb[QB][NS];   // B[k = dv][j = key] of dP = dO V^T
     f32x4 dV[QB][DVT];
-    float dk[QB][4];
+    float dk[QB][4];     // d_k = 4: VALU accumulation
+    f32x4 dkm[QB][DKM];  // d_k >= 16: dK^T[channel 16t + 4g + r][key j]
 #pragma unroll
     for (int kg = 0; kg < QB; ++kg) {
-      const int ki = k0 + 16 * kg + j;
-      kfb[kg] = kp[g * L + ki] * a.scale2;
+      const int ki = min(k0 + 16 * kg + j, L - 1);
+#pragma unroll
+      for (int c = 0; c < DKT; ++c) kfb[kg][c] = kp[(size_t)(4 * c + g) * L + ki] * a.scale2;
 #pragma unroll
       for (int s = 0; s < NS; ++s) vfb[kg][s] = vp[(size_t)(4 * s + g) * L + ki];
 #pragma unroll
       for (int t = 0; t < DVT; ++t) dV[kg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int d = 0; d < 4; ++d) dk[kg][d] = 0.f;
+#pragma unroll
+      for (int t = 0; t < DKM; ++t) dkm[kg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int qt0 = (k0 + strict) >> 4;  // first query tile that sees a key of this block
 
 #define K4_LOAD(QQ, QFA, DOFA, DOFT, QR, NL, ND)                                                   \
   {                                                                                                 \
-    QFA = qp[g * L + (QQ) + j];                                                                     \
+    _Pragma("unroll") for (int c = 0; c < DKT; ++c) QFA[c] = qp[(size_t)(4 * c + g) * L + (QQ) + j]; \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) DOFA[s] = dop[(size_t)(4 * s + g) * L + (QQ) + j]; \
     _Pragma("unroll") for (int t = 0; t < DVT; ++t)                                                 \
         DOFT[t] = *reinterpret_cast<const float4*>(dop + (size_t)(16 * t + j) * L + (QQ) + 4 * g);   \
-    _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                   \
-        QR[d] = *reinterpret_cast<const float4*>(qp + d * L + (QQ) + 4 * g);                         \
+    if constexpr (DKT >= 4) {                                                                       \
+      _Pragma("unroll") for (int t = 0; t < DKM; ++t)                                               \
+          QR[t] = *reinterpret_cast<const float4*>(qp + (size_t)(16 * t + j) * L + (QQ) + 4 * g);    \
+    } else {                                                                                        \
+      _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                 \
+          QR[d] = *reinterpret_cast<const float4*>(qp + d * L + (QQ) + 4 * g);                       \
+    }                                                                                               \
     NL = *reinterpret_cast<const float4*>(lp + (QQ) + 4 * g);                                        \
     ND = *reinterpret_cast<const float4*>(dlt + (QQ) + 4 * g);                                       \
   }
-    float qfa, dofa[NS];
-    float4 doft[DVT], qr[4], nl4, nd4;
+    float qfa[DKT], dofa[NS];
+    float4 doft[DVT], qr[DKT >= 4 ? DKM : 4], nl4, nd4;
     K4_LOAD(min(qt0, nqt - 1) << 4, qfa, dofa, doft, qr, nl4, nd4)
     for (int qt = qt0; qt < nqt; ++qt) {
       const int qq0 = qt << 4;
       const int qn = (qt + 1 < nqt) ? qq0 + 16 : qq0;
-      float qfa_n, dofa_n[NS];
-      float4 doft_n[DVT], qr_n[4], nl4_n, nd4_n;
+      float qfa_n[DKT], dofa_n[NS];
+      float4 doft_n[DVT], qr_n[DKT >= 4 ? DKM : 4], nl4_n, nd4_n;
       K4_LOAD(qn, qfa_n, dofa_n, doft_n, qr_n, nl4_n, nd4_n)
 #pragma unroll
       for (int kg = 0; kg < QB; ++kg) {
         const int kk0 = k0 + 16 * kg;
-        if (kk0 + strict > qq0 + 15) continue;  // no query of the tile sees a key of this group
+        if (kk0 + strict > qq0 + 15 || kk0 >= L) continue;  // no query of the tile sees a key of this group
         // S[query 4g + r][key j] - lse2[query]
-        f32x4 s4 = MFMA4(qfa, kfb[kg], (f32x4{-nl4.x, -nl4.y, -nl4.z, -nl4.w}));
+        f32x4 s4 = f32x4{-nl4.x, -nl4.y, -nl4.z, -nl4.w};
+#pragma unroll
+        for (int c = 0; c < DKT; ++c) s4 = MFMA4(qfa[c], kfb[kg][c], s4);
         float p[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s4[r]);
@@ -375,29 +455,49 @@ __global__ void __launch_bounds__(64) attn_dkv_k4_kernel(const PgAttnArgs a) {
         float ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ds[r] = p[r] * dp[r];
+        if constexpr (DKT >= 4) {  // dK^T[16 channels][key] += Q^T[16 channels x 4 queries] dS[4 queries x 16 keys]
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-          dk[kg][d] += (ds[0] * qr[d].x + ds[1] * qr[d].y) + (ds[2] * qr[d].z + ds[3] * qr[d].w);
+          for (int t = 0; t < DKM; ++t) {
+            dkm[kg][t] = MFMA4(qr[t].x, ds[0], dkm[kg][t]);
+            dkm[kg][t] = MFMA4(qr[t].y, ds[1], dkm[kg][t]);
+            dkm[kg][t] = MFMA4(qr[t].z, ds[2], dkm[kg][t]);
+            dkm[kg][t] = MFMA4(qr[t].w, ds[3], dkm[kg][t]);
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            dk[kg][d] += (ds[0] * qr[d].x + ds[1] * qr[d].y) + (ds[2] * qr[d].z + ds[3] * qr[d].w);
+        }
       }
-      qfa = qfa_n; nl4 = nl4_n; nd4 = nd4_n;
+      nl4 = nl4_n; nd4 = nd4_n;
+#pragma unroll
+      for (int c = 0; c < DKT; ++c) qfa[c] = qfa_n[c];
 #pragma unroll
       for (int s = 0; s < NS; ++s) dofa[s] = dofa_n[s];
 #pragma unroll
       for (int t = 0; t < DVT; ++t) doft[t] = doft_n[t];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) qr[d] = qr_n[d];
+      for (int d = 0; d < (DKT >= 4 ? DKM : 4); ++d) qr[d] = qr_n[d];
     }
 #undef K4_LOAD
 #pragma unroll
     for (int kg = 0; kg < QB; ++kg) {
+      if (k0 + 16 * kg >= L) continue;
       const int ki = k0 + 16 * kg + j;
-      float mine = 0.f;
+      if constexpr (DKT >= 4) {
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const float t = xor_sum(dk[kg][d]);
-        if (d == g) mine = t;
+        for (int t = 0; t < DKM; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dkp[(size_t)(16 * t + 4 * g + r) * L + ki] = dkm[kg][t][r] * a.scale;
+      } else {
+        float mine = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float t = xor_sum(dk[kg][d]);
+          if (d == g) mine = t;
+        }
+        dkp[g * L + ki] = mine * a.scale;
       }
-      dkp[g * L + ki] = mine * a.scale;
 #pragma unroll
       for (int t = 0; t < DVT; ++t)
 #pragma unroll
@@ -406,24 +506,27 @@ __global__ void __launch_bounds__(64) attn_dkv_k4_kernel(const PgAttnArgs a) {
   }
 }
 
-template <int DVT, int QB>
+template <int DKT, int DVT, int QB>
 void k4_launch(int which, const PgAttnArgs& a, dim3 grid, hipStream_t st) {
   if (which == PG_ATTN_FWD)
-    hipLaunchKernelGGL((attn_fwd_k4_kernel<DVT, QB>), grid, dim3(64), 0, st, a);
+    hipLaunchKernelGGL((attn_fwd_k4_kernel<DKT, DVT, QB>), grid, dim3(64), 0, st, a);
   else if (which == PG_ATTN_DQ)
-    hipLaunchKernelGGL((attn_dq_k4_kernel<DVT, QB>), grid, dim3(64), 0, st, a);
+    hipLaunchKernelGGL((attn_dq_k4_kernel<DKT, DVT, QB>), grid, dim3(64), 0, st, a);
   else
-    hipLaunchKernelGGL((attn_dkv_k4_kernel<DVT, QB>), grid, dim3(64), 0, st, a);
+    hipLaunchKernelGGL((attn_dkv_k4_kernel<DKT, DVT, QB>), grid, dim3(64), 0, st, a);
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
-// Returns 1 if these kernels took the launch (d_k == 4, d_v in {16, 32}, L % 64 == 0, 16-byte
-// aligned planes), else 0.
+// Returns 1 if these kernels took the launch: (d_k, d_v) in {(4, 16), (4, 32), (32, 32)}, L % 16 == 0,
+// 16-byte aligned planes; else 0.
 int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st) {
-  if (a.dk_dim != 4 || (a.dv_dim != 16 && a.dv_dim != 32) || (a.L % 64) != 0) return 0;
+  const bool small_k = a.dk_dim == 4 && (a.dv_dim == 16 || a.dv_dim == 32);
+  const bool big_k = a.dk_dim == 32 && a.dv_dim == 32;
+  if (!(small_k || big_k) || (a.L % 16) != 0 || a.L < 16) return 0;
+  if (which > PG_ATTN_DKV) return 0;
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) % 4 != 0) return 0;
   if (!al16(a.k) || !al16(a.v) || !al16(a.q)) return 0;
   if (which != PG_ATTN_FWD) {
@@ -434,18 +537,22 @@ int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st) {
   // A lone wave keeps its SIMD's matrix pipe ~50 % busy (score -> exp -> P.V is one dependent chain
   // per 16-query group), so below ~3 waves per SIMD the blocks are halved to 32 rows: twice the
   // waves, each half as long (measured at batch 128: 1 wave per SIMD ran 2x over the MFMA bound).
+  // d_k = 32 always takes 32-row blocks: with 64 rows the resident operands (q / k / v / dO fragments of
+  // four groups) do not fit the register file.
   static const int force_qb = []() { const char* e = getenv("PG_ATTN_K4_QB"); return e ? atoi(e) : 0; }();
-  int qb = ((long)units * ((a.L / 64 + 1) / 2) >= 3 * 1024) ? 4 : 2;
-  if (force_qb == 2 || force_qb == 4) qb = force_qb;
-  const int NB = a.L / (16 * qb);
+  int qb = (!big_k && (long)units * (((a.L + 63) / 64 + 1) / 2) >= 3 * 1024) ? 4 : 2;
+  if (!big_k && (force_qb == 2 || force_qb == 4)) qb = force_qb;
+  const int NB = (a.L + 16 * qb - 1) / (16 * qb);
   const int npair = (NB + 1) / 2;
   // units in groups of 64 (8 per XCD); every group has 8 * 8 * npair workgroups
   const int groups = (units + 63) / 64;
   dim3 grid((unsigned)(groups * 64 * npair));
-  if (a.dv_dim == 32) {
-    if (qb == 4) k4_launch<2, 4>(which, a, grid, st); else k4_launch<2, 2>(which, a, grid, st);
+  if (big_k) {
+    k4_launch<8, 2, 2>(which, a, grid, st);
+  } else if (a.dv_dim == 32) {
+    if (qb == 4) k4_launch<1, 2, 4>(which, a, grid, st); else k4_launch<1, 2, 2>(which, a, grid, st);
   } else {
-    if (qb == 4) k4_launch<1, 4>(which, a, grid, st); else k4_launch<1, 2>(which, a, grid, st);
+    if (qb == 4) k4_launch<1, 1, 4>(which, a, grid, st); else k4_launch<1, 1, 2>(which, a, grid, st);
   }
   return 1;
 }

@@ -1017,7 +1017,7 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
     // bit-reproducible dQ: the fused kernel sums dQ over key blocks with fp32 LDS atomics)
     if (!pg_attn_fused_bwd_enabled() || a0.dk_dim != 4 || a0.dv_dim != 4) return 0;
   }
-  if (a0.dk_dim == 4 && a0.dv_dim != 4) return pg_attn_k4_launch(which, a0, st);
+  if ((a0.dk_dim == 4 && a0.dv_dim != 4) || (a0.dk_dim == 32 && a0.dv_dim == 32)) return pg_attn_k4_launch(which, a0, st);
   if (a0.dk_dim != 4 || a0.dv_dim != 4) return 0;
   PgAttnArgs a = a0;
   const int NB = (a.L + 63) / 64;

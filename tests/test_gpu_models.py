@@ -108,6 +108,10 @@ BASELINE_CONFIGS = {
     "image_gpt_cifar": ("ImageGPT", dict(in_channels=3, out_channels=3, in_size=32,
                                          n_transformer_blocks=2, n_attention_heads=4,
                                          n_embedding_channels=16), (2, 3, 32, 32)),
+    # the reference's reproduce() shape (image_gpt.py:147-154): 64 embedding channels / 2 heads -> d = 32
+    "image_gpt_repro": ("ImageGPT", dict(in_channels=1, out_channels=1, in_size=28,
+                                         n_transformer_blocks=8, n_attention_heads=2,
+                                         n_embedding_channels=64), (2, 1, 28, 28)),
     "gated_pixel_cnn": ("GatedPixelCNN", dict(in_channels=3, out_channels=3, n_gated=10,
                                               gated_channels=128, head_channels=32), (2, 3, 32, 32)),
     "pixel_snail": ("PixelSNAIL", dict(in_channels=3, out_channels=3, n_channels=64,

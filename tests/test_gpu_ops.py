@@ -147,7 +147,9 @@ ATTN_CASES = [
     # (N, heads, dk, dv, H, W, strict)
     (2, 4, 4, 4, 28, 28, False),   # ImageGPT baseline block
     (2, 1, 4, 32, 32, 32, True),   # PixelSNAIL block
-    (2, 2, 32, 32, 12, 12, False),  # ImageGPT reproduce() shape (2 heads x 32)
+    (2, 2, 32, 32, 12, 12, False),  # ImageGPT reproduce() head dims (2 heads x 32): matrix-core path since round 3
+    (2, 2, 32, 32, 28, 28, False),  # ... at the reproduce() image size, L = 784 (49 query groups: ragged last block)
+    (1, 1, 32, 32, 20, 20, True),   # ... strict mask, L = 400
     (2, 2, 2, 2, 7, 7, False),     # reference MultipleChannelsTests (L=49, ragged chunks)
     (1, 1, 4, 4, 5, 5, True),      # L < 64, strict, L % 8 != 0
     (2, 3, 8, 16, 9, 7, True),     # odd everything

@@ -1,21 +1,34 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + SEPARATE PMC passes for the HBM and
-# SQ counters (never combined with other trace domains) for both halves of the bench line, outputs
-# under gpurun_out/prof_r02/.   usage: bash tools/collect_profiles.sh
+# SQ counters (never combined with other trace domains), outputs under gpurun_out/prof_r03/.
+#   ImageGPT headline (batch 1024, hipGraph replay): stats, FETCH_SIZE, WRITE_SIZE, SQ counters.
+#   PixelSNAIL (batch 512): stats on the graphed run; the counter passes on an UNGRAPHED 2-step run
+#   restricted to the matrix-core kernels (counter collection over the ~11 k-launch graph stalled in
+#   round 2: 25 GPU-minutes lost).
+# usage: bash tools/collect_profiles.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof_r02
+OUT=$R/gpurun_out/prof_r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE"
-for W in "igpt --model image_gpt --batch 1024" "snail --model pixel_snail --batch 512"; do
-  set -- $W; TAG=$1; shift
-  CMD="python $R/bench.py $* --steps 10 --warmup 3 --no-cpu-baseline"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o p -- $CMD > $OUT/${TAG}_stats.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o p -- $CMD > $OUT/${TAG}_fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o p -- $CMD > $OUT/${TAG}_write.log 2>&1
-  rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/${TAG}_sq -o p -- $CMD > $OUT/${TAG}_sq.log 2>&1
-  tail -1 $OUT/${TAG}_stats.log | cut -c1-160
-done
+run() {  # tag, timeout, rocprof args..., -- cmd
+  local tag=$1 to=$2; shift 2
+  timeout $to rocprofv3 "$@" > $OUT/$tag.log 2>&1 || echo "[$tag] rc=$?"
+}
+IG="python $R/bench.py --model image_gpt --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline"
+run igpt_stats 300 --kernel-trace --stats --output-format csv -d $OUT/igpt_stats -o p -- $IG
+run igpt_fetch 300 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/igpt_fetch -o p -- $IG
+run igpt_write 300 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/igpt_write -o p -- $IG
+run igpt_sq 300 --kernel-trace --pmc $SQ --output-format csv -d $OUT/igpt_sq -o p -- $IG
+tail -1 $OUT/igpt_stats.log | cut -c1-160
+SN="python $R/bench.py --model pixel_snail --batch 512 --steps 10 --warmup 3 --no-cpu-baseline"
+run snail_stats 300 --kernel-trace --stats --output-format csv -d $OUT/snail_stats -o p -- $SN
+SNE="python $R/bench.py --model pixel_snail --batch 512 --steps 2 --warmup 1 --no-cpu-baseline --no-graph"
+RX='conv_b3|conv_wgrad_b3|attn_.*_k4|gated_fwd4'
+run snail_fetch 240 --kernel-trace --kernel-include-regex "$RX" --pmc FETCH_SIZE --output-format csv -d $OUT/snail_fetch -o p -- $SNE
+run snail_write 240 --kernel-trace --kernel-include-regex "$RX" --pmc WRITE_SIZE --output-format csv -d $OUT/snail_write -o p -- $SNE
+run snail_sq 240 --kernel-trace --kernel-include-regex "$RX" --pmc $SQ --output-format csv -d $OUT/snail_sq -o p -- $SNE
+tail -1 $OUT/snail_stats.log | cut -c1-160
 # keep only small summaries (counter CSVs are aggregated here to stay under the merge limit)
 python - <<PY
 import csv, collections, glob, json, os
