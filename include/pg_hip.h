@@ -383,6 +383,16 @@ int pg_mse_fwd(const float* a, const float* b, float* loss, size_t n, void* stre
 int pg_mse_bwd(const float* a, const float* b, const float* g_loss, float* da, float* db, size_t n,
                void* stream);
 
+/* Discretized mixture-of-logistics negative log-likelihood (the PixelCNN++ loss of BASELINE.json
+ * configs[2]; absent from the reference: Salimans et al., ICLR 2017, eq. (2)-(3), restated in
+ * oracle/dmol.py). l (N, 10 K, L): K logits, then per sub-pixel c = 0..2: K means, K log-scales, K raw
+ * coefficients; x (N, 3, L) in [-1, 1]; K <= 16.
+ *   fwd: loss[0] += -(1 / N) sum log p(x) (nats; zeroed by the caller)
+ *   bwd: dl = gscale[0] * d loss / d l */
+int pg_dmol_fwd(const float* l, const float* x, float* loss, int N, int K, int L, void* stream);
+int pg_dmol_bwd(const float* l, const float* x, const float* gscale, float* dl, int N, int K, int L,
+                void* stream);
+
 /* dst[r * dst_stride + i] (+)= src[r * src_stride + i] for r < rows, i < row_len (strides in floats).
  * The channel concatenation in front of a merged projection (nn/attention.py:139-143
  * torch.cat((x, extra_x), dim=1): a row = the channels of one image) and the assembly / gradient split

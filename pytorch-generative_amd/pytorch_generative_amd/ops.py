@@ -1161,6 +1161,41 @@ class _BCEWithLogitsSumMean(torch.autograd.Function):
         return dz, None
 
 
+class _DmolLossSumMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, l, x, n_mix):
+        lib = _lib.load()
+        l = _chk(l, "dmol.params")
+        x = _chk(x, "dmol.images")
+        n, c, h, w = l.shape
+        if c != 10 * n_mix or tuple(x.shape) != (n, 3, h, w):
+            raise ValueError("dmol: expected (N, 10 * n_mix, H, W) parameters and (N, 3, H, W) images in [-1, 1]")
+        loss = torch.zeros(1, device=l.device, dtype=torch.float32)
+        _lib.check(lib.pg_dmol_fwd(l.data_ptr(), x.data_ptr(), loss.data_ptr(), n, n_mix, h * w, _stream()),
+                   "pg_dmol_fwd")
+        ctx.save_for_backward(l, x)
+        ctx.n_mix = n_mix
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        l, x = ctx.saved_tensors
+        g = _chk(g.reshape(1), "dmol.grad")
+        n, _, h, w = l.shape
+        dl = torch.empty_like(l)
+        _lib.check(lib.pg_dmol_bwd(l.data_ptr(), x.data_ptr(), g.data_ptr(), dl.data_ptr(), n, ctx.n_mix, h * w,
+                                   _stream()), "pg_dmol_bwd")
+        return dl, None, None
+
+
+def dmol_loss_sum_mean(params, images, n_mix=10):
+    """Discretized mixture-of-logistics negative log-likelihood (PixelCNN++, Salimans et al. 2017), nats,
+    summed over pixels and averaged over the batch. params (N, 10 * n_mix, H, W), images (N, 3, H, W) in
+    [-1, 1]. Not in the reference (BASELINE.json configs[2] names it): parity is against oracle/dmol.py."""
+    return _DmolLossSumMean.apply(params, images, int(n_mix))
+
+
 def bce_with_logits_sum_mean(logits, targets):
     """F.binary_cross_entropy_with_logits(reduction='none').sum(pixels).mean(batch)
     (reference image_gpt.py:158-162 and every other AR reproduce())."""

@@ -1,0 +1,71 @@
+"""CPU: the discretized mixture-of-logistics oracle (oracle/dmol.py) against analytic known answers —
+the reference has no implementation of this loss, so these properties are what pins the restatement
+of the published algorithm (Salimans et al. 2017, eq. 2-3)."""
+
+import math
+
+import torch
+
+from oracle import dmol
+
+
+def _grid_images(vals_r, g=37, b=200):
+    """(len(vals), 3, 1, 1) images with the given red values and fixed green / blue, in [-1, 1]."""
+    x = torch.tensor([[v, g, b] for v in vals_r], dtype=torch.float64) / 127.5 - 1.0
+    return x.view(-1, 3, 1, 1)
+
+
+def test_bin_masses_sum_to_one_per_subpixel():
+    torch.manual_seed(0)
+    k = 5
+    l = torch.randn(1, 10 * k, 1, 1, dtype=torch.float64) * 1.5
+    l[:, k + k:k + 2 * k] -= 2.0  # some narrow components
+    # red: marginal over red only (green / blue terms sum to one on their own grids)
+    logits, means, log_scales, coeffs = dmol.split_params(l, k)
+    for c, fixed in ((0, (0, 0)), (1, (91, 0)), (2, (91, 203))):
+        vals = torch.arange(256, dtype=torch.float64)
+        imgs = torch.zeros(256, 3, 1, 1, dtype=torch.float64)
+        imgs[:, 0, 0, 0] = (vals if c == 0 else torch.full_like(vals, fixed[0])) / 127.5 - 1
+        imgs[:, 1, 0, 0] = (vals if c == 1 else torch.full_like(vals, fixed[1])) / 127.5 - 1
+        imgs[:, 2, 0, 0] = vals / 127.5 - 1 if c == 2 else 0.0
+        lp = dmol.component_log_probs(imgs, means.expand(256, -1, -1, -1, -1), log_scales.expand(256, -1, -1, -1, -1),
+                                      coeffs.expand(256, -1, -1, -1, -1))
+        mass = lp[:, c].exp().sum(dim=0)  # (K, 1, 1): every component's masses over the 256 values
+        assert torch.allclose(mass, torch.ones_like(mass), atol=1e-6), (c, mass.flatten())
+
+
+def test_single_wide_component_is_uniform_inside():
+    k = 1
+    l = torch.zeros(1, 10, 1, 1, dtype=torch.float64)
+    l[:, 1 + 1] = 9.0   # log-scale of red: scale e^9 >> 2, the logistic is flat over [-1, 1]
+    l[:, 1 + 3 + 1] = 9.0
+    l[:, 1 + 6 + 1] = 9.0
+    x = _grid_images([100])
+    ll = dmol.dmol_log_likelihood(l.expand(1, -1, -1, -1), x, k)
+    # three interior sub-pixels, each with mass ~ (2/255) * pdf(0) = (2/255) / (4 s)
+    s = math.exp(9.0)
+    want = 3 * math.log((2.0 / 255.0) / (4.0 * s))
+    assert abs(float(ll) - want) < 1e-6 * abs(want)
+
+
+def test_invariant_to_component_permutation_and_matches_finite_differences():
+    torch.manual_seed(1)
+    k, n, h, w = 4, 2, 3, 2
+    l = torch.randn(n, 10 * k, h, w, dtype=torch.float64)
+    x = (torch.randint(0, 256, (n, 3, h, w)).double() / 127.5 - 1.0)
+    x[0, :, 0, 0] = -1.0  # edge bins
+    x[1, :, 1, 1] = 1.0
+    base = dmol.dmol_loss_sum_mean(l, x, k)
+    perm = torch.tensor([2, 0, 3, 1])
+    idx = torch.cat([perm] + [k + c * 3 * k + j * k + perm for c in range(3) for j in range(3)])
+    assert abs(float(dmol.dmol_loss_sum_mean(l[:, idx], x, k) - base)) < 1e-10
+    lg = l.clone().requires_grad_(True)
+    dmol.dmol_loss_sum_mean(lg, x, k).backward()
+    eps = 1e-6
+    for pos in [(0, 1, 0, 0), (1, k + 2, 1, 1), (0, k + k + 1, 2, 0), (1, k + 2 * k + 3, 0, 1),
+                (0, k + 3 * k + 2 * k + 1, 1, 0), (1, k + 6 * k + 2 * k + 2, 2, 1)]:
+        lp, lm = l.clone(), l.clone()
+        lp[pos] += eps
+        lm[pos] -= eps
+        fd = float(dmol.dmol_loss_sum_mean(lp, x, k) - dmol.dmol_loss_sum_mean(lm, x, k)) / (2 * eps)
+        assert abs(fd - float(lg.grad[pos])) < 1e-5 * max(1.0, abs(fd)), (pos, fd, float(lg.grad[pos]))

@@ -68,3 +68,29 @@ def test_vq_vae_models_match_reference_golden(dev, name, ctor):
     for k, v in model.state_dict().items():
         if k.endswith(("_embedding", "_cluster_size", "_embedding_avg")):
             _util.assert_close(v, after[k], 1e-5, f"buffer {k} after forward")
+
+
+@pytest.mark.parametrize("n_mix,shape", [(10, (3, 32, 32)), (4, (2, 5, 7)), (1, (2, 8, 8))])
+def test_dmol_loss_matches_oracle(dev, n_mix, shape):
+    """Discretized mixture-of-logistics loss (PixelCNN++; not in the reference): HIP forward / backward
+    against oracle/dmol.py (the published algorithm, pinned by tests/test_dmol_cpu.py), incl. both edge
+    bins, clamped log-scales and the density fallback for vanishing bin masses."""
+    from oracle import dmol
+    from pytorch_generative_amd import ops
+
+    n, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    l = torch.randn(n, 10 * n_mix, h, w, generator=g) * 1.5
+    l[:, n_mix + n_mix:n_mix + 2 * n_mix] -= 3.0      # narrow red components: some masses below the switch
+    l[0, n_mix + 3 * n_mix + n_mix] = -9.0             # a log-scale below the clamp
+    x = torch.randint(0, 256, (n, 3, h, w), generator=g).float() / 127.5 - 1.0
+    x[0, :, 0, 0] = -1.0
+    x[-1, :, -1, -1] = 1.0
+    lo = l.clone().requires_grad_(True)
+    want = dmol.dmol_loss_sum_mean(lo, x, n_mix)
+    want.backward()
+    lg = l.to(dev).requires_grad_(True)
+    got = ops.dmol_loss_sum_mean(lg, x.to(dev), n_mix)
+    _util.assert_close(got, want, TOL, "dmol loss")
+    (got * 1.7).backward()
+    _util.assert_close(lg.grad, lo.grad * 1.7, 2e-4, "dmol gradient")
