@@ -338,11 +338,11 @@ def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
     return {"launch_ms": ms, "flop_per_launch": flop, "tflops": flop / ms / 1e9}
 
 
-def measured_traffic(batch, kernel):
+def measured_traffic(batch, kernel, files=("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):
     """HBM bytes per launch of the headline's dominant kernel from the committed PMC profiles
     (collected in separate rocprofv3 --pmc passes, see profiles/README.md); None when no committed
     profile holds this kernel at this batch."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in files:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -601,7 +601,11 @@ def main():
                     "bf16x3_ceiling": BF16_PEAK_TFLOPS / 6.0,
                     "frac_of_bf16x3_ceiling": c["tflops"] / (BF16_PEAK_TFLOPS / 6.0),
                     "launch_ms": c["launch_ms"],
-                    "flop_per_launch": c["flop_per_launch"], "traffic": None,
+                    "flop_per_launch": c["flop_per_launch"],
+                    # per-launch HBM bytes of this kernel averaged over its launches INSIDE the model step
+                    # (profiles/r03_snail_traffic.json, batch 512: forward, data-gradient and 1x1 launches)
+                    "traffic": measured_traffic(512, "conv_b3_kernel<4, 4, 1, false>", ("r03_snail_traffic.json",)),
+                    "traffic_profile_batch": 512,
                     "other_kernels": {"conv_wgrad_b3_kernel<4> + wgrad_reduce_kernel": w,
                                       "attn_fwd_k4_kernel": a["fwd"], "attn_dq_k4_kernel": a["dq"],
                                       "attn_dkv_k4_kernel": a["dkv"]},

@@ -383,6 +383,11 @@ int pg_mse_fwd(const float* a, const float* b, float* loss, size_t n, void* stre
 int pg_mse_bwd(const float* a, const float* b, const float* g_loss, float* da, float* db, size_t n,
                void* stream);
 
+/* PixelCNN++'s concatenated ELU (Salimans et al. 2017, section 2.3; not in the reference):
+ * y (N, 2C, L) = [elu(x) | elu(-x)]; CL = C * L. */
+int pg_concat_elu_fwd(const float* x, float* y, int N, long CL, void* stream);
+int pg_concat_elu_bwd(const float* x, const float* dy, float* dx, int N, long CL, void* stream);
+
 /* Discretized mixture-of-logistics negative log-likelihood (the PixelCNN++ loss of BASELINE.json
  * configs[2]; absent from the reference: Salimans et al., ICLR 2017, eq. (2)-(3), restated in
  * oracle/dmol.py). l (N, 10 K, L): K logits, then per sub-pixel c = 0..2: K means, K log-scales, K raw

@@ -512,3 +512,42 @@ PG_EXPORT int pg_copy_rows(const float* src, float* dst, long rows, long row_len
   return 0;
 }
 
+// ---- concat_elu (PixelCNN++: Salimans et al. 2017, section 2.3 "concatenated ELU") -------------------
+// y[:, :C] = elu(x), y[:, C:] = elu(-x); dx = dy1 * elu'(x) - dy2 * elu'(-x). x (N, C, L), y (N, 2C, L).
+namespace {
+__global__ void concat_elu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total, long CL) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / CL, r = i - n * CL;
+    const float v = x[i];
+    y[n * 2 * CL + r] = pg_apply_act(v, PG_ACT_ELU);
+    y[n * 2 * CL + CL + r] = pg_apply_act(-v, PG_ACT_ELU);
+  }
+}
+__global__ void concat_elu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                      float* __restrict__ dx, long total, long CL) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / CL, r = i - n * CL;
+    const float v = x[i];
+    dx[i] = dy[n * 2 * CL + r] * pg_act_grad(v, PG_ACT_ELU) - dy[n * 2 * CL + CL + r] * pg_act_grad(-v, PG_ACT_ELU);
+  }
+}
+}  // namespace
+
+PG_EXPORT int pg_concat_elu_fwd(const float* x, float* y, int N, long CL, void* stream) {
+  PG_REQUIRE(x && y && N > 0 && CL > 0, PG_EINVAL, "pg_concat_elu_fwd: bad arguments");
+  const long total = (long)N * CL;
+  hipLaunchKernelGGL(concat_elu_fwd_kernel, dim3(ew_blocks((size_t)total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     x, y, total, CL);
+  PG_LAUNCH_CHECK("pg_concat_elu_fwd");
+  return 0;
+}
+
+PG_EXPORT int pg_concat_elu_bwd(const float* x, const float* dy, float* dx, int N, long CL, void* stream) {
+  PG_REQUIRE(x && dy && dx && N > 0 && CL > 0, PG_EINVAL, "pg_concat_elu_bwd: bad arguments");
+  const long total = (long)N * CL;
+  hipLaunchKernelGGL(concat_elu_bwd_kernel, dim3(ew_blocks((size_t)total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     x, dy, dx, total, CL);
+  PG_LAUNCH_CHECK("pg_concat_elu_bwd");
+  return 0;
+}
+

@@ -121,6 +121,8 @@ SIGNATURES = {
     "pg_adam_prepare": (c_i, [c_f, c_s]),
     "pg_adam_step": (c_i, [c_f, c_f, c_f, c_f, c_z, c_f, c_flt, c_flt, c_flt, c_s]),
     "pg_attn_fused_bwd": (c_i, [c_i]),
+    "pg_concat_elu_fwd": (c_i, [c_f, c_f, c_i, c_l, c_s]),
+    "pg_concat_elu_bwd": (c_i, [c_f, c_f, c_f, c_i, c_l, c_s]),
     "pg_dmol_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_s]),
     "pg_dmol_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_s]),
     "pg_copy_rows": (c_i, [c_f, c_f, c_l, c_l, c_l, c_l, c_i, c_s]),

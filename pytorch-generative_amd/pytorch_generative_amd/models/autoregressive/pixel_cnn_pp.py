@@ -1,0 +1,141 @@
+"""PixelCNN++ on the MI355X operator path — SURVEY.md §8(f) rank 4 (BASELINE.json configs[2] names it).
+
+The reference repository has NO PixelCNN++; this module follows the published architecture — Salimans,
+Karpathy, Chen, Kingma, "PixelCNN++", ICLR 2017 (section 2: discretized logistic mixture likelihood,
+conditioning on whole pixels, two streams of down-shifted / down-right-shifted convolutions, gated
+residual blocks on concatenated ELUs, down- and up-sampling by strided convolutions with short-cut
+connections across the three resolutions). Its CPU restatement is oracle/pixelcnnpp.py, written on
+torch's strided / transposed convolutions; since there is no reference implementation, parity means HIP
+path == that oracle plus the autoregressive property (tests/test_gpu_f4.py, tests/test_dmol_cpu.py).
+
+How the pieces map onto this package's kernels:
+  * down-shifted (2 x 3) and down-right-shifted (2 x 2) convolutions, and the extra row / column shift
+    of the input layers, are tap lists of the masked-convolution kernels (padding + crop, no shifting
+    copies);
+  * stride-2 down-sampling = the stride-1 shifted convolution followed by ops.subsample2; stride-2
+    up-sampling = ops.zero_insert2 followed by the same shifted convolution (the transposed convolution
+    of the paper written as a gather);
+  * the gate a * sigmoid(b) + residual is GatedActivation's fused kernel; concat_elu is ops.concat_elu;
+  * the loss is ops.dmol_loss_sum_mean on images scaled to [-1, 1].
+"""
+
+import torch
+from torch import nn
+
+from pytorch_generative_amd import nn as pg_nn
+from pytorch_generative_amd import ops
+from pytorch_generative_amd.models import base
+
+
+class ShiftedConv2d(pg_nn.Conv2d):
+    """kind "ds": down-shifted — the (kh x kw) window ends at the output's row and is centred on its
+    column; kind "drs": down-right-shifted — the window ends at the output's row AND column.
+    shift_down / shift_right move the whole window one more row up / column left (the input layers)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, kind, shift_down=False, shift_right=False):
+        kh, kw = kernel_size
+        assert kind in ("ds", "drs") and (kind == "drs" or kw % 2 == 1)
+        ph = kh - 1 + int(shift_down)
+        pw = (kw - 1 if kind == "drs" else (kw - 1) // 2) + int(shift_right)
+        super().__init__(in_channels, out_channels, kernel_size=(kh, kw), padding=(ph, pw))
+
+    def forward(self, x, **kw):
+        return super().forward(x, crop=(x.shape[2], x.shape[3]), **kw)
+
+
+class GatedResnet(nn.Module):
+    """x + a' * sigmoid(b'), [a' | b'] = conv2(concat_elu(conv1(concat_elu(x)) + nin(concat_elu(aux))))."""
+
+    def __init__(self, n_filters, kind, aux_channels=0):
+        super().__init__()
+        ks = (2, 3) if kind == "ds" else (2, 2)
+        self._conv_in = ShiftedConv2d(2 * n_filters, n_filters, ks, kind)
+        self._nin = pg_nn.Conv2d(2 * aux_channels, n_filters, kernel_size=1) if aux_channels else None
+        self._conv_out = ShiftedConv2d(2 * n_filters, 2 * n_filters, ks, kind)
+        self._gate = pg_nn.GatedActivation(activation_fn=nn.Identity())
+
+    def forward(self, x, aux=None):
+        c1 = self._conv_in(ops.concat_elu(x))
+        if aux is not None:
+            c1 = self._nin(ops.concat_elu(aux), res=c1)
+        c2 = self._conv_out(ops.concat_elu(c1))
+        return self._gate(c2, res=x)
+
+
+class PixelCNNpp(base.AutoregressiveModel):
+    """forward(x) -> (N, 10 * n_mix, H, W) mixture parameters for images x in [-1, 1] with 3 channels
+    (H, W multiples of 4). Paper configuration: n_filters=160, n_resnet=5, n_mix=10."""
+
+    def __init__(self, in_channels=3, n_filters=160, n_resnet=5, n_mix=10, sample_fn=None):
+        super().__init__(sample_fn)
+        if in_channels != 3:
+            raise ValueError("PixelCNNpp: the discretized logistic mixture conditions R, G, B sub-pixels (3 channels)")
+        f, cin = n_filters, in_channels + 1  # + a channel of ones (so that the shifted convolutions see the border)
+        self._n_mix, self._n_resnet = n_mix, n_resnet
+        self._u_in = ShiftedConv2d(cin, f, (2, 3), "ds", shift_down=True)
+        self._ul_in_a = ShiftedConv2d(cin, f, (1, 3), "ds", shift_down=True)
+        self._ul_in_b = ShiftedConv2d(cin, f, (2, 1), "drs", shift_right=True)
+        self._up_u = nn.ModuleList([nn.ModuleList([GatedResnet(f, "ds") for _ in range(n_resnet)]) for _ in range(3)])
+        self._up_ul = nn.ModuleList([nn.ModuleList([GatedResnet(f, "drs", aux_channels=f) for _ in range(n_resnet)])
+                                     for _ in range(3)])
+        self._down_u_conv = nn.ModuleList([ShiftedConv2d(f, f, (2, 3), "ds") for _ in range(2)])
+        self._down_ul_conv = nn.ModuleList([ShiftedConv2d(f, f, (2, 2), "drs") for _ in range(2)])
+        counts = [n_resnet, n_resnet + 1, n_resnet + 1]
+        self._dn_u = nn.ModuleList([nn.ModuleList([GatedResnet(f, "ds", aux_channels=f) for _ in range(c)])
+                                    for c in counts])
+        self._dn_ul = nn.ModuleList([nn.ModuleList([GatedResnet(f, "drs", aux_channels=2 * f) for _ in range(c)])
+                                     for c in counts])
+        self._up_u_conv = nn.ModuleList([ShiftedConv2d(f, f, (2, 3), "ds") for _ in range(2)])
+        self._up_ul_conv = nn.ModuleList([ShiftedConv2d(f, f, (2, 2), "drs") for _ in range(2)])
+        self._out = pg_nn.Conv2d(f, 10 * n_mix, kernel_size=1)
+
+    def forward(self, x):
+        n, _, h, w = x.shape
+        if h % 4 or w % 4:
+            raise ValueError("PixelCNNpp: H and W must be multiples of 4 (two stride-2 levels)")
+        xp = ops.concat_channels([x, torch.ones((n, 1, h, w), device=x.device, dtype=x.dtype)])
+        u = [self._u_in(xp)]
+        ul = [self._ul_in_b(xp, res=self._ul_in_a(xp))]
+        for s in range(3):  # up pass: towards the coarse resolution
+            for ru, rul in zip(self._up_u[s], self._up_ul[s]):
+                u.append(ru(u[-1]))
+                ul.append(rul(ul[-1], aux=u[-1]))
+            if s < 2:
+                u.append(ops.subsample2(self._down_u_conv[s](u[-1])))
+                ul.append(ops.subsample2(self._down_ul_conv[s](ul[-1])))
+        hu, hul = u.pop(), ul.pop()
+        for s in range(3):  # down pass: back to the fine resolution, short-cuts from the up pass
+            for ru, rul in zip(self._dn_u[s], self._dn_ul[s]):
+                hu = ru(hu, aux=u.pop())
+                hul = rul(hul, aux=ops.concat_channels([hu, ul.pop()]))
+            if s < 2:
+                hu = self._up_u_conv[s](ops.zero_insert2(hu))
+                hul = self._up_ul_conv[s](ops.zero_insert2(hul))
+        assert not u and not ul
+        return self._out(hul, in_act="elu")
+
+    def _sample(self, n_samples):
+        raise NotImplementedError("PixelCNNpp: sampling from the logistic mixture is not implemented on this path")
+
+
+def dmol_loss(x, _, preds, n_mix=10):
+    """loss_fn(x, y, preds) of the recipe: images in [0, 1] (the loaders' range) are mapped to [-1, 1]."""
+    return ops.dmol_loss_sum_mean(preds, x * 2.0 - 1.0, n_mix)
+
+
+def reproduce(n_epochs=457, batch_size=16, log_dir="/tmp/run", n_gpus=1, device_id=0, debug_loader=None,
+              n_filters=160, n_resnet=5, n_mix=10):
+    """Training recipe in the shape of the reference's reproduce() functions (there is no PixelCNN++ in the
+    reference): CIFAR-10-shaped batches, the paper's model size by default, Adam lr 1e-3 with the per-batch
+    decay 0.999995 of the paper, the discretized logistic mixture loss. Returns the Trainer."""
+    from pytorch_generative_amd import recipes
+
+    class _Wrapped(PixelCNNpp):  # the loaders deliver [0, 1]; the network sees [-1, 1]
+        def forward(self, x):
+            return super().forward(x * 2.0 - 1.0)
+
+    return recipes.run(
+        lambda: _Wrapped(in_channels=3, n_filters=n_filters, n_resnet=n_resnet, n_mix=n_mix),
+        loaders=lambda b: recipes.datasets.get_cifar10_loaders(b), loss_fn=lambda x, y, p: dmol_loss(x, y, p, n_mix),
+        lr=1e-3, lr_decay=0.999995, n_epochs=n_epochs, batch_size=batch_size, log_dir=log_dir, n_gpus=n_gpus,
+        device_id=device_id, debug_loader=debug_loader)

@@ -1430,3 +1430,75 @@ def phase_split(x):
 
 def phase_merge(xs):
     return _PhaseMerge.apply(xs)
+
+
+# --------------------------------------------------------------------------------------------
+# PixelCNN++ pieces (SURVEY.md §8(f) rank 4; not in the reference)
+# --------------------------------------------------------------------------------------------
+class _ConcatElu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _chk(x, "concat_elu.x")
+        n, c, h, w = x.shape
+        y = torch.empty((n, 2 * c, h, w), device=x.device, dtype=torch.float32)
+        _lib.check(lib.pg_concat_elu_fwd(x.data_ptr(), y.data_ptr(), n, c * h * w, _stream()), "pg_concat_elu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = _chk(dy, "concat_elu.dy")
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(lib.pg_concat_elu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, c * h * w, _stream()),
+                   "pg_concat_elu_bwd")
+        return dx
+
+
+def concat_elu(x):
+    """[elu(x) | elu(-x)] along the channels."""
+    return _ConcatElu.apply(x)
+
+
+class _Resample2(torch.autograd.Function):
+    """up=False: y = x[:, :, ::2, ::2]; up=True: y (2H, 2W) with y[:, :, ::2, ::2] = x and zeros elsewhere.
+    Each is the other's adjoint; both run on pg_phase_split2 (phase 0 of the 2x2 phase decomposition)."""
+
+    @staticmethod
+    def forward(ctx, x, up):
+        ctx.up = up
+        return _Resample2._run(x, up)
+
+    @staticmethod
+    def _run(x, up):
+        lib = _lib.load()
+        x = _chk(x, "resample2.x")
+        n, c, h, w = x.shape
+        if up:
+            xs = torch.zeros((4, n, c, h, w), device=x.device, dtype=torch.float32)
+            xs[0].copy_(x)
+            y = torch.empty((n, c, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
+            _lib.check(lib.pg_phase_split2(y.data_ptr(), xs.data_ptr(), n * c, h, w, 1, _stream()), "pg_phase_split2")
+            return y
+        if h % 2 or w % 2:
+            raise ValueError("subsample2: H and W must be even")
+        xs = torch.empty((4, n, c, h // 2, w // 2), device=x.device, dtype=torch.float32)
+        _lib.check(lib.pg_phase_split2(x.data_ptr(), xs.data_ptr(), n * c, h // 2, w // 2, 0, _stream()),
+                   "pg_phase_split2")
+        return xs[0].clone()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _Resample2._run(dy, not ctx.up), None
+
+
+def subsample2(x):
+    return _Resample2.apply(x, False)
+
+
+def zero_insert2(x):
+    return _Resample2.apply(x, True)
+

@@ -24,6 +24,7 @@ MODEL_DICT = {
     "gated_pixel_cnn": autoregressive.gated_pixel_cnn,
     "image_gpt": autoregressive.image_gpt,
     "pixel_cnn": autoregressive.pixel_cnn,
+    "pixel_cnn_pp": autoregressive.pixel_cnn_pp,
     "pixel_snail": autoregressive.pixel_snail,
     "vae": vae.vae,
     "vd_vae": vae.vd_vae,
