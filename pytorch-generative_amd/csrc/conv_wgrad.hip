@@ -574,6 +574,19 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   hipStream_t st = (hipStream_t)stream;
   const long stride = (long)Cout * Cin * T + Cout;
   const long max_rows = wgrad_max_rows(Cout, Cin);
+  // 1x1 convolutions whose shape the bf16x3 kernel takes (Cout % 64 == 0, Cin % 32 == 0, W % 8 == 0) go there
+  // first (PG_WGRAD_B3_PW=0: the fp32 direct-fragment kernel below, for A/B)
+  static const bool b3_pw = []() { const char* e = getenv("PG_WGRAD_B3_PW"); return !(e && e[0] == '0'); }();
+  if (b3_pw && T == 1 && KH == 1 && KW == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW) {
+    const int g = pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
+                                     Cout, OH, OW, T, tap_dr, tap_dc, in_act, st);
+    PG_REQUIRE(g >= 0, PG_EINVAL, "pg_conv2d_wgrad(bf16x3, 1x1): launch failed");
+    if (g > 0) {
+      launch_reduce(workspace, stride, g, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
+      PG_LAUNCH_CHECK("pg_conv2d_wgrad(reduce)");
+      return 0;
+    }
+  }
   if (T == 1 && KH == 1 && KW == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
       ((OH * OW) % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {
     PwWgArgs p;

@@ -353,7 +353,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   static const bool on = []() { const char* e = getenv("PG_WGRAD_B3"); return !(e && e[0] == '0'); }();
   if (!on) return 0;
   if (IH != OH || IW != OW || OW % 8 != 0 || Cout % WB_CO != 0 || Cin % WB_CI != 0) return 0;
-  if (!(T == 2 || T == 3 || T == 4 || T == 6 || T == 9)) return 0;
+  if (!(T == 1 || T == 2 || T == 3 || T == 4 || T == 6 || T == 9)) return 0;
   if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return 0;
   WbArgs a;
   int min_dr = tap_dr[0], max_dr = tap_dr[0];
@@ -405,6 +405,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
 #define PG_WB(TT) hipLaunchKernelGGL((conv_wgrad_b3_kernel<TT>), grid, dim3(WB_THREADS), shmem, st, a)
   switch (T) {
+    case 1: PG_WB(1); break;
     case 2: PG_WB(2); break;
     case 3: PG_WB(3); break;
     case 4: PG_WB(4); break;

@@ -58,6 +58,9 @@ CONV_CASES = [
     (140, 69, 32, 32, 36, 1, 1, 0, 0, None, None, None, False, True),   # fp32-MFMA kernel (ragged channels), 560 tiles
     (30, 32, 64, 64, 64, 3, 3, 1, 1, None, None, "relu", False, True),  # 64x64 3x3: 22 row tiles per image
     (700, 32, 28, 28, 32, 3, 3, 1, 1, None, "B", "relu", False, True),  # PixelCNN residual conv at bench batch
+    # 1x1 shapes the bf16x3 weight-gradient kernel takes since round 3 (T = 1)
+    (3, 64, 16, 16, 128, 1, 1, 0, 0, None, None, "elu", True, True),
+    (130, 32, 32, 32, 64, 1, 1, 0, 0, None, None, None, False, True),   # several pixel tiles per workgroup
 ]
 
 
