@@ -30,7 +30,14 @@ class CausalResidualBlock(nn.Module):
             pg_nn.Conv2d(in_channels=n_channels // 2, out_channels=n_channels, kernel_size=1),
         )
 
-    def forward(self, x):
+    def forward(self, x, double=False):
+        """double=True (extension) returns x + (x + net(x)) — the block residual AND the model loop's
+        (pixel_cnn.py:52-53, :109) — with both adds in the last convolution's epilogue; x's three readers
+        go through the first convolution's pass-through aliases, so backward has no gradient-sum kernels."""
+        if double:
+            h, x1, x2 = self._net[1](x, in_act="relu", n_skip=2)
+            h = self._net[3](h, in_act="relu")
+            return self._net[5](h, in_act="relu", res=x1, res2=x2)
         h = self._net[1](x, in_act="relu")
         h = self._net[3](h, in_act="relu")
         return self._net[5](h, in_act="relu", res=x)
@@ -72,7 +79,7 @@ class PixelCNN(base.AutoregressiveModel):
     def forward(self, x):
         x = self._input(x)
         for layer in self._causal_layers:
-            x = ops.add(x, layer(x))
+            x = layer(x, double=True)
         return self._head[3](self._head[1](x, in_act="relu"), in_act="relu")
 
 

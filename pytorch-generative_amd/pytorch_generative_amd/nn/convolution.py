@@ -103,15 +103,23 @@ class Conv2d(nn.Conv2d):
             band[:, :, :k, :].copy_(band[:, :, 1:, :].clone())
         return y
 
+    def two_residuals_ok(self, x, crop=None):
+        return (not self._down2) and ops.RowDecode.current is None and ops.conv_two_residuals_ok(
+            x, self.weight, self._conv_spec(), crop)
+
     def forward(self, x, *, crop=None, in_act=None, res=None, out_act=None, out_pre_scaled=False,
-                in_post=None, n_skip=0):
+                in_post=None, n_skip=0, res2=None):
         """n_skip > 0 (extension) returns (y, x_1, .., x_n): pass-through aliases of x for the skip
         connections that also read x, see ops.conv2d_taps."""
+        if res2 is not None and not self.two_residuals_ok(x, crop):
+            y = self.forward(x, crop=crop, in_act=in_act, res=res, out_act=out_act,
+                             out_pre_scaled=out_pre_scaled, in_post=in_post, n_skip=n_skip)
+            return (ops.add(y[0], res2),) + tuple(y[1:]) if n_skip else ops.add(y, res2)
         if n_skip:
             ctx = ops.RowDecode.current
             if ctx is not None or self._down2 or not x.requires_grad:
                 y = self.forward(x, crop=crop, in_act=in_act, res=res, out_act=out_act,
-                                 out_pre_scaled=out_pre_scaled, in_post=in_post)
+                                 out_pre_scaled=out_pre_scaled, in_post=in_post, res2=res2)
                 return (y,) + (x,) * n_skip
         ctx = ops.RowDecode.current
         if ctx is not None:
@@ -135,7 +143,7 @@ class Conv2d(nn.Conv2d):
         return ops.conv2d_taps(
             x, self.weight, self.bias, self._conv_spec(), out_hw=crop, in_act=_ACTS[in_act],
             res=res, weight_param=self.weight, bias_param=self.bias, out_act=_ACTS[out_act],
-            out_pre_scaled=out_pre_scaled, in_post=_ACTS[in_post], n_skip=n_skip,
+            out_pre_scaled=out_pre_scaled, in_post=_ACTS[in_post], n_skip=n_skip, res2=res2,
         )
 
     def _forward_down2(self, x, in_act, res):

@@ -179,7 +179,7 @@ def _pack(lib, weight, spec, transpose):
 class _ConvTaps(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, res, spec, out_hw, in_act, gw, gb, out_act=ACT_NONE,
-                out_pre_scaled=False, in_post=ACT_NONE, n_skip=0):
+                out_pre_scaled=False, in_post=ACT_NONE, n_skip=0, res2=None):
         lib = _lib.load()
         x = _chk(x, "conv2d.x")
         weight = _chk(weight, "conv2d.weight")
@@ -196,6 +196,13 @@ class _ConvTaps(torch.autograd.Function):
                 raise ValueError("conv2d: residual shape mismatch")
         out = torch.empty((n, cout, oh, ow), device=x.device, dtype=torch.float32)
         mfma = _use_mfma(lib, cin, cout, spec, (oh, ow), iw)
+        if res2 is not None:
+            res2 = _chk(res2, "conv2d.res2")
+            if res is None or tuple(res2.shape) != (n, cout, oh, ow):
+                raise ValueError("conv2d: res2 needs res and the output's shape")
+            if not (mfma == CONV_FMT_B3 and cout >= 64):
+                raise ValueError("conv2d: a second residual needs the bf16x3 kernel with >= 64 output channels "
+                                 "(check ops.conv_two_residuals_ok first)")
         if (out_act != ACT_NONE or in_post != ACT_NONE) and not mfma:
             raise ValueError("conv2d: fused output activations need the matrix-core path "
                              "(check ops.conv_mfma_ok first)")
@@ -207,10 +214,10 @@ class _ConvTaps(torch.autograd.Function):
             else:
                 wfrag = _pack_frag(lib, weight, spec, False, mfma)
             _lib.check(
-                lib.pg_conv2d_mfma(
+                lib.pg_conv2d_mfma_ex(
                     x.data_ptr(), wfrag.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih,
                     iw, cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, 0, ACT_NONE,
-                    out_act, mfma, _stream(),
+                    out_act, mfma, _p(res2), 0, 0, _stream(),
                 ),
                 "pg_conv2d_mfma",
             )
@@ -230,6 +237,7 @@ class _ConvTaps(torch.autograd.Function):
         else:
             ctx.save_for_backward(x, weight)
         ctx.spec, ctx.in_act, ctx.has_bias, ctx.has_res = spec, in_act, bias is not None, res is not None
+        ctx.has_res2 = res2 is not None
         ctx.gw, ctx.gb = gw, gb
         ctx.out_act, ctx.out_pre_scaled, ctx.in_post = out_act, out_pre_scaled, in_post
         ctx.n_skip = n_skip
@@ -243,7 +251,8 @@ class _ConvTaps(torch.autograd.Function):
     def backward(ctx, dy, *d_skips):
         need = ctx.needs_input_grad
         return _ConvTaps.backward_impl(ctx, dy, need[0], need[1], ctx.has_bias and need[2],
-                                       d_skips=d_skips) + (None, None, None, None)
+                                       d_skips=d_skips) + (None, None, None, None,
+                                                           dy if getattr(ctx, "has_res2", False) else None)
 
     @staticmethod
     def backward_impl(ctx, dy, need_dx, need_w, need_b, d_skips=()):
@@ -449,9 +458,18 @@ def conv_mfma_ok(x, weight, spec, out_hw=None):
                 and _use_mfma(lib, cout, cin, spec, (x.shape[2], x.shape[3]), out_hw[1]))
 
 
+def conv_two_residuals_ok(x, weight, spec, out_hw=None):
+    """True if conv2d_taps(..., res=, res2=) is available for this problem (bf16x3 kernel, >= 64 output channels)."""
+    if out_hw is None:
+        out_hw = spec.full_out(x.shape[2], x.shape[3])
+    cout, cin = weight.shape[0], weight.shape[1]
+    return bool(x.is_cuda and cout >= 64
+                and _use_mfma(_lib.load(), cin, cout, spec, out_hw, x.shape[3]) == CONV_FMT_B3)
+
+
 def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
                 weight_param=None, bias_param=None, out_act=ACT_NONE, out_pre_scaled=False,
-                in_post=ACT_NONE, n_skip=0):
+                in_post=ACT_NONE, n_skip=0, res2=None):
     """y = out_act(conv(in_act(x)) + bias) (+ res), cropped to out_hw (defaults to the full extent).
 
     out_act (matrix-core path only): activation fused into the epilogue; its backward recovers act'
@@ -472,11 +490,11 @@ def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
         raise ValueError(f"conv2d: requested output {out_hw} exceeds the full extent {full}")
     if n_skip and not FUSE_SKIP:
         y = _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act, _sink(weight_param),
-                            _sink(bias_param), out_act, bool(out_pre_scaled), in_post, 0)
+                            _sink(bias_param), out_act, bool(out_pre_scaled), in_post, 0, res2)
         return (y,) + (x,) * int(n_skip)
     return _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act,
                            _sink(weight_param), _sink(bias_param), out_act, bool(out_pre_scaled),
-                           in_post, int(n_skip))
+                           in_post, int(n_skip), res2)
 
 
 # --------------------------------------------------------------------------------------------
