@@ -55,17 +55,23 @@ class GatedPixelCNNLayer(nn.Module):
             in_channels=out_channels, out_channels=out_channels, kernel_size=1
         )
 
-    def forward(self, vstack_input, hstack_input):
+    def forward(self, vstack_input, hstack_input, skip_acc=None):
+        """skip_acc (extension): the running sum of the skip connections, added in `_hstack_skip`'s epilogue
+        (gated_pixel_cnn.py:186-189 accumulates it in place). Every tensor with two readers goes through its
+        first reader's convolution with a pass-through alias for the second (ops.conv2d_taps, n_skip): no
+        gradient-sum kernels in backward."""
         _, _, h, w = vstack_input.shape
         # vertical stack
-        vconv = self._vstack_Nx1(self._vstack_1xN(vstack_input), crop=(h, w))
-        link = self._link(vconv)
-        vstack = self._activation(self._vstack_1x1(vstack_input, res=vconv))
+        t, vin = self._vstack_1xN(vstack_input, n_skip=1)
+        vconv = self._vstack_Nx1(t, crop=(h, w))
+        link, vconv_s = self._link(vconv, n_skip=1)
+        vstack = self._activation(self._vstack_1x1(vin, res=vconv_s))
         # horizontal stack
-        hstack = self._activation(self._hstack_1xN(hstack_input, crop=(h, w), res=link))
-        skip = self._hstack_skip(hstack)
+        hx, hin = self._hstack_1xN(hstack_input, crop=(h, w), res=link, n_skip=1)
+        hstack = self._activation(hx)
+        skip, hstack_s = self._hstack_skip(hstack, res=skip_acc, n_skip=1)
         # a causal (mask_center) layer must not see its own input through the residual
-        hstack = self._hstack_residual(hstack, res=None if self._mask_center else hstack_input)
+        hstack = self._hstack_residual(hstack_s, res=None if self._mask_center else hin)
         return vstack, hstack, skip
 
 
@@ -108,8 +114,7 @@ class GatedPixelCNN(base.AutoregressiveModel):
     def forward(self, x):
         vstack, hstack, skip_connections = self._input(x, x)
         for gated_layer in self._gated_layers:
-            vstack, hstack, skip = gated_layer(vstack, hstack)
-            skip_connections = ops.add(skip_connections, skip)
+            vstack, hstack, skip_connections = gated_layer(vstack, hstack, skip_acc=skip_connections)
         return self._head[3](self._head[1](skip_connections, in_act="relu"), in_act="relu")
 
 
