@@ -111,15 +111,19 @@ __device__ __forceinline__ u32x4 shift_left1(const u32x4 d, unsigned int next) {
 
 #define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
 
-template <int T>
+// MR = MFMA row tiles (16 dy channels) per wave: 2 -> a workgroup owns 64 co (the shape the kernel was built for),
+// 1 -> 32 co (round 3: the 32-channel 3x3 convolutions of PixelCNN / VD-VAE / beta-VAE, which otherwise stay on
+// the fp32 kernel; half the MFMA work per staged x tile)
+template <int T, int MR = 2>
 __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbArgs a) {
+  constexpr int COT = 2 * MR;  // dy channel tiles per workgroup
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave & 1, wi = wave >> 1;   // co half (2 row tiles), ci tile of this wave
-  const int co0 = blockIdx.y * WB_CO, ci0 = blockIdx.z * WB_CI;
-  const int dplane = 4 * a.dpb * 16;         // entries per dy piece plane
+  const int co0 = blockIdx.y * (16 * COT), ci0 = blockIdx.z * WB_CI;
+  const int dplane = COT * a.dpb * 16;       // entries per dy piece plane
   const int xplane = 2 * a.xpb * 16;         // entries per x (copy, piece) plane
 
   // ---- staging slots: the same (channel, tile row, column block) for every tile
@@ -226,10 +230,10 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     }                                                                                              \
   }
 
-  f32x4 acc[2][T];
-  f32x4 accb[2];
+  f32x4 acc[MR][T];
+  f32x4 accb[MR];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
+  for (int m = 0; m < MR; ++m) {
     accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
   for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
 
   const bf16x8* L = reinterpret_cast<const bf16x8*>(lds16) + lane;
-  const int a_base = 2 * wc * a.dpb * 16;
+  const int a_base = MR * wc * a.dpb * 16;
   int b_base[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) b_base[t] = a.x_off16 + a.tap_base[t] + wi * a.xpb * 16;
@@ -291,14 +295,14 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     if (!(a.dbg & 4))
     for (int ks = 0; ks < a.ksteps; ++ks) {
       const bf16x8* Lk = L + ks * 64;
-      bf16x8 af[2][3];
+      bf16x8 af[MR][3];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[m][p] = Lk[a_base + (p * 4 + m) * a.dpb * 16];
+        for (int p = 0; p < 3; ++p) af[m][p] = Lk[a_base + (p * COT + m) * a.dpb * 16];
       if (bias_wave) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
           for (int p = 0; p < 3; ++p) accb[m] = MFMA16B(af[m][p], ones, accb[m]);
       }
@@ -308,7 +312,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[p] = Lk[b_base[t] + p * xplane];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MR; ++m) {
           f32x4 c = acc[m][t];
           c = MFMA16B(af[m][2], bf[0], c);  // l.h
           c = MFMA16B(af[m][0], bf[2], c);  // h.l
@@ -328,8 +332,8 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
   float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
   const int ci = ci0 + wi * 16 + (lane & 15);
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int co_b = co0 + (2 * wc + m) * 16 + (lane >> 4) * 4;
+  for (int m = 0; m < MR; ++m) {
+    const int co_b = co0 + (MR * wc + m) * 16 + (lane >> 4) * 4;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -352,7 +356,10 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
                        const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st) {
   static const bool on = []() { const char* e = getenv("PG_WGRAD_B3"); return !(e && e[0] == '0'); }();
   if (!on) return 0;
-  if (IH != OH || IW != OW || OW % 8 != 0 || Cout % WB_CO != 0 || Cin % WB_CI != 0) return 0;
+  if (IH != OH || IW != OW || OW % 8 != 0 || Cout % 32 != 0 || Cin % WB_CI != 0) return 0;
+  const int MR = Cout % WB_CO == 0 ? 2 : 1;  // 64 or 32 dy channels per workgroup
+  const int wb_co = 32 * MR;
+  if (MR == 1 && T == 1) return 0;  // 1x1 with 32 output channels: too little MFMA work per staged tile
   if (!(T == 1 || T == 2 || T == 3 || T == 4 || T == 6 || T == 9)) return 0;
   if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return 0;
   WbArgs a;
@@ -375,7 +382,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   int TR = 0;
   for (int tr = 1; tr <= OH + 3; ++tr) {
     if ((tr * PBR) % 4 != 0) continue;
-    const long dslots = (long)WB_CO * tr * PBR, xslots = (long)WB_CI * (tr + hr) * PBR;
+    const long dslots = (long)wb_co * tr * PBR, xslots = (long)WB_CI * (tr + hr) * PBR;
     const long bytes = (3 * dslots + 3L * a.ndc * xslots) * 16;
     if (dslots > WB_DS * WB_THREADS || xslots > WB_XS * WB_THREADS || bytes > WB_LDS_BUDGET) break;
     TR = tr;
@@ -388,8 +395,8 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   a.tiles_per_img = (OH + TR - 1) / TR;
   a.total_tiles = N * a.tiles_per_img;
   a.PBR = PBR; a.dpb = TR * PBR; a.xpb = a.xh * PBR; a.ksteps = a.dpb / 4;
-  a.dslots = WB_CO * a.dpb; a.xslots = WB_CI * a.xpb;
-  a.x_off16 = 3 * 4 * a.dpb * 16;
+  a.dslots = wb_co * a.dpb; a.xslots = WB_CI * a.xpb;
+  a.x_off16 = 3 * (2 * MR) * a.dpb * 16;
   a.in_act = in_act; a.has_bias = has_bias;
   static const int dbg = []() { const char* e = getenv("PG_WB_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
@@ -397,13 +404,17 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   for (int t = 0; t < T; ++t) a.tap_base[t] = copy_of[t] * 3 * xplane + (tap_dr[t] - min_dr) * PBR * 16;
   for (int t = T; t < WB_MAXT; ++t) a.tap_base[t] = 0;
   const size_t shmem = ((size_t)a.x_off16 + (size_t)a.ndc * 3 * xplane) * 16;
-  const int co_chunks = Cout / WB_CO, ci_chunks = Cin / WB_CI;
+  const int co_chunks = Cout / wb_co, ci_chunks = Cin / WB_CI;
   long G = 512 / ((long)co_chunks * ci_chunks);
   if (G < 16) G = 16;
   if (G > a.total_tiles) G = a.total_tiles;
   if (G > max_rows) G = max_rows;
   dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
-#define PG_WB(TT) hipLaunchKernelGGL((conv_wgrad_b3_kernel<TT>), grid, dim3(WB_THREADS), shmem, st, a)
+#define PG_WB(TT)                                                                                        \
+  {                                                                                                      \
+    if (MR == 2) hipLaunchKernelGGL((conv_wgrad_b3_kernel<TT, 2>), grid, dim3(WB_THREADS), shmem, st, a); \
+    else hipLaunchKernelGGL((conv_wgrad_b3_kernel<TT, 1>), grid, dim3(WB_THREADS), shmem, st, a);         \
+  }
   switch (T) {
     case 1: PG_WB(1); break;
     case 2: PG_WB(2); break;

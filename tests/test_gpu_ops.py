@@ -58,6 +58,10 @@ CONV_CASES = [
     (140, 69, 32, 32, 36, 1, 1, 0, 0, None, None, None, False, True),   # fp32-MFMA kernel (ragged channels), 560 tiles
     (30, 32, 64, 64, 64, 3, 3, 1, 1, None, None, "relu", False, True),  # 64x64 3x3: 22 row tiles per image
     (700, 32, 28, 28, 32, 3, 3, 1, 1, None, "B", "relu", False, True),  # PixelCNN residual conv at bench batch
+    # 32 output channels on the bf16x3 weight-gradient kernel (round 3: one MFMA row tile per wave)
+    (3, 32, 16, 16, 32, 3, 3, 1, 1, None, "B", "relu", False, True),
+    (20, 64, 32, 32, 32, 3, 3, 1, 1, None, None, "gelu", True, True),
+    (2, 32, 8, 8, 32, 3, 3, 1, 1, None, None, "gelu", False, True),     # VD-VAE 8x8 level
     # 1x1 shapes the bf16x3 weight-gradient kernel takes since round 3 (T = 1)
     (3, 64, 16, 16, 128, 1, 1, 0, 0, None, None, "elu", True, True),
     (130, 32, 32, 32, 64, 1, 1, 0, 0, None, None, None, False, True),   # several pixel tiles per workgroup
