@@ -175,9 +175,19 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
     launch, fallback, step = "eager", None, eager_step
     if use_graph:
         try:
-            gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
+            try:
+                gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
+            except Exception as e1:  # capture with the collective inside failed: retry with it between two graphs
+                if reducer is None or not reducer.capturable:
+                    raise
+                print(f"[bench] rank {env.rank}: capture with the all-reduce inside the graph failed "
+                      f"({type(e1).__name__}: {e1}); retrying with two graphs around an eager collective",
+                      file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                reducer.force_split = True
+                gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
             step = lambda: gstep()  # noqa: E731
-            launch = "hipGraph replay"
+            launch = "hipGraph replay" if not gstep.split else "two hipGraphs around an eager all-reduce"
         except Exception as e:  # e.g. capture refused next to a live RCCL communicator
             fallback = f"{type(e).__name__}: {e}"
             print(f"[bench] WARNING rank {env.rank}: hipGraph capture of {name} FAILED ({fallback}); "
@@ -213,7 +223,7 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
         "global_batch": batch * env.world, "launch": launch, "graph_fallback": fallback,
         "grad_exchange": None if reducer is None else
         f"{reducer.transport} all-reduce of the flat gradient ({opt.flat_grad.numel() * 4 / 1e6:.2f} MB), "
-        + ("inside the step graph" if (launch != "eager" and reducer.capturable) else "eager"),
+        + ("inside the step graph" if launch == "hipGraph replay" and reducer.capturable else "eager launch"),
         "loss_nats_per_image": loss_val, "bits_per_dim": loss_val / (dims * LN2),
         # whole step against the per-image algorithmic work of SURVEY.md §8(d)
         "step_hbm_gbps_algorithmic": value * w["mbytes"] * 1e6 / 1e9,

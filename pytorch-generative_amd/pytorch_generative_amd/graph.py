@@ -47,7 +47,9 @@ class GraphedTrainStep:
             forward_fn = lambda x, y: loss_fn(x, model(x))  # noqa: E731
         self.forward_fn = forward_fn
         self.reduce = reducer is not None and reducer.active
-        self.split = self.reduce and not reducer.capturable
+        # force_split: keep the collective OUT of the graph even if it is capturable (fallback when a
+        # capture next to a live multi-rank communicator fails: two graphs around an eager collective)
+        self.split = self.reduce and (not reducer.capturable or getattr(reducer, "force_split", False))
         self.static_x = example_x.clone()
         self.static_y = None if example_y is None else example_y.clone()
         self.static_out = None
