@@ -538,6 +538,11 @@ inline int pad_stride(int s) {  // smallest s' >= s with s' % 32 == 2
 
 }  // namespace
 
+// conv_wgrad_small.hip: input layers (<= 4 input channels, many taps); same return convention
+int pg_wgrad_small_launch(const float* x, const float* dy, float* part, long part_stride, long max_rows,
+                          int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
+                          const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st);
+
 // conv_wgrad_b3.hip: the bf16x3 kernel for the shapes it takes (returns the partial rows it wrote)
 int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_stride, long max_rows,
                        int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
@@ -607,6 +612,16 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     launch_reduce(workspace, stride, (int)gx, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
     PG_LAUNCH_CHECK("pg_conv2d_wgrad(reduce)");
     return 0;
+  }
+  {
+    const int g = pg_wgrad_small_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
+                                        Cout, OH, OW, T, tap_dr, tap_dc, in_act, st);
+    PG_REQUIRE(g >= 0, PG_EINVAL, "pg_conv2d_wgrad(input layer): launch failed");
+    if (g > 0) {
+      launch_reduce(workspace, stride, g, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
+      PG_LAUNCH_CHECK("pg_conv2d_wgrad(reduce)");
+      return 0;
+    }
   }
   {
     const int g = pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
