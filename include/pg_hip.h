@@ -325,6 +325,22 @@ int pg_gpt_block_tail_bwd(const float* o, const float* x, const float* wp, const
                           float* dw2, float* db2, int N, int C, int Hd, int L, float eps,
                           float* workspace, size_t workspace_floats, void* stream);
 size_t pg_gpt_block_tail_bwd_workspace_floats(int N, int L);
+/* One reduce launch per block instead of two (at the reference's batch 64 the reductions were 6 % of the
+ * step): _tail_bwd_partial runs the tail kernel and leaves its partial rows in `workspace` (keep it alive);
+ * _head_bwd_with_tail of the SAME block then reduces both kernels' rows in one launch. Results identical to
+ * pg_gpt_block_tail_bwd + pg_gpt_block_head_bwd (same summation order). */
+int pg_gpt_block_tail_bwd_partial(const float* o, const float* x, const float* wp, const float* bp,
+                                  const float* ln_w, const float* ln_b, const float* w1, const float* b1,
+                                  const float* w2, const float* dx_new, float* d_o, float* gx, int N, int Cc,
+                                  int Hd, int L, float eps, float* workspace, size_t workspace_floats,
+                                  void* stream);
+int pg_gpt_block_head_bwd_with_tail(const float* x, const float* ln_w, const float* ln_b, const float* wq,
+                                    const float* wkv, const float* dqkv, const float* gx, float* dx,
+                                    float* dln_w, float* dln_b, float* dwq, float* dbq, float* dwkv,
+                                    float* dbkv, int N, int Cc, int L, float eps, float* workspace,
+                                    size_t workspace_floats, const float* tail_workspace, float* t_dw1,
+                                    float* t_db1, float* t_dw2, float* t_db2, float* t_dwp, float* t_dbp,
+                                    float* t_dln_w, float* t_dln_b, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Incremental autoregressive sampling (models/base.py:97-120 runs H*W full forwards; the causal

@@ -495,6 +495,39 @@ __global__ void __launch_bounds__(256) seg_reduce_kernel(const SegArgs a) {
   }
 }
 
+// Two segmented reductions in ONE launch (round 3): the tail and head kernels of a block each leave rows of
+// partial weight-gradient sums; at the reference's batch 64 the 16 reduce launches of a step were 6 % of it.
+struct SegArgs2 { SegArgs j[2]; int blocks0; };
+__global__ void __launch_bounds__(256) seg_reduce2_kernel(const SegArgs2 a2) {
+  __shared__ float red[32][9];
+  const bool second = (int)blockIdx.x >= a2.blocks0;
+  const SegArgs& a = a2.j[second ? 1 : 0];
+  const int blk = second ? blockIdx.x - a2.blocks0 : blockIdx.x;
+  const int sl = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int s = blk * 8 + sl;
+  float a0 = 0.f, a1 = 0.f;
+  if (s < a.stride) {
+    const float* p = a.part + s;
+    int r = rg;
+    for (; r + 32 < a.rows; r += 64) {
+      a0 += p[(size_t)r * a.stride];
+      a1 += p[(size_t)(r + 32) * a.stride];
+    }
+    if (r < a.rows) a0 += p[(size_t)r * a.stride];
+  }
+  red[rg][sl] = a0 + a1;
+  __syncthreads();
+  if (rg != 0 || s >= a.stride) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) acc += red[r][sl];
+  int begin = 0;
+  for (int k = 0; k < a.nseg; ++k) {
+    if (s < a.end[k]) { a.dst[k][s - begin] += acc; return; }
+    begin = a.end[k];
+  }
+}
+
 // Workgroups per launch: whole rounds of resident waves (256 CUs x 4 SIMDs; the kernels hold 5 / 3 / 4 / 2
 // waves per SIMD by their register counts), at least `min_tiles` tiles per wave. which: 0 head fwd,
 // 1 head bwd, 2 tail fwd, 3 tail bwd. PG_BLOCK_GRID="a,b,c,d" overrides the caps (tuning).
@@ -565,11 +598,26 @@ PG_EXPORT int pg_gpt_block_head_fwd(const float* x, const float* ln_w, const flo
   return 0;
 }
 
-PG_EXPORT int pg_gpt_block_head_bwd(const float* x, const float* ln_w, const float* ln_b, const float* wq,
-                                    const float* wkv, const float* dqkv, const float* gx, float* dx,
-                                    float* dln_w, float* dln_b, float* dwq, float* dbq, float* dwkv,
-                                    float* dbkv, int N, int Cc, int L, float eps, float* workspace,
-                                    size_t workspace_floats, void* stream) {
+namespace {
+SegArgs tail_seg_args(const float* workspace, int rows, float* dw1, float* db1, float* dw2, float* db2,
+                      float* dwp, float* dbp, float* dln_w, float* dln_b) {
+  SegArgs r = {};
+  r.part = workspace; r.rows = rows; r.stride = T_PART; r.nseg = 8;
+  r.end[0] = T_B1; r.dst[0] = dw1;
+  r.end[1] = T_W2; r.dst[1] = db1;
+  r.end[2] = T_B2; r.dst[2] = dw2;
+  r.end[3] = T_WP; r.dst[3] = db2;
+  r.end[4] = T_BP; r.dst[4] = dwp;
+  r.end[5] = T_G2; r.dst[5] = dbp;
+  r.end[6] = T_BE2; r.dst[6] = dln_w;
+  r.end[7] = T_PART; r.dst[7] = dln_b;
+  return r;
+}
+
+int head_bwd_impl(const float* x, const float* ln_w, const float* ln_b, const float* wq, const float* wkv,
+                  const float* dqkv, const float* gx, float* dx, float* dln_w, float* dln_b, float* dwq,
+                  float* dbq, float* dwkv, float* dbkv, int N, int Cc, int L, float eps, float* workspace,
+                  size_t workspace_floats, const SegArgs* tail, void* stream) {
   PG_REQUIRE(x && ln_w && ln_b && wq && wkv && dqkv && gx && dx && dln_w && dln_b && dwq && dbq && dwkv &&
                  dbkv && workspace, PG_EINVAL, "pg_gpt_block_head_bwd: null pointer");
   int rc = check_shape("pg_gpt_block_head_bwd", N, Cc, L);
@@ -594,9 +642,42 @@ PG_EXPORT int pg_gpt_block_head_bwd(const float* x, const float* ln_w, const flo
   r.end[3] = H_G1; r.dst[3] = dbkv;
   r.end[4] = H_BE1; r.dst[4] = dln_w;
   r.end[5] = H_PART; r.dst[5] = dln_b;
-  hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)((H_PART + 7) / 8)), dim3(256), 0, st, r);
+  if (tail) {  // one launch for this block's two reductions
+    SegArgs2 r2;
+    r2.j[0] = r; r2.j[1] = *tail; r2.blocks0 = (H_PART + 7) / 8;
+    hipLaunchKernelGGL(seg_reduce2_kernel, dim3((unsigned)(r2.blocks0 + (T_PART + 7) / 8)), dim3(256), 0, st, r2);
+  } else {
+    hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)((H_PART + 7) / 8)), dim3(256), 0, st, r);
+  }
   PG_LAUNCH_CHECK("pg_gpt_block_head_bwd(reduce)");
   return 0;
+}
+}  // namespace
+
+PG_EXPORT int pg_gpt_block_head_bwd(const float* x, const float* ln_w, const float* ln_b, const float* wq,
+                                    const float* wkv, const float* dqkv, const float* gx, float* dx,
+                                    float* dln_w, float* dln_b, float* dwq, float* dbq, float* dwkv,
+                                    float* dbkv, int N, int Cc, int L, float eps, float* workspace,
+                                    size_t workspace_floats, void* stream) {
+  return head_bwd_impl(x, ln_w, ln_b, wq, wkv, dqkv, gx, dx, dln_w, dln_b, dwq, dbq, dwkv, dbkv, N, Cc, L, eps,
+                       workspace, workspace_floats, nullptr, stream);
+}
+
+// head backward + the reduction a preceding pg_gpt_block_tail_bwd_partial of the SAME block left undone
+PG_EXPORT int pg_gpt_block_head_bwd_with_tail(const float* x, const float* ln_w, const float* ln_b, const float* wq,
+                                              const float* wkv, const float* dqkv, const float* gx, float* dx,
+                                              float* dln_w, float* dln_b, float* dwq, float* dbq, float* dwkv,
+                                              float* dbkv, int N, int Cc, int L, float eps, float* workspace,
+                                              size_t workspace_floats, const float* tail_workspace, float* t_dw1,
+                                              float* t_db1, float* t_dw2, float* t_db2, float* t_dwp, float* t_dbp,
+                                              float* t_dln_w, float* t_dln_b, void* stream) {
+  PG_REQUIRE(tail_workspace && t_dw1 && t_db1 && t_dw2 && t_db2 && t_dwp && t_dbp && t_dln_w && t_dln_b, PG_EINVAL,
+             "pg_gpt_block_head_bwd_with_tail: null pointer");
+  if (int rc = check_shape("pg_gpt_block_head_bwd_with_tail", N, Cc, L)) return rc;
+  const SegArgs tail = tail_seg_args(tail_workspace, bwd_blocks(N, L), t_dw1, t_db1, t_dw2, t_db2, t_dwp, t_dbp,
+                                     t_dln_w, t_dln_b);
+  return head_bwd_impl(x, ln_w, ln_b, wq, wkv, dqkv, gx, dx, dln_w, dln_b, dwq, dbq, dwkv, dbkv, N, Cc, L, eps,
+                       workspace, workspace_floats, &tail, stream);
 }
 
 PG_EXPORT int pg_gpt_block_tail_fwd(const float* o, const float* x, const float* wp, const float* bp,
@@ -617,12 +698,13 @@ PG_EXPORT int pg_gpt_block_tail_fwd(const float* o, const float* x, const float*
   return 0;
 }
 
-PG_EXPORT int pg_gpt_block_tail_bwd(const float* o, const float* x, const float* wp, const float* bp,
+namespace {
+int tail_bwd_impl(const float* o, const float* x, const float* wp, const float* bp,
                                     const float* ln_w, const float* ln_b, const float* w1, const float* b1,
                                     const float* w2, const float* dx_new, float* d_o, float* gx,
                                     float* dwp, float* dbp, float* dln_w, float* dln_b, float* dw1,
                                     float* db1, float* dw2, float* db2, int N, int Cc, int Hd, int L,
-                                    float eps, float* workspace, size_t workspace_floats, void* stream) {
+                                    float eps, float* workspace, size_t workspace_floats, bool reduce_now, void* stream) {
   PG_REQUIRE(o && x && wp && bp && ln_w && ln_b && w1 && b1 && w2 && dx_new && d_o && gx && dwp && dbp &&
                  dln_w && dln_b && dw1 && db1 && dw2 && db2 && workspace, PG_EINVAL,
              "pg_gpt_block_tail_bwd: null pointer");
@@ -645,17 +727,32 @@ PG_EXPORT int pg_gpt_block_tail_bwd(const float* o, const float* x, const float*
   (void)attr;  // thread-safe one-time opt-in
   hipLaunchKernelGGL(tail_bwd_kernel, dim3((unsigned)blocks), dim3(GB_THREADS), shmem, st, a);
   PG_LAUNCH_CHECK("pg_gpt_block_tail_bwd");
-  SegArgs r = {};
-  r.part = workspace; r.rows = blocks; r.stride = T_PART; r.nseg = 8;
-  r.end[0] = T_B1; r.dst[0] = dw1;
-  r.end[1] = T_W2; r.dst[1] = db1;
-  r.end[2] = T_B2; r.dst[2] = dw2;
-  r.end[3] = T_WP; r.dst[3] = db2;
-  r.end[4] = T_BP; r.dst[4] = dwp;
-  r.end[5] = T_G2; r.dst[5] = dbp;
-  r.end[6] = T_BE2; r.dst[6] = dln_w;
-  r.end[7] = T_PART; r.dst[7] = dln_b;
+  if (!reduce_now) return 0;  // the partial rows stay in `workspace` for pg_gpt_block_head_bwd_with_tail
+  const SegArgs r = tail_seg_args(workspace, blocks, dw1, db1, dw2, db2, dwp, dbp, dln_w, dln_b);
   hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)((T_PART + 7) / 8)), dim3(256), 0, st, r);
   PG_LAUNCH_CHECK("pg_gpt_block_tail_bwd(reduce)");
   return 0;
+}
+}  // namespace
+
+PG_EXPORT int pg_gpt_block_tail_bwd(const float* o, const float* x, const float* wp, const float* bp,
+                                    const float* ln_w, const float* ln_b, const float* w1, const float* b1,
+                                    const float* w2, const float* dx_new, float* d_o, float* gx,
+                                    float* dwp, float* dbp, float* dln_w, float* dln_b, float* dw1,
+                                    float* db1, float* dw2, float* db2, int N, int Cc, int Hd, int L,
+                                    float eps, float* workspace, size_t workspace_floats, void* stream) {
+  return tail_bwd_impl(o, x, wp, bp, ln_w, ln_b, w1, b1, w2, dx_new, d_o, gx, dwp, dbp, dln_w, dln_b, dw1, db1, dw2,
+                       db2, N, Cc, Hd, L, eps, workspace, workspace_floats, true, stream);
+}
+
+// the tail kernel only: its rows of partial weight-gradient sums stay in `workspace` (which must stay alive) until
+// pg_gpt_block_head_bwd_with_tail of the same block reduces them together with its own
+PG_EXPORT int pg_gpt_block_tail_bwd_partial(const float* o, const float* x, const float* wp, const float* bp,
+                                            const float* ln_w, const float* ln_b, const float* w1, const float* b1,
+                                            const float* w2, const float* dx_new, float* d_o, float* gx, int N,
+                                            int Cc, int Hd, int L, float eps, float* workspace,
+                                            size_t workspace_floats, void* stream) {
+  float* dummy = workspace;  // the gradient destinations are not touched without the reduction
+  return tail_bwd_impl(o, x, wp, bp, ln_w, ln_b, w1, b1, w2, dx_new, d_o, gx, dummy, dummy, dummy, dummy, dummy, dummy,
+                       dummy, dummy, N, Cc, Hd, L, eps, workspace, workspace_floats, false, stream);
 }

@@ -63,6 +63,8 @@ SIGNATURES = {
     "pg_gpt_block_tail_fwd": (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_i, c_flt, c_s]),
     "pg_gpt_block_tail_bwd": (c_i, [c_f] * 20 + [c_i, c_i, c_i, c_i, c_flt, c_f, c_z, c_s]),
     "pg_gpt_block_tail_bwd_workspace_floats": (c_z, [c_i, c_i]),
+    "pg_gpt_block_tail_bwd_partial": (c_i, [c_f] * 12 + [c_i, c_i, c_i, c_i, c_flt, c_f, c_z, c_s]),
+    "pg_gpt_block_head_bwd_with_tail": (c_i, [c_f] * 14 + [c_i, c_i, c_i, c_flt, c_f, c_z] + [c_f] * 9 + [c_s]),
     "pg_sample_embed": (c_i, [c_f] * 5 + [c_i] * 10 + [c_f, c_s]),
     "pg_attn_decode": (c_i, [c_f] * 4 + [c_i] * 8 + [c_f, c_s]),
     "pg_mlp_gelu_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_s]),

@@ -43,10 +43,11 @@ class TransformerBlock(nn.Module):
         if not self._fused_ok(x):
             return ops.add(x, self.forward(x))
         attn = self._attn
-        qkv, xs = ops.gpt_block_head(x, self._ln1, attn._q, attn._kv)
+        pair = {}  # lets the block's two backward kernels share one weight-gradient reduction launch
+        qkv, xs = ops.gpt_block_head(x, self._ln1, attn._q, attn._kv, pair)
         o = ops.causal_attention_qkv(qkv, attn._n_heads, attn._embed_channels, attn._out_channels,
                                      attn._mask_center)
-        return ops.gpt_block_tail(o, xs, attn._proj, self._ln2, self._out[0], self._out[2])
+        return ops.gpt_block_tail(o, xs, attn._proj, self._ln2, self._out[0], self._out[2], pair)
 
     def forward(self, x):
         # skip=True: the residual branch's gradient is added inside the LayerNorm backward kernel

@@ -573,6 +573,7 @@ def mlp_gelu(x, conv1, conv2, res=None):
 # ImageGPT transformer block minus the attention core: fused head / tail (gpt_block.hip)
 # --------------------------------------------------------------------------------------------
 FUSE_BLOCK = os.environ.get("PG_FUSE_BLOCK", "1") != "0"
+DEFER_BLOCK_REDUCE = os.environ.get("PG_BLOCK_REDUCE_MERGED", "1") != "0"  # A/B: 0 = two reduce launches per block
 
 
 def _grad_targets(params):
@@ -596,8 +597,9 @@ class _GPTBlockHead(torch.autograd.Function):
     (the residual routes of the block) is added to LN1's input gradient inside the backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, lnw, lnb, wq, bq, wkv, bkv, eps, params):
+    def forward(ctx, x, lnw, lnb, wq, bq, wkv, bkv, eps, params, pair=None):
         lib = _lib.load()
+        ctx.pair = pair
         x_in = x
         x = _chk(x, "gpt_block_head.x")
         n, c, h, w = x.shape
@@ -617,23 +619,33 @@ class _GPTBlockHead(torch.autograd.Function):
         lib = _lib.load()
         x, lnw, lnb, wq, wkv = ctx.saved_tensors
         n, c, h, w = x.shape
+        pending = ctx.pair.pop("tail", None) if ctx.pair is not None else None
         if dqkv is None:
-            return gx, None, None, None, None, None, None, None, None
+            if pending is not None:
+                raise RuntimeError("gpt_block_head: a deferred tail reduction is pending but the head has no gradient")
+            return gx, None, None, None, None, None, None, None, None, None
         dqkv = _chk(dqkv, "gpt_block_head.dqkv")
         gx = torch.zeros_like(x) if gx is None else _chk(gx, "gpt_block_head.gx")
         dx = torch.empty_like(x)
         tgt, ret = _grad_targets(ctx.params)  # order: lnw, lnb, wq, bq, wkv, bkv
         ws_n = lib.pg_gpt_block_head_bwd_workspace_floats(n, h * w)
         ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
-        _lib.check(
-            lib.pg_gpt_block_head_bwd(x.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), wq.data_ptr(),
-                                      wkv.data_ptr(), dqkv.data_ptr(), gx.data_ptr(), dx.data_ptr(),
-                                      tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr(),
-                                      tgt[3].data_ptr(), tgt[4].data_ptr(), tgt[5].data_ptr(), n, c,
-                                      h * w, ctx.eps, ws.data_ptr(), ws_n, _stream()),
-            "pg_gpt_block_head_bwd",
-        )
-        return (dx, *ret, None, None)
+        head_args = (x.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), wq.data_ptr(),
+                     wkv.data_ptr(), dqkv.data_ptr(), gx.data_ptr(), dx.data_ptr(),
+                     tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr(),
+                     tgt[3].data_ptr(), tgt[4].data_ptr(), tgt[5].data_ptr(), n, c,
+                     h * w, ctx.eps, ws.data_ptr(), ws_n)
+        if pending is not None:  # this block's tail kernel left its partial rows: ONE reduce launch for both
+            t_ws, t = pending    # t order: wp, bp, lnw, lnb, w1, b1, w2, b2
+            _lib.check(
+                lib.pg_gpt_block_head_bwd_with_tail(*head_args, t_ws.data_ptr(), t[4].data_ptr(), t[5].data_ptr(),
+                                                    t[6].data_ptr(), t[7].data_ptr(), t[0].data_ptr(),
+                                                    t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), _stream()),
+                "pg_gpt_block_head_bwd_with_tail",
+            )
+        else:
+            _lib.check(lib.pg_gpt_block_head_bwd(*head_args, _stream()), "pg_gpt_block_head_bwd")
+        return (dx, *ret, None, None, None)
 
 
 class _GPTBlockTail(torch.autograd.Function):
@@ -641,8 +653,9 @@ class _GPTBlockTail(torch.autograd.Function):
     block and the model loop's `x + block(x)`)."""
 
     @staticmethod
-    def forward(ctx, o, x, wp, bp, lnw, lnb, w1, b1, w2, b2, eps, params):
+    def forward(ctx, o, x, wp, bp, lnw, lnb, w1, b1, w2, b2, eps, params, pair=None):
         lib = _lib.load()
+        ctx.pair = pair
         o = _chk(o, "gpt_block_tail.o")
         x = _chk(x, "gpt_block_tail.x")
         n, c, h, w = x.shape
@@ -668,6 +681,18 @@ class _GPTBlockTail(torch.autograd.Function):
         tgt, ret = _grad_targets(ctx.params)  # order: wp, bp, lnw, lnb, w1, b1, w2, b2
         ws_n = lib.pg_gpt_block_tail_bwd_workspace_floats(n, h * w)
         ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
+        if ctx.pair is not None and DEFER_BLOCK_REDUCE and all(r is None for r in ret):
+            # every gradient goes into a sink (FlatAdam): leave the partial rows for the head's backward of the
+            # same block, which reduces both kernels' rows in one launch
+            _lib.check(
+                lib.pg_gpt_block_tail_bwd_partial(o.data_ptr(), x.data_ptr(), wp.data_ptr(), bp.data_ptr(),
+                                                  lnw.data_ptr(), lnb.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                                  w2.data_ptr(), d.data_ptr(), d_o.data_ptr(), gx.data_ptr(), n, c,
+                                                  w1.shape[0], h * w, ctx.eps, ws.data_ptr(), ws_n, _stream()),
+                "pg_gpt_block_tail_bwd_partial",
+            )
+            ctx.pair["tail"] = (ws, tgt)
+            return (d_o, gx, *ret, None, None, None)
         _lib.check(
             lib.pg_gpt_block_tail_bwd(o.data_ptr(), x.data_ptr(), wp.data_ptr(), bp.data_ptr(),
                                       lnw.data_ptr(), lnb.data_ptr(), w1.data_ptr(), b1.data_ptr(),
@@ -678,7 +703,7 @@ class _GPTBlockTail(torch.autograd.Function):
                                       ctx.eps, ws.data_ptr(), ws_n, _stream()),
             "pg_gpt_block_tail_bwd",
         )
-        return (d_o, gx, *ret, None, None)
+        return (d_o, gx, *ret, None, None, None)
 
 
 def gpt_block_supported(x, ln1, q, kv, proj, ln2, fc1, fc2):
@@ -695,14 +720,16 @@ def gpt_block_supported(x, ln1, q, kv, proj, ln2, fc1, fc2):
     return tuple(ln1.normalized_shape) == (16,) and tuple(ln2.normalized_shape) == (16,)
 
 
-def gpt_block_head(x, ln1, q, kv):
+def gpt_block_head(x, ln1, q, kv, pair=None):
+    """pair: a dict shared with gpt_block_tail of the SAME block (one per forward): lets the two backward
+    kernels share one weight-gradient reduction launch."""
     params = (ln1.weight, ln1.bias, q.weight, q.bias, kv.weight, kv.bias)
-    return _GPTBlockHead.apply(x, *params, float(ln1.eps), params)
+    return _GPTBlockHead.apply(x, *params, float(ln1.eps), params, pair)
 
 
-def gpt_block_tail(o, x, proj, ln2, fc1, fc2):
+def gpt_block_tail(o, x, proj, ln2, fc1, fc2, pair=None):
     params = (proj.weight, proj.bias, ln2.weight, ln2.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
-    return _GPTBlockTail.apply(o, x, *params, float(ln2.eps), params)
+    return _GPTBlockTail.apply(o, x, *params, float(ln2.eps), params, pair)
 
 
 # --------------------------------------------------------------------------------------------
