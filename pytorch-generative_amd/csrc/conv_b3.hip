@@ -475,6 +475,204 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
 #undef PG_B3_COMMIT_ALL
 }
 
+// ---- 1x1 convolutions: no x tile in LDS ---------------------------------------------------------------
+// With one tap a wave's B fragments are read by that wave only, so staging x through LDS buys nothing and
+// costs the workgroup barriers that keep the waves of conv_b3_kernel in lockstep (loads, split and MFMA
+// phases back to back). Here every wave is on its own: the weights of the output chunk (all channel chunks,
+// <= 24 KB) go to LDS once per workgroup, then a wave walks its 32-pixel tiles with no further barrier —
+// float2 loads straight into the B-fragment layout, activation + split in registers, the next chunk's loads
+// in flight under the MFMAs, and the other waves of the SIMD filling the matrix pipe meanwhile (a 64 x 32
+// accumulator tile: two waves per SIMD at 64 output channels, three / four at 32 / 16).
+// Column j of pixel group n is pixel 2 j + n of the tile: lane (j, kq) then needs 2 CONSECUTIVE pixels of
+// its 8 channels = one float2 per channel (16 lanes x 8 B = 128 contiguous bytes per channel and load).
+// Same packed weights, bias / activation / one residual or derivative operand as conv_b3_kernel (the
+// multi-stream epilogues stay there).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int PW_EPS = 36;   // floats per channel row of a wave's 16 x 32 transposition scratch
+constexpr int PW_WAVES = 4;
+
+template <int MT>
+__global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)) conv_b3_pw_kernel(const B3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, jc = lane & 15;
+  const int L = a.OH * a.OW;
+  const int nchunk = a.Cin / a.CIB;
+  const int co0 = blockIdx.y * B3_CO_CHUNK;
+  const int tpi = (L + 31) >> 5;  // 32-pixel tiles per image, the last one may be ragged (L % 2 == 0)
+  const int nitems = a.N * tpi;
+
+  {  // weights of this output chunk, every channel chunk: [j][co tile][piece][lane] 16-byte fragments
+    const float4* wsrc = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * a.wslab4;
+    float4* wdst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < nchunk * a.wslab4; i += 64 * PW_WAVES) wdst[i] = wsrc[i];
+    if (tid < B3_CO_CHUNK) lds[a.b_off + tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
+  }
+  __syncthreads();  // the only barrier of the kernel
+
+  const int gw = blockIdx.x * PW_WAVES + wave, GW = gridDim.x * PW_WAVES;
+  if (gw >= nitems) return;
+  float* ep = lds + a.ep_off + wave * (16 * PW_EPS);
+  const float* bl = lds + a.b_off;
+  const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds) + lane;
+  const bool kact = kq < a.cgs;  // K groups beyond the chunk's channels are zero (weights packed as zero too)
+  const unsigned lane_in = (unsigned)((kact ? 8 * kq : 0) * L + 2 * jc);  // floats from the (image, chunk, tile) base
+  const size_t cstride = (size_t)L;
+  const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
+  const int half = lane >> 5, px = lane & 31;  // store phase: lane = (8-channel half, pixel)
+
+  f32x2 raw[8], nxt[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) nxt[c] = f32x2{0.f, 0.f};
+// addresses = uniform base (SGPR pair: image, channel chunk, tile) + 32-bit lane offset: one VGPR per stream
+#define PG_PW_ISSUE(IT, J, DST)                                                                        \
+  {                                                                                                    \
+    const int ni_ = (IT) / tpi;                                                                        \
+    const int t0_ = ((IT) - ni_ * tpi) * 32;                                                           \
+    const bool ok_ = kact && t0_ + 2 * jc < L;                                                         \
+    /* every lane loads from a valid address (its own when ok_, the tile's first otherwise): no branches */ \
+    const unsigned lo_ = ok_ ? lane_in : 0u;                                                           \
+    const float* sb_ = a.in + ((size_t)ni_ * a.Cin + (J) * a.CIB) * cstride + t0_;                     \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                    \
+      const f32x2 t_ = *reinterpret_cast<const f32x2*>(sb_ + c * cstride + lo_);                       \
+      DST[c] = f32x2{ok_ ? t_[0] : 0.f, ok_ ? t_[1] : 0.f};                                            \
+    }                                                                                                  \
+  }
+#define PG_PW_MFMA(ACT)                                                                   \
+  _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                         \
+    float e_[8];                                                                          \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) e_[c] = pg_apply_act(raw[c][n], ACT);   \
+    u32x4 h_, m_, l_;                                                                     \
+    split8t(e_, h_, m_, l_);                                                              \
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, h_);                                     \
+    const bf16x8 bm = __builtin_bit_cast(bf16x8, m_);                                     \
+    const bf16x8 bo = __builtin_bit_cast(bf16x8, l_);                                     \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                      \
+      f32x4 c = acc[m][n];                                                                \
+      c = MFMA16B(af[m][2], bh, c);                                                       \
+      c = MFMA16B(af[m][0], bo, c);                                                       \
+      c = MFMA16B(af[m][1], bm, c);                                                       \
+      c = MFMA16B(af[m][1], bh, c);                                                       \
+      c = MFMA16B(af[m][0], bm, c);                                                       \
+      c = MFMA16B(af[m][0], bh, c);                                                       \
+      acc[m][n] = c;                                                                      \
+    }                                                                                     \
+  }
+
+  PG_PW_ISSUE(gw, 0, raw)
+  for (int it = gw; it < nitems; it += GW) {
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nchunk; ++j) {
+      const bool lastj = j + 1 == nchunk;
+      const int it2 = lastj ? it + GW : it, j2 = lastj ? 0 : j + 1;
+      if (it2 < nitems) PG_PW_ISSUE(it2, j2, nxt)
+      bf16x8 af[MT][3];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) af[m][pc] = wl[((j * MT + m) * 3 + pc) * 64];
+      switch (a.in_act) { /* wave-uniform */
+        case PG_ACT_RELU: PG_PW_MFMA(PG_ACT_RELU) break;
+        case PG_ACT_ELU:  PG_PW_MFMA(PG_ACT_ELU) break;
+        case PG_ACT_GELU: PG_PW_MFMA(PG_ACT_GELU) break;
+        default:          PG_PW_MFMA(PG_ACT_NONE) break;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) raw[c] = nxt[c];
+    }
+    // ---- epilogue: v = out_act(acc + bias) (+ res | * act'(dact_src)), transposed through the wave's own
+    // scratch: lanes 0-31 take channels 0-7 of a 16-channel tile, lanes 32-63 channels 8-15, lane & 31 =
+    // pixel, so a store covers two runs of 128 contiguous bytes
+    const int n_img = it / tpi;
+    const int t0 = (it - n_img * tpi) * 32;
+    const bool sok = t0 + px < L;
+    const size_t so = ((size_t)n_img * a.Cout + co0) * cstride + t0;   // uniform
+    const unsigned lo = sok ? (unsigned)(8 * half * L + px) : 0u;        // lane part
+    const int cvalid = a.Cout - co0 - 8 * half;
+    float* outp = a.out + so;
+    const float* op = has_res ? a.res + so : (has_ds ? a.dact_src + so : nullptr);
+    const int dsel = has_ds ? a.dact : PG_ACT_NONE;
+    float ov[8];
+#define PG_PW_REQUEST(M)                                                       \
+  if (op) {                                                                    \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                            \
+      const int cc = (M) * 16 + c;                                             \
+      ov[c] = (op + (size_t)(cc < cvalid ? cc : 0) * cstride)[lo];             \
+    }                                                                          \
+  }
+    PG_PW_REQUEST(0)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x2*>(ep + (kq * 4 + r) * PW_EPS + 2 * jc) = f32x2{acc[m][0][r], acc[m][1][r]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = ep[(8 * half + c) * PW_EPS + px] + bl[m * 16 + 8 * half + c];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      switch (a.out_act) { /* wave-uniform */
+        case PG_ACT_RELU:
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = pg_apply_act(v[c], PG_ACT_RELU);
+          break;
+        case PG_ACT_ELU:
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = pg_apply_act(v[c], PG_ACT_ELU);
+          break;
+        case PG_ACT_GELU:
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = pg_apply_act(v[c], PG_ACT_GELU);
+          break;
+        default: break;
+      }
+      if (has_res) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] += ov[c];
+      } else {
+        switch (dsel) {
+          case PG_ACT_RELU:
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(ov[c], PG_ACT_RELU);
+            break;
+          case PG_ACT_ELU:
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(ov[c], PG_ACT_ELU);
+            break;
+          case PG_ACT_GELU:
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(ov[c], PG_ACT_GELU);
+            break;
+          case PG_ACT_ELU_OUT:
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(ov[c], PG_ACT_ELU_OUT);
+            break;
+          default: break;
+        }
+      }
+      // the next tile's operand is requested BEFORE this tile's stores (loads and stores retire in order)
+      __builtin_amdgcn_sched_barrier(0);
+      if (m + 1 < MT) PG_PW_REQUEST(m + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      if (sok) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int cc = m * 16 + c;
+          if (cc < cvalid) (outp + (size_t)cc * cstride)[lo] = v[c];
+        }
+      }
+    }
+#undef PG_PW_REQUEST
+  }
+#undef PG_PW_ISSUE
+#undef PG_PW_MFMA
+}
+
 // ---- weight pack: A fragments of the three bf16 pieces ------------------------------------------
 // wfrag (16-byte units) [co chunk][channel chunk][k step][co tile m][piece][lane]: the 8 bf16 of
 //   Wsel[64 chunk + 16 m + (lane & 15)][channel = CIB * j + 8 cg(g) + 0..7][tap t(g)], g = 4 ks + (lane >> 4)
@@ -601,6 +799,14 @@ void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st)
 #undef PG_B3_L
 }
 
+template <int MT>
+void b3_pw_launch(const B3Args& a, dim3 grid, size_t shmem, hipStream_t st) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_pw_kernel<MT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  (void)attr;
+  hipLaunchKernelGGL((conv_b3_pw_kernel<MT>), grid, dim3(64 * PW_WAVES), shmem, st, a);
+}
+
 void tap_extent(int T, const int* dr, const int* dc, int& min_dr, int& hr, int& min_dc, int& hc) {
   int a0 = dr[0], a1 = dr[0], b0 = dc[0], b1 = dc[0];
   for (int t = 1; t < T; ++t) {
@@ -679,10 +885,51 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   const int TR = b3_rows(T, OH, OW, hr, hc);
   PG_REQUIRE(pl.ok && TR >= 1 && OH * OW >= 256 && OW <= 256, PG_ESHAPE,
              "pg_conv2d_mfma(bf16x3): shape not covered");
+  a.CIB = pl.CIB; a.cgs = pl.cgs; a.groups = pl.groups; a.ksteps = pl.ksteps;
+  a.wslab4 = pl.ksteps * pl.MT * 192;
+  // multi-stream epilogue (two residuals, residual + derivative, batch-strided residual): own instantiations
+  const bool ms = res2 != nullptr || (res != nullptr && dact_src != nullptr) ||
+                  (res != nullptr && a.res_bs != (long)Cout * OH * OW);
+  {
+    // 1x1 without an LDS x tile (conv_b3_pw_kernel) up to 64 input channels (weight slab of an output chunk <= 24 KB).
+    // Measured forward, old -> new kernel (tools/exp/pw_ab.py): 64 -> 64 at N = 512, 32x32: 76.8 -> 65.4 us (4.1 TB/s of
+    // algorithmic traffic), with ELU on both sides 83.0 -> 74.8; 64 -> 32 at N = 1024, 28x28: 84.1 -> 64.7; 32 -> 64:
+    // 99.4 -> 88.7. 128 input channels are compute-heavy enough for the staged kernel: 182 -> 197 us, left there.
+    static const bool pw_on = []() { const char* e = getenv("PG_CONV_B3_PW"); return !(e && e[0] == '0'); }();
+    const int nchunk = Cin / pl.CIB;
+    const size_t wbytes = (size_t)nchunk * pl.MT * 3 * 1024;
+    if (pw_on && !ms && T == 1 && pl.ksteps == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
+        (OH * OW) % 2 == 0 && wbytes <= 24 * 1024) {
+      a.TR = 0; a.tile_h = a.tile_w = a.plane16 = a.tiles_per_img = 0;
+      a.xslots = 0; a.dump16 = 0; a.w_off16 = 0;
+      for (int g = 0; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }
+      a.ep_off = (int)(wbytes / 4);
+      a.b_off = a.ep_off + PW_WAVES * 16 * PW_EPS;
+      const size_t shmem = ((size_t)a.b_off + B3_CO_CHUNK + 4) * sizeof(float);
+      const int chunks_y = b3_chunks(Cout);
+      const long items = (long)N * ((OH * OW + 31) / 32);
+      // resident workgroups per CU: what the registers allow (waves per SIMD = 4 / 3 / 2 for 1 / 2 / 3-4 output
+      // tiles of 16 channels), LDS permitting
+      const int by_regs = pl.MT == 1 ? 4 : (pl.MT == 2 ? 3 : 2);
+      const int by_lds = (int)((160 * 1024) / shmem);
+      const int per_cu = by_lds < by_regs ? by_lds : by_regs;
+      long gx = (long)256 * per_cu / chunks_y;
+      if (gx > (items + PW_WAVES - 1) / PW_WAVES) gx = (items + PW_WAVES - 1) / PW_WAVES;
+      if (gx < 1) gx = 1;
+      const dim3 grid((unsigned)gx, (unsigned)chunks_y);
+      switch (pl.MT) {
+        case 1: b3_pw_launch<1>(a, grid, shmem, st); break;
+        case 2: b3_pw_launch<2>(a, grid, shmem, st); break;
+        case 3: b3_pw_launch<3>(a, grid, shmem, st); break;
+        default: b3_pw_launch<4>(a, grid, shmem, st); break;
+      }
+      PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, 1x1)");
+      return 0;
+    }
+  }
   a.TR = TR; a.tile_h = TR + hr; a.tile_w = OW + hc;
   a.plane16 = ((a.tile_h * a.tile_w + 15) / 16) * 16;
   a.tiles_per_img = (OH + TR - 1) / TR;
-  a.CIB = pl.CIB; a.cgs = pl.cgs; a.groups = pl.groups; a.ksteps = pl.ksteps;
   for (int g = 0; g < pl.groups; ++g) {
     const int t = g / pl.cgs, cg = g - t * pl.cgs;
     a.g_tapoff[g] = (tap_dr[t] - a.min_dr) * a.tile_w + (tap_dc[t] - a.min_dc);
@@ -690,7 +937,6 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   }
   for (int g = pl.groups; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }
   a.xslots = pl.cgs * a.tile_h * a.tile_w;
-  a.wslab4 = pl.ksteps * pl.MT * 192;
   const size_t x16 = (size_t)pl.cgs * 3 * a.plane16;
   a.dump16 = (int)x16;              // one spare 16-byte entry (+ padding to a 256-byte boundary)
   a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
@@ -710,9 +956,6 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   long gx = (want / a.tiles_per_img) * a.tiles_per_img;
   if (gx > (long)N * a.tiles_per_img) gx = (long)N * a.tiles_per_img;
   dim3 grid((unsigned)gx, (unsigned)chunks_y);
-  // multi-stream epilogue (two residuals, residual + derivative, batch-strided residual): own instantiations
-  const bool ms = res2 != nullptr || (res != nullptr && dact_src != nullptr) ||
-                  (res != nullptr && a.res_bs != (long)Cout * OH * OW);
   PG_REQUIRE(!ms || pl.MT == 4, PG_ESHAPE,
              "pg_conv2d_mfma_ex(bf16x3): the multi-stream epilogue is instantiated for >= 64 output channels");
   if (CG == 2) {

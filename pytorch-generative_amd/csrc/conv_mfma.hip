@@ -563,6 +563,13 @@ PG_EXPORT int pg_conv2d_mfma_ex(const float* in, const float* wfrag, const float
   PG_REQUIRE(dact >= PG_ACT_NONE && dact <= PG_ACT_ELU_OUT && ((dact == PG_ACT_NONE) == (dact_src == nullptr)),
              PG_EINVAL, "pg_conv2d_mfma: dact_src / dact mismatch");
   hipStream_t st = (hipStream_t)stream;
+  {  // PG_CONV_LOG=1: one line per launch on stderr (which shapes a model sends to which kernel family)
+    static const bool log_on = []() { const char* e = getenv("PG_CONV_LOG"); return e && e[0] == '1'; }();
+    if (log_on)
+      fprintf(stderr, "pg_conv2d_mfma %s N=%d Cin=%d %dx%d Cout=%d %dx%d T=%d in_act=%d out_act=%d res=%d res2=%d dact=%d\n",
+              fmt == PG_CONV_FMT_B3 ? "b3" : "f32", N, Cin, IH, IW, Cout, OH, OW, T, in_act, out_act, res != nullptr,
+              res2 != nullptr, dact);
+  }
   if (fmt == PG_CONV_FMT_B3)
     return pg_b3_conv(in, wfrag, bias, res, out, N, Cin, IH, IW, Cout, OH, OW, T, tap_dr, tap_dc, in_act,
                       dact_src, dact, out_act, res2, res_bs, res2_bs, st);

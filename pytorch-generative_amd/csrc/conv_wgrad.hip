@@ -548,6 +548,11 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
                        int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
                        const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st);
 
+// ... and its "shifted dy" variant (32 output channels per workgroup, full tap grids, W % 4 == 0)
+int pg_wgrad_b3s_launch(const float* x, const float* dy, float* part, long part_stride, long max_rows,
+                        int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
+                        const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st);
+
 static long wgrad_max_rows(int Cout, int Cin) {
   const long chunks = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
   const long g = 512 / chunks;
@@ -624,8 +629,17 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     }
   }
   {
-    const int g = pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
-                                     Cout, OH, OW, T, tap_dr, tap_dc, in_act, st);
+    // 64 output channels per workgroup where the shape divides that way (the kernel PixelSNAIL / GatedPixelCNN were
+    // tuned on), else — or when its x copies do not fit LDS (3x3 on 64-wide rows) — the shifted-dy variant
+    int g = Cout % 64 == 0 ? pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
+                                                Cout, OH, OW, T, tap_dr, tap_dc, in_act, st)
+                           : 0;
+    if (g == 0)
+      g = pg_wgrad_b3s_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW, Cout, OH, OW, T,
+                              tap_dr, tap_dc, in_act, st);
+    if (g == 0 && Cout % 64 != 0)
+      g = pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW, Cout, OH, OW, T,
+                             tap_dr, tap_dc, in_act, st);
     PG_REQUIRE(g >= 0, PG_EINVAL, "pg_conv2d_wgrad(bf16x3): launch failed");
     if (g > 0) {
       launch_reduce(workspace, stride, g, dw, db, Cout, Cin, KH, KW, T, tap_u, tap_v, st);

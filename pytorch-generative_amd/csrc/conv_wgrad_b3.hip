@@ -346,6 +346,258 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
   }
 }
 
+// ---- "shifted dy" variant: 32 co x 32 ci per workgroup, full NR x NC tap grids ---------------------------
+// Same GEMM, the column shift moved to the OTHER operand:
+//   dw[co][ci][dr, dc] = sum_{r, c'} dy[r][c' - dc] * act(x)[r + dr][c']
+// so x is staged ONCE (a row shift is a whole number of pixel blocks, as before) and dy once per distinct
+// column shift (copy_dc[c'] = dy[c' - dc], zero outside the row). With 32 dy channels per workgroup the dy tile
+// (TR rows) is smaller than the x tile (TR + NR - 1 rows), so this halves the shift arithmetic of a 3x3 and
+// cuts LDS from 3 x copies to 3 (smaller) dy copies: 64-pixel-wide images fit (the x-copy layout needs 110 KB
+// there: those launches ran on the fp32 kernel), and 32-wide images get two output rows per tile.
+// Rows whose width is a multiple of 4 but not of 8 (28 x 28) end in a half pixel block: its upper four K slots
+// are zero in both operands.
+// Per K step a wave holds the A fragments of all NC copies (NC x 3 pieces) and walks the NR row shifts with one
+// set of B fragments each: NC * 3 + NR * 3 LDS reads for NR * NC * 6 MFMAs.
+struct WsArgs {
+  const float* x; const float* dy; float* part;
+  long part_stride;
+  int N, Cin, Cout, H, W, T;
+  int TR, xh, tiles_per_img, total_tiles, min_dr, min_dc;
+  int PBR, dpb, xpb, ksteps;
+  int dslots, xslots;
+  int x_off16;                 // first 16-byte entry of the x area (behind NC dy copies x 3 pieces)
+  int v0;                      // dy copy with dc == 0 (bias sums)
+  int wpart;                   // W % 8 != 0: the last pixel block of a row holds 4 pixels
+  int in_act, has_bias;
+  int tap_of[9];               // caller's tap index of grid position (ri, ci): ri * NC + ci
+};
+
+template <int NR, int NC>
+__global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3s_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wi = wave >> 1;   // co tile, ci tile of this wave
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * WB_CI;
+  const int dplane = 2 * a.dpb * 16;         // entries per dy (copy, piece) plane
+  const int xplane = 2 * a.xpb * 16;         // entries per x piece plane
+
+  int d_goff[WB_DS], d_meta[WB_DS], x_goff[WB_XS], x_meta[WB_XS];  // meta: LDS entry | tile row << 20
+  int d_edge = 0;  // bit k: slot k is the first column block of its row; bit 8 + k: the last
+  int d_half = 0, x_half = 0;  // bit k: slot k is a half block (4 pixels)
+#pragma unroll
+  for (int k = 0; k < WB_DS; ++k) {
+    int e = tid + k * WB_THREADS;
+    const bool in = e < a.dslots;
+    e = in ? e : 0;
+    const int i = e & 15; e >>= 4;
+    const int cb = e % a.PBR; e /= a.PBR;
+    const int tr = e % a.TR;
+    const int cot = e / a.TR;
+    d_goff[k] = in ? ((cot * 16 + i) * a.H + tr) * a.W + 8 * cb : -1;
+    d_meta[k] = ((cot * a.dpb + tr * a.PBR + cb) * 16 + i) | (tr << 20);
+    if (cb == 0) d_edge |= 1 << k;
+    if (cb == a.PBR - 1) {
+      d_edge |= 256 << k;
+      if (a.wpart) d_half |= 1 << k;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < WB_XS; ++k) {
+    int e = tid + k * WB_THREADS;
+    const bool in = e < a.xslots;
+    e = in ? e : 0;
+    const int i = e & 15; e >>= 4;
+    const int cb = e % a.PBR; e /= a.PBR;
+    const int tr = e % a.xh;
+    const int cit = e / a.xh;
+    x_goff[k] = in ? ((cit * 16 + i) * a.H + tr) * a.W + 8 * cb : -1;
+    x_meta[k] = (a.x_off16 + (cit * a.xpb + tr * a.PBR + cb) * 16 + i) | (tr << 20);
+    if (cb == a.PBR - 1 && a.wpart) x_half |= 1 << k;
+  }
+  // copy v holds dc = min_dc + v: dc = +1 needs the pixel LEFT of the slot's 8, dc = -1 the pixel right of them
+  const bool want_prev = a.min_dc + NC - 1 >= 1, want_next = a.min_dc <= -1;  // wave-uniform
+
+  float4 dv[WB_DS][2], xv[WB_XS][2];
+  float de[WB_DS][2];
+#pragma unroll
+  for (int k = 0; k < WB_DS; ++k) {
+    dv[k][0] = dv[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    de[k][0] = de[k][1] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < WB_XS; ++k) xv[k][0] = xv[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int dok = 0, xok = 0;
+
+#define PG_WS_ISSUE(TILE)                                                                          \
+  {                                                                                                \
+    const int n_ = (TILE) / a.tiles_per_img;                                                       \
+    const int row0_ = ((TILE) - n_ * a.tiles_per_img) * a.TR;                                      \
+    const float* dyb_ = a.dy + (((long)n_ * a.Cout + co0) * a.H + row0_) * (long)a.W;              \
+    const float* xb_ = a.x + (((long)n_ * a.Cin + ci0) * a.H + (row0_ + a.min_dr)) * (long)a.W;    \
+    dok = 0; xok = 0;                                                                              \
+    _Pragma("unroll") for (int k = 0; k < WB_DS; ++k) {                                            \
+      if (d_goff[k] >= 0 && row0_ + (d_meta[k] >> 20) < a.H) {                                     \
+        const float* q_ = dyb_ + d_goff[k];                                                        \
+        const float4* p_ = reinterpret_cast<const float4*>(q_);                                    \
+        const int hb_ = (d_half >> k) & 1;                                                         \
+        dv[k][0] = p_[0]; dv[k][1] = p_[hb_ ? 0 : 1];  /* a half block never reads past its row */ \
+        /* edge slots load an in-row pixel instead (zeroed at commit): no select on a loaded value */ \
+        if (want_prev) de[k][0] = q_[((d_edge >> k) & 1) ? 0 : -1];                                \
+        if (want_next) de[k][1] = q_[((d_edge >> (8 + k)) & 1) ? 3 : 8];                           \
+        dok |= 1 << k;                                                                             \
+      }                                                                                            \
+    }                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < WB_XS; ++k) {                                            \
+      const int ir_ = row0_ + a.min_dr + (x_meta[k] >> 20);                                        \
+      if (x_goff[k] >= 0 && ir_ >= 0 && ir_ < a.H) {                                               \
+        const float4* p_ = reinterpret_cast<const float4*>(xb_ + x_goff[k]);                       \
+        xv[k][0] = p_[0]; xv[k][1] = p_[((x_half >> k) & 1) ? 0 : 1];                              \
+        xok |= 1 << k;                                                                             \
+      }                                                                                            \
+    }                                                                                              \
+  }
+
+#define PG_WS_COMMIT_X(ACT)                                                                        \
+  _Pragma("unroll") for (int k = 0; k < WB_XS; ++k) {                                              \
+    if (x_goff[k] >= 0) {                                                                          \
+      const bool ld_ = (xok >> k) & 1;                                                             \
+      const bool hb_ = (x_half >> k) & 1;                                                          \
+      const float r_[8] = {xv[k][0].x, xv[k][0].y, xv[k][0].z, xv[k][0].w,                         \
+                           xv[k][1].x, xv[k][1].y, xv[k][1].z, xv[k][1].w};                        \
+      float e_[8];                                                                                 \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                \
+        e_[c] = (ld_ && !(hb_ && c >= 4)) ? pg_apply_act(r_[c], ACT) : 0.f;                        \
+      u32x4 p_[3];                                                                                 \
+      split8(e_, p_[0], p_[1], p_[2]);                                                             \
+      u32x4* dst_ = lds16 + (x_meta[k] & 0xfffff);                                                 \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) dst_[q * xplane] = p_[q];                      \
+    }                                                                                              \
+  }
+
+  f32x4 acc[NR][NC];
+  f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool bias_wave = a.has_bias && wi == 0 && blockIdx.z == 0;  // wave-uniform
+  bf16x8 ones;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
+
+  const bf16x8* L = reinterpret_cast<const bf16x8*>(lds16) + lane;
+  const int a_base = wc * a.dpb * 16;
+  const int b_base = a.x_off16 + wi * a.xpb * 16;
+
+  int tile = blockIdx.x;
+  if (tile < a.total_tiles) PG_WS_ISSUE(tile)
+  for (; tile < a.total_tiles; tile += gridDim.x) {
+    __syncthreads();  // the previous tile's fragment reads are done
+    // every prefetch register is "used" here on every path: ONE s_waitcnt vmcnt(0) lands at this point
+    // (see conv_wgrad_b3_kernel)
+#pragma unroll
+    for (int k = 0; k < WB_DS; ++k)
+      asm volatile("" :: "v"(dv[k][0].x), "v"(dv[k][0].y), "v"(dv[k][0].z), "v"(dv[k][0].w),
+                         "v"(dv[k][1].x), "v"(dv[k][1].y), "v"(dv[k][1].z), "v"(dv[k][1].w),
+                         "v"(de[k][0]), "v"(de[k][1]));
+#pragma unroll
+    for (int k = 0; k < WB_XS; ++k)
+      asm volatile("" :: "v"(xv[k][0].x), "v"(xv[k][0].y), "v"(xv[k][0].z), "v"(xv[k][0].w),
+                         "v"(xv[k][1].x), "v"(xv[k][1].y), "v"(xv[k][1].z), "v"(xv[k][1].w));
+#pragma unroll
+    for (int k = 0; k < WB_DS; ++k) {
+      if (d_goff[k] >= 0) {
+        const bool ld = (dok >> k) & 1;
+        const bool hb = (d_half >> k) & 1;
+        const float r[8] = {dv[k][0].x, dv[k][0].y, dv[k][0].z, dv[k][0].w,
+                            dv[k][1].x, dv[k][1].y, dv[k][1].z, dv[k][1].w};
+        float e[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) e[c] = (ld && !(hb && c >= 4)) ? r[c] : 0.f;
+        u32x4 p[3];
+        split8(e, p[0], p[1], p[2]);
+        u32x4* dst0 = lds16 + (d_meta[k] & 0xfffff);
+#pragma unroll
+        for (int v = 0; v < NC; ++v) {
+          const int dc = a.min_dc + v;  // wave-uniform
+          u32x4* dst = dst0 + v * 3 * dplane;
+          if (dc == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) dst[q * dplane] = p[q];
+          } else {
+            // copy[c'] = dy[c' - dc]: dc = +1 shifts towards higher columns (the pixel left of the block
+            // enters), dc = -1 towards lower ones (the pixel right of it enters); zero at the row ends
+            unsigned int s[3];
+            const bool edge = (d_edge >> (dc > 0 ? k : 8 + k)) & 1;
+            split1(ld && !edge ? (dc > 0 ? de[k][0] : de[k][1]) : 0.f, s[0], s[1], s[2]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              dst[q * dplane] = dc > 0 ? shift_right1(p[q], s[q]) : shift_left1(p[q], s[q]);
+          }
+        }
+      }
+    }
+    switch (a.in_act) {  // wave-uniform
+      case PG_ACT_RELU: PG_WS_COMMIT_X(PG_ACT_RELU) break;
+      case PG_ACT_ELU:  PG_WS_COMMIT_X(PG_ACT_ELU) break;
+      case PG_ACT_GELU: PG_WS_COMMIT_X(PG_ACT_GELU) break;
+      default:          PG_WS_COMMIT_X(PG_ACT_NONE) break;
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.total_tiles) PG_WS_ISSUE(tile + (int)gridDim.x)
+    for (int ks = 0; ks < a.ksteps; ++ks) {
+      const bf16x8* Lk = L + ks * 64;
+      bf16x8 af[NC][3];
+#pragma unroll
+      for (int v = 0; v < NC; ++v)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[v][p] = Lk[a_base + (v * 3 + p) * dplane];
+      if (bias_wave) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) accb = MFMA16B(Lk[a_base + (a.v0 * 3 + p) * dplane], ones, accb);
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        bf16x8 bf[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[p] = Lk[b_base + r * a.PBR * 16 + p * xplane];
+#pragma unroll
+        for (int v = 0; v < NC; ++v) {
+          f32x4 c = acc[r][v];
+          c = MFMA16B(af[v][2], bf[0], c);  // l.h
+          c = MFMA16B(af[v][0], bf[2], c);  // h.l
+          c = MFMA16B(af[v][1], bf[1], c);  // m.m
+          c = MFMA16B(af[v][1], bf[0], c);  // m.h
+          c = MFMA16B(af[v][0], bf[1], c);  // h.m
+          c = MFMA16B(af[v][0], bf[0], c);  // h.h
+          acc[r][v] = c;
+        }
+      }
+    }
+  }
+#undef PG_WS_ISSUE
+#undef PG_WS_COMMIT_X
+
+  // ---- this workgroup's row of partial sums: D[row = (lane >> 4) * 4 + r][col = lane & 15]
+  float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
+  const int ci = ci0 + wi * 16 + (lane & 15);
+  const int co_b = co0 + wc * 16 + (lane >> 4) * 4;
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int v = 0; v < NC; ++v) {
+      const int t = a.tap_of[r * NC + v];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) prow[((size_t)(co_b + q) * a.Cin + ci) * a.T + t] = acc[r][v][q];
+    }
+  if (bias_wave && (lane & 15) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) prow[(size_t)a.Cout * a.Cin * a.T + co_b + q] = accb[q];
+  }
+}
+
 }  // namespace
 
 // Launches the bf16x3 kernel when it takes the problem; returns the number of partial rows written
@@ -424,6 +676,77 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
     default: PG_WB(9); break;
   }
 #undef PG_WB
+  if (hipGetLastError() != hipSuccess) return -1;
+  return (int)G;
+}
+
+// The "shifted dy" kernel (32 co x 32 ci per workgroup, full tap grids): same return convention.
+int pg_wgrad_b3s_launch(const float* x, const float* dy, float* part, long part_stride, long max_rows,
+                        int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
+                        const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st) {
+  static const bool on = []() {
+    const char* e = getenv("PG_WGRAD_B3");
+    const char* s = getenv("PG_WGRAD_B3S");
+    return !(e && e[0] == '0') && !(s && s[0] == '0');
+  }();
+  if (!on) return 0;
+  if (IH != OH || IW != OW || OW % 4 != 0 || Cout % 32 != 0 || Cin % WB_CI != 0 || T < 2 || T > 9) return 0;
+  if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return 0;
+  int min_dr = tap_dr[0], max_dr = tap_dr[0], min_dc = tap_dc[0], max_dc = tap_dc[0];
+  for (int t = 1; t < T; ++t) {
+    min_dr = tap_dr[t] < min_dr ? tap_dr[t] : min_dr;
+    max_dr = tap_dr[t] > max_dr ? tap_dr[t] : max_dr;
+    min_dc = tap_dc[t] < min_dc ? tap_dc[t] : min_dc;
+    max_dc = tap_dc[t] > max_dc ? tap_dc[t] : max_dc;
+  }
+  const int NR = max_dr - min_dr + 1, NC = max_dc - min_dc + 1;
+  if (min_dc < -1 || max_dc > 1 || NR > 3 || NR * NC != T) return 0;
+  if (has_bias && (min_dc > 0 || max_dc < 0)) return 0;  // the bias sums read the unshifted copy
+  WsArgs a;
+  for (int i = 0; i < 9; ++i) a.tap_of[i] = -1;
+  for (int t = 0; t < T; ++t) {
+    const int slot = (tap_dr[t] - min_dr) * NC + (tap_dc[t] - min_dc);
+    if (a.tap_of[slot] >= 0) return 0;  // a repeated tap: not a full grid
+    a.tap_of[slot] = t;
+  }
+  const int hr = NR - 1;
+  const int PBR = (OW + 7) / 8;
+  int TR = 0;
+  for (int tr = 1; tr <= OH + 3; ++tr) {
+    if ((tr * PBR) % 4 != 0) continue;
+    const long dslots = 32L * tr * PBR, xslots = (long)WB_CI * (tr + hr) * PBR;
+    const long bytes = (3L * NC * dslots + 3 * xslots) * 16;
+    if (dslots > WB_DS * WB_THREADS || xslots > WB_XS * WB_THREADS || bytes > WB_LDS_BUDGET) break;
+    TR = tr;
+    if (tr >= OH) break;
+  }
+  if (TR == 0) return 0;
+  a.x = x; a.dy = dy; a.part = part; a.part_stride = part_stride;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = OH; a.W = OW; a.T = T;
+  a.TR = TR; a.xh = TR + hr; a.min_dr = min_dr; a.min_dc = min_dc;
+  a.tiles_per_img = (OH + TR - 1) / TR;
+  a.total_tiles = N * a.tiles_per_img;
+  a.PBR = PBR; a.dpb = TR * PBR; a.xpb = a.xh * PBR; a.ksteps = a.dpb / 4;
+  a.dslots = 32 * a.dpb; a.xslots = WB_CI * a.xpb;
+  a.x_off16 = NC * 3 * (2 * a.dpb * 16);
+  a.v0 = -min_dc;
+  a.wpart = (OW % 8) != 0;
+  a.in_act = in_act; a.has_bias = has_bias;
+  const size_t shmem = ((size_t)a.x_off16 + (size_t)3 * (2 * a.xpb * 16)) * 16;
+  const int co_chunks = Cout / 32, ci_chunks = Cin / WB_CI;
+  long G = 512 / ((long)co_chunks * ci_chunks);
+  if (G < 16) G = 16;
+  if (G > a.total_tiles) G = a.total_tiles;
+  if (G > max_rows) G = max_rows;
+  dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
+#define PG_WS(R, C) hipLaunchKernelGGL((conv_wgrad_b3s_kernel<R, C>), grid, dim3(WB_THREADS), shmem, st, a)
+  if (NR == 3 && NC == 3) PG_WS(3, 3);
+  else if (NR == 2 && NC == 2) PG_WS(2, 2);
+  else if (NR == 1 && NC == 3) PG_WS(1, 3);
+  else if (NR == 2 && NC == 1) PG_WS(2, 1);
+  else if (NR == 2 && NC == 3) PG_WS(2, 3);
+  else return 0;
+#undef PG_WS
   if (hipGetLastError() != hipSuccess) return -1;
   return (int)G;
 }

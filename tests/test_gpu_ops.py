@@ -65,6 +65,20 @@ CONV_CASES = [
     # 1x1 shapes the bf16x3 weight-gradient kernel takes since round 3 (T = 1)
     (3, 64, 16, 16, 128, 1, 1, 0, 0, None, None, "elu", True, True),
     (130, 32, 32, 32, 64, 1, 1, 0, 0, None, None, None, False, True),   # several pixel tiles per workgroup
+    # 1x1 on the barrier-free bf16x3 kernel (conv_b3_pw_kernel): 1-4 output tiles, partial K groups, ragged pixel tiles
+    (5, 64, 32, 32, 64, 1, 1, 0, 0, None, None, "elu", True, True),     # PixelSNAIL's 64 -> 64 + residual
+    (4, 128, 32, 32, 32, 1, 1, 0, 0, None, None, "relu", False, True),  # four channel chunks, 32 output channels
+    (3, 48, 14, 22, 96, 1, 1, 0, 0, None, None, "gelu", True, True),    # 16-channel chunks, partial co chunk, L = 308
+    (600, 64, 28, 28, 32, 1, 1, 0, 0, None, None, "relu", False, True),  # PixelCNN 64 -> 32 at bench batch, ragged tiles
+    (2, 32, 16, 16, 16, 1, 1, 0, 0, None, None, None, False, False),    # one output tile, no bias
+    # the "shifted dy" bf16x3 weight-gradient kernel (32 output channels per workgroup, full tap grids, W % 4 == 0)
+    (6, 32, 64, 64, 32, 3, 3, 1, 1, None, None, "gelu", False, True),   # VD-VAE 64x64: one row per tile
+    (4, 64, 64, 64, 64, 3, 3, 1, 1, None, None, "relu", False, True),   # 64 -> 64 on 64-wide rows: x copies overflow LDS
+    (5, 32, 32, 32, 32, 2, 2, 1, 1, "hw", None, "elu", False, True),    # 2 x 2 grid, column shifts {-1, 0}
+    (3, 32, 12, 12, 32, 3, 3, 1, 1, None, "B", None, False, True),      # W = 12: two pixel blocks, the second half full
+    (3, 32, 10, 20, 32, 1, 3, 0, 1, None, None, "relu", False, False),  # 1 x 3 grid, W = 20, no bias
+    (3, 32, 9, 16, 96, 2, 1, 2, 0, "hw", None, None, False, True),      # 2 x 1 grid, three co chunks
+    (3, 64, 8, 24, 32, 2, 3, 1, 1, "hw", None, "gelu", True, True),     # 2 x 3 grid, two ci chunks
 ]
 
 
