@@ -485,13 +485,13 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
 // accumulator tile: two waves per SIMD at 64 output channels, three / four at 32 / 16).
 // Column j of pixel group n is pixel 2 j + n of the tile: lane (j, kq) then needs 2 CONSECUTIVE pixels of
 // its 8 channels = one float2 per channel (16 lanes x 8 B = 128 contiguous bytes per channel and load).
-// Same packed weights, bias / activation / one residual or derivative operand as conv_b3_kernel (the
-// multi-stream epilogues stay there).
+// Same packed weights and epilogue (bias, activation, derivative of the fused input activation, up to two
+// residual streams) as conv_b3_kernel.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int PW_EPS = 36;   // floats per channel row of a wave's 16 x 32 transposition scratch
 constexpr int PW_WAVES = 4;
 
-template <int MT>
+template <int MT, bool MS>
 __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)) conv_b3_pw_kernel(const B3Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
   const bool kact = kq < a.cgs;  // K groups beyond the chunk's channels are zero (weights packed as zero too)
   const unsigned lane_in = (unsigned)((kact ? 8 * kq : 0) * L + 2 * jc);  // floats from the (image, chunk, tile) base
   const size_t cstride = (size_t)L;
-  const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
+  const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr, has_res2 = a.res2 != nullptr;
   const int half = lane >> 5, px = lane & 31;  // store phase: lane = (8-channel half, pixel)
 
   f32x2 raw[8], nxt[8];
@@ -595,14 +595,28 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
     const unsigned lo = sok ? (unsigned)(8 * half * L + px) : 0u;        // lane part
     const int cvalid = a.Cout - co0 - 8 * half;
     float* outp = a.out + so;
-    const float* op = has_res ? a.res + so : (has_ds ? a.dact_src + so : nullptr);
+    // up to three operand streams: derivative source, residual, second residual (a residual may be a
+    // batch-strided channel slice: res_bs); v = out_act(acc + bias) * act'(o0) + o1 + o2
+    const size_t so_c = (size_t)co0 * cstride + t0;
+    const float* st0 = has_ds ? a.dact_src + so : nullptr;
+    const float* st1 = has_res ? a.res + (size_t)n_img * a.res_bs + so_c : nullptr;
+    const float* st2 = has_res2 ? a.res2 + (size_t)n_img * a.res2_bs + so_c : nullptr;
     const int dsel = has_ds ? a.dact : PG_ACT_NONE;
-    float ov[8];
+    // MS = false: at most one of the streams (one buffer); MS = true: its own instantiation (MT = 4), because
+    // two more operand buffers spill in the narrower kernels
+    constexpr int NB = MS ? 8 : 1;
+    float o0[8], o1[NB], o2[NB];
+    const float* sts = st0 ? st0 : st1;  // the single stream of the MS = false kernels
 #define PG_PW_REQUEST(M)                                                       \
-  if (op) {                                                                    \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                            \
-      const int cc = (M) * 16 + c;                                             \
-      ov[c] = (op + (size_t)(cc < cvalid ? cc : 0) * cstride)[lo];             \
+  _Pragma("unroll") for (int c = 0; c < 8; ++c) {                              \
+    const int cc = (M) * 16 + c;                                               \
+    const size_t off_ = (size_t)(cc < cvalid ? cc : 0) * cstride;              \
+    if constexpr (MS) {                                                        \
+      if (st0) o0[c] = (st0 + off_)[lo];                                       \
+      if (st1) o1[c] = (st1 + off_)[lo];                                       \
+      if (st2) o2[c] = (st2 + off_)[lo];                                       \
+    } else {                                                                   \
+      if (sts) o0[c] = (sts + off_)[lo];                                       \
     }                                                                          \
   }
     PG_PW_REQUEST(0)
@@ -631,28 +645,38 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
           break;
         default: break;
       }
-      if (has_res) {
+      switch (dsel) {
+        case PG_ACT_RELU:
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] += ov[c];
+          for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(o0[c], PG_ACT_RELU);
+          break;
+        case PG_ACT_ELU:
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(o0[c], PG_ACT_ELU);
+          break;
+        case PG_ACT_GELU:
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(o0[c], PG_ACT_GELU);
+          break;
+        case PG_ACT_ELU_OUT:
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(o0[c], PG_ACT_ELU_OUT);
+          break;
+        default: break;
+      }
+      if constexpr (MS) {
+        if (st1) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] += o1[c];
+        }
+        if (st2) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] += o2[c];
+        }
       } else {
-        switch (dsel) {
-          case PG_ACT_RELU:
+        if (st1) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(ov[c], PG_ACT_RELU);
-            break;
-          case PG_ACT_ELU:
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(ov[c], PG_ACT_ELU);
-            break;
-          case PG_ACT_GELU:
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(ov[c], PG_ACT_GELU);
-            break;
-          case PG_ACT_ELU_OUT:
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(ov[c], PG_ACT_ELU_OUT);
-            break;
-          default: break;
+          for (int c = 0; c < 8; ++c) v[c] += o0[c];
         }
       }
       // the next tile's operand is requested BEFORE this tile's stores (loads and stores retire in order)
@@ -799,12 +823,12 @@ void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st)
 #undef PG_B3_L
 }
 
-template <int MT>
+template <int MT, bool MS = false>
 void b3_pw_launch(const B3Args& a, dim3 grid, size_t shmem, hipStream_t st) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_pw_kernel<MT>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_pw_kernel<MT, MS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   (void)attr;
-  hipLaunchKernelGGL((conv_b3_pw_kernel<MT>), grid, dim3(64 * PW_WAVES), shmem, st, a);
+  hipLaunchKernelGGL((conv_b3_pw_kernel<MT, MS>), grid, dim3(64 * PW_WAVES), shmem, st, a);
 }
 
 void tap_extent(int T, const int* dr, const int* dc, int& min_dr, int& hr, int& min_dc, int& hc) {
@@ -898,7 +922,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     static const bool pw_on = []() { const char* e = getenv("PG_CONV_B3_PW"); return !(e && e[0] == '0'); }();
     const int nchunk = Cin / pl.CIB;
     const size_t wbytes = (size_t)nchunk * pl.MT * 3 * 1024;
-    if (pw_on && !ms && T == 1 && pl.ksteps == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
+    if (pw_on && (!ms || pl.MT == 4) && T == 1 && pl.ksteps == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
         (OH * OW) % 2 == 0 && wbytes <= 24 * 1024) {
       a.TR = 0; a.tile_h = a.tile_w = a.plane16 = a.tiles_per_img = 0;
       a.xslots = 0; a.dump16 = 0; a.w_off16 = 0;
@@ -917,7 +941,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
       if (gx > (items + PW_WAVES - 1) / PW_WAVES) gx = (items + PW_WAVES - 1) / PW_WAVES;
       if (gx < 1) gx = 1;
       const dim3 grid((unsigned)gx, (unsigned)chunks_y);
-      switch (pl.MT) {
+      if (ms) b3_pw_launch<4, true>(a, grid, shmem, st);
+      else switch (pl.MT) {
         case 1: b3_pw_launch<1>(a, grid, shmem, st); break;
         case 2: b3_pw_launch<2>(a, grid, shmem, st); break;
         case 3: b3_pw_launch<3>(a, grid, shmem, st); break;

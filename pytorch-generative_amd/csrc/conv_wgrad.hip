@@ -631,13 +631,17 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   {
     // 64 output channels per workgroup where the shape divides that way (the kernel PixelSNAIL / GatedPixelCNN were
     // tuned on), else — or when its x copies do not fit LDS (3x3 on 64-wide rows) — the shifted-dy variant
-    int g = Cout % 64 == 0 ? pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
+    // (measured, PG_WGRAD_B3S=2 prefers the shifted-dy kernel everywhere: PixelSNAIL 12.43 -> 12.31 k img/s,
+    // GatedPixelCNN 5.26 -> 5.06 k, beta-VAE 38.1 -> 38.5 k: only the 3x3 grids gain, so those go there first)
+    static const bool s_all = []() { const char* e = getenv("PG_WGRAD_B3S"); return e && e[0] == '2'; }();
+    const bool s_first = s_all || T == 9;
+    int g = (Cout % 64 == 0 && !s_first) ? pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
                                                 Cout, OH, OW, T, tap_dr, tap_dc, in_act, st)
                            : 0;
     if (g == 0)
       g = pg_wgrad_b3s_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW, Cout, OH, OW, T,
                               tap_dr, tap_dc, in_act, st);
-    if (g == 0 && Cout % 64 != 0)
+    if (g == 0 && (Cout % 64 != 0 || s_first))
       g = pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW, Cout, OH, OW, T,
                              tap_dr, tap_dc, in_act, st);
     PG_REQUIRE(g >= 0, PG_EINVAL, "pg_conv2d_wgrad(bf16x3): launch failed");
