@@ -45,6 +45,7 @@ struct B3Args {
   const float* dact_src;
   float* out;
   long res_bs, res2_bs;   // batch strides of res / res2 in floats (a channel slice of a wider tensor)
+  float res_scale;        // conv_b3_pw_kernel: res is added res_scale times (2 = both residual operands are ONE tensor)
   int N, Cin, IH, IW, Cout, OH, OW, T;
   int TR, tiles_per_img, tile_h, tile_w, min_dr, min_dc;
   int CIB, cgs, groups, ksteps;   // channels per chunk, CIB / 8, cgs * T, ceil(groups / 4)
@@ -667,7 +668,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
       if constexpr (MS) {
         if (st1) {
 #pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] += o1[c];
+          for (int c = 0; c < 8; ++c) v[c] = fmaf(o1[c], a.res_scale, v[c]);
         }
         if (st2) {
 #pragma unroll
@@ -676,7 +677,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
       } else {
         if (st1) {
 #pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] += o0[c];
+          for (int c = 0; c < 8; ++c) v[c] = fmaf(o0[c], a.res_scale, v[c]);
         }
       }
       // the next tile's operand is requested BEFORE this tile's stores (loads and stores retire in order)
@@ -898,6 +899,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
   PG_REQUIRE(res2 == nullptr || res != nullptr, PG_EINVAL, "pg_conv2d_mfma(bf16x3): res2 without res");
   a.res2 = res2;
+  a.res_scale = 1.f;
   a.res_bs = res_bs > 0 ? res_bs : (long)Cout * OH * OW;
   a.res2_bs = res2_bs > 0 ? res2_bs : (long)Cout * OH * OW;
   a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW; a.T = T;
@@ -922,7 +924,11 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     static const bool pw_on = []() { const char* e = getenv("PG_CONV_B3_PW"); return !(e && e[0] == '0'); }();
     const int nchunk = Cin / pl.CIB;
     const size_t wbytes = (size_t)nchunk * pl.MT * 3 * 1024;
-    if (pw_on && (!ms || pl.MT == 4) && T == 1 && pl.ksteps == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
+    // both residual operands the SAME tensor (PixelCNN's x + (x + net(x)) and the two equal skip gradients of its
+    // backward): one stream, added twice
+    const bool twice = res2 != nullptr && res2 == res && a.res2_bs == a.res_bs;
+    const bool ms_pw = twice ? ((dact_src != nullptr) || a.res_bs != (long)Cout * OH * OW) : ms;
+    if (pw_on && (!ms_pw || pl.MT == 4) && T == 1 && pl.ksteps == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
         (OH * OW) % 2 == 0 && wbytes <= 24 * 1024) {
       a.TR = 0; a.tile_h = a.tile_w = a.plane16 = a.tiles_per_img = 0;
       a.xslots = 0; a.dump16 = 0; a.w_off16 = 0;
@@ -941,7 +947,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
       if (gx > (items + PW_WAVES - 1) / PW_WAVES) gx = (items + PW_WAVES - 1) / PW_WAVES;
       if (gx < 1) gx = 1;
       const dim3 grid((unsigned)gx, (unsigned)chunks_y);
-      if (ms) b3_pw_launch<4, true>(a, grid, shmem, st);
+      if (twice) { a.res2 = nullptr; a.res_scale = 2.f; }
+      if (ms_pw) b3_pw_launch<4, true>(a, grid, shmem, st);
       else switch (pl.MT) {
         case 1: b3_pw_launch<1>(a, grid, shmem, st); break;
         case 2: b3_pw_launch<2>(a, grid, shmem, st); break;

@@ -51,10 +51,16 @@ class BottleneckBlock(nn.Module):
         )
 
     def forward(self, x):
-        h = self._net[1](x, in_act="gelu")
+        res = None
+        if self._is_residual:
+            # x has two readers (the first convolution and the residual add): the add reads a pass-through alias,
+            # whose gradient the first convolution's data-gradient kernel adds in its epilogue (ops.conv2d_taps)
+            h, res = self._net[1](x, in_act="gelu", n_skip=1)
+        else:
+            h = self._net[1](x, in_act="gelu")
         h = self._net[3](h, in_act="gelu")
         h = self._net[5](h, in_act="gelu")
-        return self._net[7](h, in_act="gelu", res=x if self._is_residual else None)
+        return self._net[7](h, in_act="gelu", res=res)
 
 
 class TopDownBlock(nn.Module):
