@@ -22,6 +22,7 @@
 // Workgroups are persistent like conv_mfma's: (tile, channel chunk) steps with the next step's
 // loads in flight under the MFMA loop.
 #include "common.h"
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace {
@@ -929,7 +930,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     const bool twice = res2 != nullptr && res2 == res && a.res2_bs == a.res_bs;
     const bool ms_pw = twice ? ((dact_src != nullptr) || a.res_bs != (long)Cout * OH * OW) : ms;
     if (pw_on && (!ms_pw || pl.MT == 4) && T == 1 && pl.ksteps == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
-        (OH * OW) % 2 == 0 && wbytes <= 24 * 1024) {
+        (OH * OW) % 2 == 0 && (((uintptr_t)in) & 7) == 0 && wbytes <= 24 * 1024) {
       a.TR = 0; a.tile_h = a.tile_w = a.plane16 = a.tiles_per_img = 0;
       a.xslots = 0; a.dump16 = 0; a.w_off16 = 0;
       for (int g = 0; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }

@@ -8,7 +8,7 @@
 //   dw[co][ci][t] = sum_{n,r,c} dy[n,co,r,c] * act(x[n,ci,r+dr_t,c+dc_t])      db[co] = sum dy
 //
 // GEMM view: M = co, N = ci, K = output pixels. One K step = 32 pixels = four "pixel blocks" of 8
-// consecutive pixels of one image row (W % 8 == 0): lane (i|j = lane & 15, kg = lane >> 4) holds the
+// consecutive pixels of one image row (W % 8 == 0, or W % 8 == 4 with a half-full last block): lane (i|j = lane & 15, kg = lane >> 4) holds the
 // 8 pixels of block 4 ks + kg for dy channel i (A) / x channel j (B).
 // The tap shift lives on the K axis here, and a packed-bf16 fragment cannot be read at an odd
 // element offset, so x is staged once per DISTINCT COLUMN SHIFT dc in {-1, 0, +1} ("copies":
@@ -129,6 +129,8 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
   // ---- staging slots: the same (channel, tile row, column block) for every tile
   int d_goff[WB_DS], d_meta[WB_DS], x_goff[WB_XS], x_meta[WB_XS];  // meta: LDS entry | tile row << 20
   int x_edge = 0;  // bit k: slot k is the first column block of its row; bit 8 + k: the last
+  int d_half = 0, x_half = 0;  // bit k: slot k is a half pixel block (W % 8 == 4: the last block of a row)
+  const bool wpart = (a.W & 7) != 0;
 #pragma unroll
   for (int k = 0; k < WB_DS; ++k) {
     int e = tid + k * WB_THREADS;
@@ -140,6 +142,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     const int cot = e / a.TR;
     d_goff[k] = in ? ((cot * 16 + i) * a.H + tr) * a.W + 8 * cb : -1;
     d_meta[k] = ((cot * a.dpb + tr * a.PBR + cb) * 16 + i) | (tr << 20);
+    if (wpart && cb == a.PBR - 1) d_half |= 1 << k;
   }
 #pragma unroll
   for (int k = 0; k < WB_XS; ++k) {
@@ -154,6 +157,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     x_meta[k] = (a.x_off16 + (cit * a.xpb + tr * a.PBR + cb) * 16 + i) | (tr << 20);
     if (cb == 0) x_edge |= 1 << k;
     if (cb == a.PBR - 1) x_edge |= 256 << k;
+    if (wpart && cb == a.PBR - 1) x_half |= 1 << k;
   }
   bool want_m1 = false, want_p1 = false;  // wave-uniform
   for (int v = 0; v < a.ndc; ++v) {
@@ -182,7 +186,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     _Pragma("unroll") for (int k = 0; k < WB_DS; ++k) {                                            \
       if (d_goff[k] >= 0 && row0_ + (d_meta[k] >> 20) < a.H) {                                     \
         const float4* p_ = reinterpret_cast<const float4*>(dyb_ + d_goff[k]);                      \
-        dv[k][0] = p_[0]; dv[k][1] = p_[1];                                                        \
+        dv[k][0] = p_[0]; dv[k][1] = p_[((d_half >> k) & 1) ? 0 : 1];  /* a half block stays inside its row */ \
         dok |= 1 << k;                                                                             \
       }                                                                                            \
     }                                                                                              \
@@ -191,11 +195,11 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
       if (x_goff[k] >= 0 && ir_ >= 0 && ir_ < a.H) {                                               \
         const float* q_ = xb_ + x_goff[k];                                                         \
         const float4* p_ = reinterpret_cast<const float4*>(q_);                                    \
-        xv[k][0] = p_[0]; xv[k][1] = p_[1];                                                        \
+        xv[k][0] = p_[0]; xv[k][1] = p_[((x_half >> k) & 1) ? 0 : 1];                              \
         /* edge slots load an in-image neighbour instead (zeroed at commit): no select on a   */   \
         /* loaded value here, it would put an s_waitcnt vmcnt into the issue phase             */   \
         if (want_m1) xe[k][0] = q_[((x_edge >> k) & 1) ? 0 : -1];                                  \
-        if (want_p1) xe[k][1] = q_[((x_edge >> (8 + k)) & 1) ? 7 : 8];                             \
+        if (want_p1) xe[k][1] = q_[((x_edge >> (8 + k)) & 1) ? 3 : 8];                             \
         xok |= 1 << k;                                                                             \
       }                                                                                            \
     }                                                                                              \
@@ -208,7 +212,9 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
       const float r_[8] = {xv[k][0].x, xv[k][0].y, xv[k][0].z, xv[k][0].w,                         \
                            xv[k][1].x, xv[k][1].y, xv[k][1].z, xv[k][1].w};                        \
       float e_[8];                                                                                 \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) e_[c] = ld_ ? pg_apply_act(r_[c], ACT) : 0.f;  \
+      const bool hb_ = (x_half >> k) & 1;                                                          \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                \
+        e_[c] = (ld_ && !(hb_ && c >= 4)) ? pg_apply_act(r_[c], ACT) : 0.f;                        \
       u32x4 p_[3];                                                                                 \
       split8(e_, p_[0], p_[1], p_[2]);                                                             \
       const int ent_ = x_meta[k] & 0xfffff;                                                        \
@@ -274,8 +280,9 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
         const float r[8] = {dv[k][0].x, dv[k][0].y, dv[k][0].z, dv[k][0].w,
                             dv[k][1].x, dv[k][1].y, dv[k][1].z, dv[k][1].w};
         float e[8];
+        const bool hb = (d_half >> k) & 1;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) e[c] = ld ? r[c] : 0.f;
+        for (int c = 0; c < 8; ++c) e[c] = (ld && !(hb && c >= 4)) ? r[c] : 0.f;
         u32x4 h, m, l;
         split8(e, h, m, l);
         u32x4* dst = lds16 + (d_meta[k] & 0xfffff);
@@ -608,10 +615,11 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
                        const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st) {
   static const bool on = []() { const char* e = getenv("PG_WGRAD_B3"); return !(e && e[0] == '0'); }();
   if (!on) return 0;
-  if (IH != OH || IW != OW || OW % 8 != 0 || Cout % 32 != 0 || Cin % WB_CI != 0) return 0;
+  if (IH != OH || IW != OW || OW % 4 != 0 || Cout % 32 != 0 || Cin % WB_CI != 0) return 0;
   const int MR = Cout % WB_CO == 0 ? 2 : 1;  // 64 or 32 dy channels per workgroup
   const int wb_co = 32 * MR;
-  if (MR == 1 && T == 1) return 0;  // 1x1 with 32 output channels: too little MFMA work per staged tile
+  if (MR == 1 && T == 1) return 0;  // 1x1 with 32 output channels: too little MFMA work per staged tile (measured on
+                                    // PixelCNN's 64 -> 32 layers: 70.9 vs 70.6 k img/s against the fp32 direct-fragment kernel)
   if (!(T == 1 || T == 2 || T == 3 || T == 4 || T == 6 || T == 9)) return 0;
   if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return 0;
   WbArgs a;
@@ -629,7 +637,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   }
   for (int v = a.ndc; v < 3; ++v) a.dcs[v] = 0;
   const int hr = max_dr - min_dr;
-  const int PBR = OW / 8;
+  const int PBR = (OW + 7) / 8;  // W % 8 == 4: the last pixel block of a row is half full
   // tile rows: K steps of 4 pixel blocks, staging slots within the per-thread caps, LDS within budget
   int TR = 0;
   for (int tr = 1; tr <= OH + 3; ++tr) {

@@ -79,6 +79,10 @@ CONV_CASES = [
     (3, 32, 10, 20, 32, 1, 3, 0, 1, None, None, "relu", False, False),  # 1 x 3 grid, W = 20, no bias
     (3, 32, 9, 16, 96, 2, 1, 2, 0, "hw", None, None, False, True),      # 2 x 1 grid, three co chunks
     (3, 64, 8, 24, 32, 2, 3, 1, 1, "hw", None, "gelu", True, True),     # 2 x 3 grid, two ci chunks
+    # half pixel blocks (W % 8 == 4) on the x-copy bf16x3 weight-gradient kernel (64 output channels)
+    (40, 32, 28, 28, 64, 1, 1, 0, 0, None, None, "relu", False, True),  # PixelCNN's 1x1 32 -> 64
+    (3, 32, 12, 12, 64, 2, 2, 1, 1, "hw", None, "elu", False, True),    # 2x2, two blocks per row
+    (3, 64, 20, 20, 128, 1, 3, 0, 1, None, None, None, True, True),     # 1x3, W = 20
 ]
 
 
