@@ -118,10 +118,14 @@ __device__ __forceinline__ void split8t(const float (&x)[8], u32x4& h, u32x4& m,
 // MS ("multi-stream epilogue"): v * act'(dact_src) + res + res2 with pipelined operand requests — its
 // own instantiation, because the three operand buffers cost registers that the common kernels (at 256
 // already) must not pay: with the code shared, the plain forward launch went from 136 to 185 us.
-template <int MT, int NT, int CG, bool MS = false>
+// W9 ("wide weights"): 9 weight slots and 2 x slots per thread instead of 6 and 4 — the plan of a 3x3 with 64 output
+// channels (8-channel chunks: one channel group x 9 taps = 3 K steps, a 36 KB weight slab per step), which otherwise
+// does not fit the staging slots and runs on the fp32-MFMA kernel.
+template <int MT, int NT, int CG, bool MS = false, bool W9 = false>
 __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kernel(const B3Args a) {
   constexpr int THREADS = B3_THREADS * CG;
-  constexpr int XS = CG == 1 ? B3_XS : (B3_XS + 1) / 2;  // the tile's slots over twice the threads
+  constexpr int WS = W9 ? 9 : B3_WS;
+  constexpr int XS = W9 ? 2 : (CG == 1 ? B3_XS : (B3_XS + 1) / 2);  // the tile's slots over twice the threads
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -198,20 +202,20 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
   const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) +
                          (size_t)(CG == 1 ? blockIdx.y : blockIdx.y * CG + (tid >> 8)) * nchunk * a.wslab4;
   float xv[XS][8];
-  float4 wv[B3_WS];
+  float4 wv[WS];
 #pragma unroll
   for (int k = 0; k < XS; ++k)
 #pragma unroll
     for (int c = 0; c < 8; ++c) xv[k][c] = 0.f;
 #pragma unroll
-  for (int k = 0; k < B3_WS; ++k) wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < WS; ++k) wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
 #define PG_B3_ISSUE(STEP)                                                                  \
   {                                                                                        \
     const int tl_ = (STEP) / nchunk;                                                       \
     const int ch_ = (STEP) - tl_ * nchunk;                                                 \
     const float4* ws_ = wsrc_b + (size_t)ch_ * a.wslab4;                                   \
-    _Pragma("unroll") for (int k = 0; k < B3_WS; ++k) {                                    \
+    _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                    \
       const int i = wt + k * B3_THREADS;                                                   \
       if (i < a.wslab4) wv[k] = ws_[i];                                                    \
     }                                                                                      \
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
     }                                                                                      \
     float4* wdst_ = reinterpret_cast<float4*>(lds16 + a.w_off16) +                         \
                     (CG == 1 ? 0 : (tid >> 8) * a.wslab4);                                 \
-    _Pragma("unroll") for (int k = 0; k < B3_WS; ++k) {                                    \
+    _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                    \
       const int i = wt + k * B3_THREADS;                                                   \
       if (i < a.wslab4) wdst_[i] = wv[k];                                                  \
     }                                                                                      \
@@ -761,6 +765,7 @@ inline int b3_chunks(int M) { return (M + B3_CO_CHUNK - 1) / B3_CO_CHUNK; }
 struct B3Plan {
   int ok, CIB, cgs, groups, ksteps, MT;
   size_t w_bytes;
+  int w9;  // the plan needs the 9-weight-slot instantiation (conv_b3_kernel<.., W9 = true>)
 };
 
 constexpr int B3_PX_CAP = 352;  // tile pixels (with halo) the LDS plan assumes for T > 1 (T == 1: 256)
@@ -787,8 +792,17 @@ B3Plan b3_plan(int Kc, int M, int T) {
     const double cost = (double)ksteps / CIB + 0.002 / CIB;  // MFMA work per channel, then fewer steps
     if (cost < best_cost) {
       best_cost = cost;
-      best = {1, CIB, cgs, groups, ksteps, MT, wb_s};
+      best = {1, CIB, cgs, groups, ksteps, MT, wb_s, 0};
     }
+  }
+  static const bool w9_on = []() { const char* e = getenv("PG_CONV_B3_W9"); return !(e && e[0] == '0'); }();
+  if (!best.ok && w9_on && MT == 4 && Kc % 8 == 0) {
+    // nothing fits 6 weight slots per thread: one 8-channel group per chunk with 9 slots (3x3, >= 64 output channels)
+    const int cgs = 1, groups = T, ksteps = (groups + 3) / 4;
+    const size_t xb = (size_t)cgs * 3 * px * 16, wb = (size_t)ksteps * MT * 3 * 1024;
+    if (ksteps <= 5 && groups <= B3_MAXG && xb + wb + (size_t)4 * 16 * 68 * 4 + 1024 <= 80 * 1024 &&
+        (long)cgs * px <= 2L * B3_THREADS && (long)ksteps * MT * 192 <= 9L * B3_THREADS)
+      best = {1, 8, cgs, groups, ksteps, MT, wb, 1};
   }
   return best;
 }
@@ -804,17 +818,17 @@ int b3_rows(int T, int OH, int OW, int hr, int hc) {
   return (OH + nt_rows - 1) / nt_rows;
 }
 
-template <int MT, int CG = 1, bool MS = false>
+template <int MT, int CG = 1, bool MS = false, bool W9 = false>
 void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
   // the LDS opt-in is set once per instantiation by a function-local static initialiser: thread-safe
   // (the library is entered from the main thread and from the autograd thread)
 #define PG_B3_L(NTV)                                                                                  \
   {                                                                                                   \
     static const hipError_t attr_##NTV = hipFuncSetAttribute(                                         \
-        reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV, CG, MS>),                               \
+        reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV, CG, MS, W9>),                           \
         hipFuncAttributeMaxDynamicSharedMemorySize, CG == 1 ? 80 * 1024 : 160 * 1024);                \
     (void)attr_##NTV;                                                                                 \
-    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV, CG, MS>), grid, dim3(B3_THREADS * CG), shmem, st, a); \
+    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV, CG, MS, W9>), grid, dim3(B3_THREADS * CG), shmem, st, a); \
   }
   switch (nt) {
     case 1: PG_B3_L(1) break;
@@ -975,7 +989,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
   // wide workgroups (two output chunks share one staged x tile): default; PG_CONV_B3_WIDE=0 for A/B
   static const bool wide_on = []() { const char* e = getenv("PG_CONV_B3_WIDE"); return !(e && e[0] == '0'); }();
-  const int CG = (wide_on && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0) ? 2 : 1;
+  const int CG = (wide_on && !pl.w9 && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0) ? 2 : 1;
   size_t shmem = (size_t)a.w_off16 * 16 + pl.w_bytes * CG;
   a.ep_off = (int)(shmem / 4);
   shmem += (size_t)4 * CG * 16 * 68 * 4;
@@ -995,6 +1009,12 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     if (ms) b3_launch<4, 2, true>(a, nt, grid, shmem, st);
     else b3_launch<4, 2>(a, nt, grid, shmem, st);
     PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, wide)");
+    return 0;
+  }
+  if (pl.w9) {
+    if (ms) b3_launch<4, 1, true, true>(a, nt, grid, shmem, st);
+    else b3_launch<4, 1, false, true>(a, nt, grid, shmem, st);
+    PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, 9 weight slots)");
     return 0;
   }
   if (ms) {
