@@ -93,7 +93,7 @@ __device__ __forceinline__ f32x4 load_vec(const float* __restrict__ v, int g) {
   return f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_f(float x) { return pg_gelu(x); }
 
 // row `ch` of the merged [W_q; W_kv] matrix (each row has C entries)
 __device__ __forceinline__ const float* qkv_row(const BlockArgs& a, int ch) {
@@ -377,8 +377,9 @@ __global__ void __launch_bounds__(GB_THREADS) tail_bwd_kernel(const BlockArgs a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float hv = h[m][r];
-        const float cdf = 0.5f * (1.f + erff(hv * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * __expf(-0.5f * hv * hv);
+        float cdf, ee;
+        pg_gelu_parts(hv, cdf, ee);
+        const float pdf = 0.39894228040143267794f * ee;
         const float dh = dg[m][r] * (cdf + hv * pdf);
         const int hid = 16 * m + 4 * g + r;
         tg[hid * TS + j] = hv * cdf;

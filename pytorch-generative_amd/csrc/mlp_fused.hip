@@ -33,7 +33,7 @@ constexpr int C = 16, HD = 64;           // channels, hidden units (the only ins
 constexpr int MLP_THREADS = 256;         // 4 waves
 constexpr int PART = HD * C + HD + C * HD + C;  // dW1 | db1 | dW2 | db2 floats per partial row
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_f(float x) { return pg_gelu(x); }
 
 struct MlpArgs {
   const float* x; const float* w1; const float* b1; const float* w2; const float* b2;
@@ -160,8 +160,9 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_bwd_kernel(const MlpArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float hv = h[m][r];
-        const float cdf = 0.5f * (1.f + erff(hv * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * __expf(-0.5f * hv * hv);
+        float cdf, ee;
+        pg_gelu_parts(hv, cdf, ee);
+        const float pdf = 0.39894228040143267794f * ee;
         const float gv = hv * cdf;
         const float dh = dg[m][r] * (cdf + hv * pdf);
         const int hid = 16 * m + 4 * g + r;
