@@ -21,687 +21,12 @@
 // fragments [k step][co tile][piece][lane] (pg_pack_conv_weight_frag*).
 // Workgroups are persistent like conv_mfma's: (tile, channel chunk) steps with the next step's
 // loads in flight under the MFMA loop.
-#include "common.h"
-#include <stdint.h>
-#include <stdlib.h>
+#include "conv_b3_kernels.h"
+
+// conv_b3_gelu.hip: the same launch on the instantiations that carry the GELU paths
+void pg_b3_dispatch_gelu(const B3Args& a, const B3Launch& l, hipStream_t st);
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int B3_THREADS = 256;
-constexpr int B3_CO_CHUNK = 64;
-constexpr int B3_XS = 4;       // (pixel, channel-group) staging slots per thread per step: 8 loads each
-constexpr int B3_WS = 6;       // float4 weight-fragment slots per thread per step
-constexpr int B3_MAXG = 20;    // groups per chunk (<= 5 K steps)
-
-struct B3Args {
-  const float* in;
-  const float* wfrag;
-  const float* bias;
-  const float* res;
-  const float* res2;      // second residual operand (data gradients with two pass-through gradients)
-  const float* dact_src;
-  float* out;
-  long res_bs, res2_bs;   // batch strides of res / res2 in floats (a channel slice of a wider tensor)
-  float res_scale;        // conv_b3_pw_kernel: res is added res_scale times (2 = both residual operands are ONE tensor)
-  int N, Cin, IH, IW, Cout, OH, OW, T;
-  int TR, tiles_per_img, tile_h, tile_w, min_dr, min_dc;
-  int CIB, cgs, groups, ksteps;   // channels per chunk, CIB / 8, cgs * T, ceil(groups / 4)
-  int plane16;                    // 16-byte entries per (channel group, piece) plane (multiple of 16)
-  int w_off16, b_off, ep_off, dump16;  // LDS offsets: weights (16-byte units), bias / epilogue scratch (floats), dump entry
-  int xslots, wslab4;             // staging slots per step; float4 per step's weight slab
-  int in_act, dact, out_act;
-  int dbg;                        // ablation switches (PG_B3_DBG), 0 in production
-  int g_tapoff[B3_MAXG];          // per group: tap offset in tile pixels
-  int g_cg[B3_MAXG];              // per group: channel group of the chunk
-};
-
-__device__ __forceinline__ unsigned int pack2(__bf16 a, __bf16 b) {
-  return (unsigned int)__builtin_bit_cast(unsigned short, a) |
-         ((unsigned int)__builtin_bit_cast(unsigned short, b) << 16);
-}
-
-// 8 fp32 -> three bf16x8 (h, m, l pieces)
-__device__ __forceinline__ void split8(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
-  __bf16 hh[8], mm[8], ll[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    hh[i] = (__bf16)x[i];
-    const float r1 = x[i] - (float)hh[i];
-    mm[i] = (__bf16)r1;
-    ll[i] = (__bf16)(r1 - (float)mm[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = pack2(hh[2 * i], hh[2 * i + 1]);
-    m[i] = pack2(mm[2 * i], mm[2 * i + 1]);
-    l[i] = pack2(ll[2 * i], ll[2 * i + 1]);
-  }
-}
-
-// the same split by TRUNCATION for the x tiles staged inside the kernel (h = top 16 bits of x,
-// m = top 16 bits of x - h, l = x - h - m: exact, 24 = 8 + 8 + 8 significand bits): and + sub per
-// piece instead of convert / unpack / sub — the staging arithmetic is paid per step by every
-// workgroup (conv_wgrad_b3.hip measures the difference). Weights keep round-to-nearest pieces
-// (packed once per step by b3_pack_kernel); the dropped products stay below one fp32 rounding.
-__device__ __forceinline__ void split8t(const float (&x)[8], u32x4& h, u32x4& m, u32x4& l) {
-  unsigned int xb[8], r1b[8], r2b[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    xb[i] = __builtin_bit_cast(unsigned int, x[i]);
-    const float r1 = x[i] - __builtin_bit_cast(float, xb[i] & 0xffff0000u);
-    r1b[i] = __builtin_bit_cast(unsigned int, r1);
-    const float r2 = r1 - __builtin_bit_cast(float, r1b[i] & 0xffff0000u);
-    r2b[i] = __builtin_bit_cast(unsigned int, r2);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {  // v_perm_b32: {hi16(odd element), hi16(even element)}
-    h[i] = __builtin_amdgcn_perm(xb[2 * i + 1], xb[2 * i], 0x07060302u);
-    m[i] = __builtin_amdgcn_perm(r1b[2 * i + 1], r1b[2 * i], 0x07060302u);
-    l[i] = __builtin_amdgcn_perm(r2b[2 * i + 1], r2b[2 * i], 0x07060302u);
-  }
-}
-
-#define MFMA16B(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
-
-// CG = output-channel chunks per workgroup. CG = 1: 4 waves, one 64-channel chunk (two workgroups per
-// CU). CG = 2 ("wide", the default for Cout % 128 == 0; PG_CONV_B3_WIDE=0 for A/B): 8 waves = two
-// 64-channel chunks x four pixel quarters sharing ONE staged x tile — with one chunk per workgroup every
-// chunk re-stages the same tile (loads + activation + split are ~30 % of a launch). Measured on MI355X
-// (round 3, tools/exp/conv_ab.py): forward 2x2 64 -> 128 75 -> 68 us, 2x1 256 -> 256 71 -> 64 us, 1x3
-// 128 -> 256 59 -> 56 us; GatedPixelCNN 4.27 -> 4.54 k img/s at batch 512. Both halves of a gate input
-// also meet in one workgroup. (A float4 "vector epilogue" variant was measured in the same call and
-// dropped: 136.6 vs 133 us on the 2x2 64 -> 64, slower combined with CG = 2 — it spilled registers.)
-// MS ("multi-stream epilogue"): v * act'(dact_src) + res + res2 with pipelined operand requests — its
-// own instantiation, because the three operand buffers cost registers that the common kernels (at 256
-// already) must not pay: with the code shared, the plain forward launch went from 136 to 185 us.
-// W9 ("wide weights"): 9 weight slots and 2 x slots per thread instead of 6 and 4 — the plan of a 3x3 with 64 output
-// channels (8-channel chunks: one channel group x 9 taps = 3 K steps, a 36 KB weight slab per step), which otherwise
-// does not fit the staging slots and runs on the fp32-MFMA kernel.
-template <int MT, int NT, int CG, bool MS = false, bool W9 = false>
-__global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kernel(const B3Args a) {
-  constexpr int THREADS = B3_THREADS * CG;
-  constexpr int WS = W9 ? 9 : B3_WS;
-  constexpr int XS = W9 ? 2 : (CG == 1 ? B3_XS : (B3_XS + 1) / 2);  // the tile's slots over twice the threads
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cgp = CG == 1 ? 0 : wave_all >> 2;       // which of the workgroup's output chunks
-  const int wave = CG == 1 ? wave_all : wave_all & 3;  // pixel quarter of the tile
-  // persistent: one row-tile index per workgroup, images n = n_first, n_first + nstep, ...
-  const int rt = blockIdx.x % a.tiles_per_img;
-  const int n_first = blockIdx.x / a.tiles_per_img, nstep = gridDim.x / a.tiles_per_img;
-  const int row0 = rt * a.TR;
-  const int rows = min(a.TR, a.OH - row0);
-  const int npx = rows * a.OW;
-  const int co0 = (blockIdx.y * CG + cgp) * B3_CO_CHUNK;
-  const int L = a.OH * a.OW;
-  const int plane = a.IH * a.IW;
-  const int nchunk = a.Cin / a.CIB;
-  const int ntiles = n_first < a.N ? (a.N - n_first + nstep - 1) / nstep : 0;
-  const int nsteps = ntiles * nchunk;
-  if (nsteps == 0) return;
-  const int kq = lane >> 4;
-
-  int pixoff[NT];  // tile pixel (16-byte entry index) of this lane's pixel of each 16-pixel group
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int p = (wave * NT + n) * 16 + (lane & 15);
-    const int pc = p < npx ? p : 0;
-    const int r = pc / a.OW;
-    pixoff[n] = r * a.tile_w + (pc - r * a.OW);
-  }
-  const int pw = wave * (NT * 16) + lane;  // store phase: lane = pixel
-  const bool sok = (lane < NT * 16) && pw < npx;
-  size_t so_rel;
-  {
-    const int pc = sok ? pw : 0;
-    const int r = pc / a.OW;
-    so_rel = (size_t)co0 * L + (size_t)((row0 + r) * a.OW + (pc - r * a.OW));
-  }
-  // per group g = 4 ks + kq: where it lives — plane of its channel group + tap offset (LDS table)
-  int* gtab = reinterpret_cast<int*>(lds + a.b_off + B3_CO_CHUNK * CG);
-  if (tid < B3_MAXG) gtab[tid] = tid < a.groups ? a.g_cg[tid] * 3 * a.plane16 + a.g_tapoff[tid] : 0;
-
-  // ---- staging slots: (channel group, tile row, tile column) -> 8 channel loads of one pixel
-  int s_goff[XS], s_loff[XS];  // global offset of channel cg*8 (floats), LDS entry of piece 0; -1: no slot
-#pragma unroll
-  for (int k = 0; k < XS; ++k) {
-    int e = tid + k * THREADS;
-    const bool in = e < a.xslots;
-    e = in ? e : 0;
-    const int tc = e % a.tile_w;
-    e /= a.tile_w;
-    const int tr = e % a.tile_h;
-    const int cg = e / a.tile_h;
-    const int ir = row0 + a.min_dr + tr, ic = a.min_dc + tc;
-    const bool ok = in && ir >= 0 && ir < a.IH && ic >= 0 && ic < a.IW;
-    s_goff[k] = ok ? (cg * 8) * plane + ir * a.IW + ic : -1;
-    s_loff[k] = cg * 3 * a.plane16 + tr * a.tile_w + tc;
-  }
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // zero the x planes once (halo / out-of-image entries are never written afterwards)
-  for (int i = tid; i < a.cgs * 3 * a.plane16; i += THREADS) lds16[i] = u32x4{0u, 0u, 0u, 0u};
-  if (tid < B3_CO_CHUNK * CG) {
-    const int co = CG == 1 ? co0 + tid : blockIdx.y * CG * B3_CO_CHUNK + tid;
-    lds[a.b_off + tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-  }
-
-  // weight slab of this thread's chunk: threads [256 c, 256 c + 256) load and commit chunk c's slab
-  const int wt = CG == 1 ? tid : tid & (B3_THREADS - 1);
-  const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) +
-                         (size_t)(CG == 1 ? blockIdx.y : blockIdx.y * CG + (tid >> 8)) * nchunk * a.wslab4;
-  float xv[XS][8];
-  float4 wv[WS];
-#pragma unroll
-  for (int k = 0; k < XS; ++k)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) xv[k][c] = 0.f;
-#pragma unroll
-  for (int k = 0; k < WS; ++k) wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-#define PG_B3_ISSUE(STEP)                                                                  \
-  {                                                                                        \
-    const int tl_ = (STEP) / nchunk;                                                       \
-    const int ch_ = (STEP) - tl_ * nchunk;                                                 \
-    const float4* ws_ = wsrc_b + (size_t)ch_ * a.wslab4;                                   \
-    _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                    \
-      const int i = wt + k * B3_THREADS;                                                   \
-      if (i < a.wslab4) wv[k] = ws_[i];                                                    \
-    }                                                                                      \
-    const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
-    if (!((a.dbg & 1) && (STEP) > 0))                                                      \
-    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                       \
-      if (s_goff[k] >= 0) {                                                                \
-        const float* p_ = src_ + s_goff[k];                                                \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = p_[(size_t)c * plane];    \
-      }                                                                                    \
-    }                                                                                      \
-  }
-#define PG_B3_COMMIT_X(ACT)                                                                \
-  _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                         \
-    int lo_ = s_loff[k];                                                                   \
-    asm volatile("" : "+v"(lo_));                                                          \
-    float e_[8];                                                                           \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) e_[c] = pg_apply_act(xv[k][c], ACT);     \
-    u32x4 h_, m_, l_;                                                                      \
-    split8t(e_, h_, m_, l_);                                                               \
-    const int dst_ = s_goff[k] >= 0 ? lo_ : a.dump16;                                      \
-    lds16[dst_] = h_;                                                                      \
-    lds16[dst_ + (s_goff[k] >= 0 ? a.plane16 : 0)] = m_;                                   \
-    lds16[dst_ + (s_goff[k] >= 0 ? 2 * a.plane16 : 0)] = l_;                               \
-  }
-#define PG_B3_COMMIT_ALL()                                                                 \
-  {                                                                                        \
-    switch (a.in_act) { /* wave-uniform */                                                 \
-      case PG_ACT_RELU: PG_B3_COMMIT_X(PG_ACT_RELU) break;                                 \
-      case PG_ACT_ELU:  PG_B3_COMMIT_X(PG_ACT_ELU) break;                                  \
-      case PG_ACT_GELU: PG_B3_COMMIT_X(PG_ACT_GELU) break;                                 \
-      default:          PG_B3_COMMIT_X(PG_ACT_NONE) break;                                 \
-    }                                                                                      \
-    float4* wdst_ = reinterpret_cast<float4*>(lds16 + a.w_off16) +                         \
-                    (CG == 1 ? 0 : (tid >> 8) * a.wslab4);                                 \
-    _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                    \
-      const int i = wt + k * B3_THREADS;                                                   \
-      if (i < a.wslab4) wdst_[i] = wv[k];                                                  \
-    }                                                                                      \
-  }
-
-  // Pipeline over the (tile, channel chunk) steps of this workgroup, ONE x / weight tile in LDS:
-  //   MFMA(s) | barrier | commit(s+1) (its loads were issued a whole step earlier) |
-  //   issue loads(s+2) | [epilogue of the tile that ended at s, in per-wave scratch] | barrier
-  // so loads have a whole step (+ an epilogue) to land and the epilogue's stores fly under MFMA(s+1).
-  constexpr int EPS = 68;
-  const float* bl = lds + a.b_off + (CG == 1 ? 0 : cgp * B3_CO_CHUNK);
-  const bf16x8* xl = reinterpret_cast<const bf16x8*>(lds16);
-  const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds16 + a.w_off16) + (CG == 1 ? 0 : cgp * a.wslab4) + lane;
-  PG_B3_ISSUE(0)
-  PG_B3_COMMIT_ALL()
-  __syncthreads();
-  if (nsteps > 1) PG_B3_ISSUE(1)
-  for (int step = 0; step < nsteps; ++step) {
-    const int tl = step / nchunk;
-    const bool more = step + 1 < nsteps;
-    if (!(a.dbg & 4))
-    for (int ks = 0; ks < a.ksteps; ++ks) {
-      bf16x8 af[MT][3];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) af[m][pc] = wl[((ks * MT + m) * 3 + pc) * 64];
-      const bf16x8* xb = xl + gtab[4 * ks + kq];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const bf16x8 bh = xb[pixoff[n]];
-        const bf16x8 bm = xb[pixoff[n] + a.plane16];
-        const bf16x8 bo = xb[pixoff[n] + 2 * a.plane16];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          f32x4 c = acc[m][n];
-          c = MFMA16B(af[m][2], bh, c);  // small terms first
-          c = MFMA16B(af[m][0], bo, c);
-          c = MFMA16B(af[m][1], bm, c);
-          c = MFMA16B(af[m][1], bh, c);
-          c = MFMA16B(af[m][0], bm, c);
-          c = MFMA16B(af[m][0], bh, c);
-          acc[m][n] = c;
-        }
-      }
-    }
-    __syncthreads();  // every wave is done with the tiles: the next commit may overwrite them
-    if (more && !((a.dbg & 2))) PG_B3_COMMIT_ALL()
-    if (step + 2 < nsteps) PG_B3_ISSUE(step + 2)
-    const bool last_chunk = (step + 1) % nchunk == 0;
-    if (last_chunk && !(a.dbg & 8)) {
-      // ---- epilogue: v = out_act(acc + bias) * act'(dact_src) + res + res2; per-wave transposition
-      // scratch of its own (the tiles already hold the next step). The derivative comes BEFORE the
-      // residuals: in a data gradient res / res2 are pass-through gradients of the same tensor (skip
-      // connections), which the activation derivative of the convolution's own input does not touch.
-      const int n_img = n_first + tl * nstep;
-      const size_t so = so_rel + (size_t)n_img * a.Cout * L;
-      float* ep = lds + a.ep_off + wave_all * (16 * EPS);
-      const int cvalid = a.Cout - co0;
-      float* outp = a.out + so;
-      const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr, has_res2 = a.res2 != nullptr;
-#define PG_B3_TILE_BODY(M)                                                                       \
-  _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
-  _Pragma("unroll") for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[M][n][r]; \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
-  float v[16];                                                                                   \
-  _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = ep[c * EPS + lane] + bl[(M) * 16 + c];   \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
-  switch (a.out_act) { /* wave-uniform */                                                        \
-    case PG_ACT_RELU: _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_RELU); break; \
-    case PG_ACT_ELU:  _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_ELU); break;  \
-    case PG_ACT_GELU: _Pragma("unroll") for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_GELU); break; \
-    default: break;                                                                              \
-  }
-#define PG_B3_TILE_STORE(M)                                                   \
-  if (sok) {                                                                  \
-    _Pragma("unroll") for (int c = 0; c < 16; ++c) {                          \
-      const int cc = (M) * 16 + c;                                            \
-      if (cc < cvalid) outp[(size_t)cc * L] = v[c];                           \
-    }                                                                         \
-  }
-      if (!has_res && !has_ds) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          PG_B3_TILE_BODY(m)
-          PG_B3_TILE_STORE(m)
-        }
-      } else {
-        if constexpr (MS) {
-        // Up to three operand streams (derivative source, res, res2). Loads and stores share vmcnt and
-        // retire in order, so a load issued behind a tile's stores waits for them: the operands of tile
-        // m + 1 are therefore requested BEFORE the stores of tile m (single buffer: right after tile
-        // m's values have been used); the wait in front of their use then covers the loads only.
-        const float* st0 = has_ds ? a.dact_src + so : nullptr;
-        const float* st1 = has_res ? a.res + so_rel + (size_t)n_img * a.res_bs : nullptr;
-        const float* st2 = has_res2 ? a.res2 + so_rel + (size_t)n_img * a.res2_bs : nullptr;
-        const int dsel = has_ds ? a.dact : PG_ACT_NONE;
-        // half tiles (8 channels) at a time: 24 operand registers instead of 48 (the kernel is at its
-        // register limit; with whole-tile buffers this instantiation spilled 33 dwords)
-        float o0[8], o1[8], o2[8];
-#define PG_B3_REQUEST(M, H)                                                                \
-  _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                          \
-    const int cc = (M) * 16 + (H) * 8 + c;                                                 \
-    const size_t off_ = (size_t)(cc < cvalid ? cc : 0) * L;                                \
-    if (st0) o0[c] = st0[off_];                                                            \
-    if (st1) o1[c] = st1[off_];                                                            \
-    if (st2) o2[c] = st2[off_];                                                            \
-  }
-        PG_B3_REQUEST(0, 0)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          PG_B3_TILE_BODY(m)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            switch (dsel) {
-              case PG_ACT_RELU:
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_RELU);
-                break;
-              case PG_ACT_ELU:
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_ELU);
-                break;
-              case PG_ACT_GELU:
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_GELU);
-                break;
-              case PG_ACT_ELU_OUT:
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_ELU_OUT);
-                break;
-              default: break;
-            }
-            if (st1) {
-#pragma unroll
-              for (int c = 0; c < 8; ++c) v[hh * 8 + c] += o1[c];
-            }
-            if (st2) {
-#pragma unroll
-              for (int c = 0; c < 8; ++c) v[hh * 8 + c] += o2[c];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (hh == 0) { PG_B3_REQUEST(m, 1) }
-            else if (m + 1 < MT) { PG_B3_REQUEST(m + 1, 0) }
-            __builtin_amdgcn_sched_barrier(0);
-            if (sok) {
-#pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                const int cc = m * 16 + hh * 8 + c;
-                if (cc < cvalid) outp[(size_t)cc * L] = v[hh * 8 + c];
-              }
-            }
-          }
-        }
-#undef PG_B3_REQUEST
-        } else {
-          // one or two operand streams as measured in round 2: the first one requested for two tiles
-          // before any store, a derivative source behind a residual per tile (res + res -> * act')
-        const float* op1 = (has_res ? a.res : a.dact_src) + so;
-        const float* op2 = (has_res && has_ds) ? a.dact_src + so : nullptr;
-        constexpr int MH = MT > 2 ? 2 : MT;
-        float ov[MH][16];
-        const int dsel = has_ds ? a.dact : PG_ACT_NONE;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          if (m % MH == 0) {
-#pragma unroll
-            for (int mm = 0; mm < MH; ++mm)
-#pragma unroll
-              for (int c = 0; c < 16; ++c) {
-                const int cc = (m + mm) * 16 + c;
-                ov[mm][c] = op1[(size_t)(cc < cvalid ? cc : 0) * L];
-              }
-          }
-          PG_B3_TILE_BODY(m)
-          float sv[16];
-          if (has_res) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] += ov[m % MH][c];
-            if (op2) {
-#pragma unroll
-              for (int c = 0; c < 16; ++c) {
-                const int cc = m * 16 + c;
-                sv[c] = op2[(size_t)(cc < cvalid ? cc : 0) * L];
-              }
-            }
-          } else {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) sv[c] = ov[m % MH][c];
-          }
-          switch (dsel) {
-            case PG_ACT_RELU:
-#pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_RELU);
-              break;
-            case PG_ACT_ELU:
-#pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU);
-              break;
-            case PG_ACT_GELU:
-#pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_GELU);
-              break;
-            case PG_ACT_ELU_OUT:
-#pragma unroll
-              for (int c = 0; c < 16; ++c) v[c] *= pg_act_grad(sv[c], PG_ACT_ELU_OUT);
-              break;
-            default: break;
-          }
-          PG_B3_TILE_STORE(m)
-        }
-        }
-      }
-#undef PG_B3_TILE_BODY
-#undef PG_B3_TILE_STORE
-    }
-    if (last_chunk) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (more) __syncthreads();  // the commit is visible before the next MFMA loop
-  }
-#undef PG_B3_ISSUE
-#undef PG_B3_COMMIT_X
-#undef PG_B3_COMMIT_ALL
-}
-
-// ---- 1x1 convolutions: no x tile in LDS ---------------------------------------------------------------
-// With one tap a wave's B fragments are read by that wave only, so staging x through LDS buys nothing and
-// costs the workgroup barriers that keep the waves of conv_b3_kernel in lockstep (loads, split and MFMA
-// phases back to back). Here every wave is on its own: the weights of the output chunk (all channel chunks,
-// <= 24 KB) go to LDS once per workgroup, then a wave walks its 32-pixel tiles with no further barrier —
-// float2 loads straight into the B-fragment layout, activation + split in registers, the next chunk's loads
-// in flight under the MFMAs, and the other waves of the SIMD filling the matrix pipe meanwhile (a 64 x 32
-// accumulator tile: two waves per SIMD at 64 output channels, three / four at 32 / 16).
-// Column j of pixel group n is pixel 2 j + n of the tile: lane (j, kq) then needs 2 CONSECUTIVE pixels of
-// its 8 channels = one float2 per channel (16 lanes x 8 B = 128 contiguous bytes per channel and load).
-// Same packed weights and epilogue (bias, activation, derivative of the fused input activation, up to two
-// residual streams) as conv_b3_kernel.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int PW_EPS = 36;   // floats per channel row of a wave's 16 x 32 transposition scratch
-constexpr int PW_WAVES = 4;
-
-template <int MT, bool MS>
-__global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)) conv_b3_pw_kernel(const B3Args a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kq = lane >> 4, jc = lane & 15;
-  const int L = a.OH * a.OW;
-  const int nchunk = a.Cin / a.CIB;
-  const int co0 = blockIdx.y * B3_CO_CHUNK;
-  const int tpi = (L + 31) >> 5;  // 32-pixel tiles per image, the last one may be ragged (L % 2 == 0)
-  const int nitems = a.N * tpi;
-
-  {  // weights of this output chunk, every channel chunk: [j][co tile][piece][lane] 16-byte fragments
-    const float4* wsrc = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * a.wslab4;
-    float4* wdst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < nchunk * a.wslab4; i += 64 * PW_WAVES) wdst[i] = wsrc[i];
-    if (tid < B3_CO_CHUNK) lds[a.b_off + tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
-  }
-  __syncthreads();  // the only barrier of the kernel
-
-  const int gw = blockIdx.x * PW_WAVES + wave, GW = gridDim.x * PW_WAVES;
-  if (gw >= nitems) return;
-  float* ep = lds + a.ep_off + wave * (16 * PW_EPS);
-  const float* bl = lds + a.b_off;
-  const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds) + lane;
-  const bool kact = kq < a.cgs;  // K groups beyond the chunk's channels are zero (weights packed as zero too)
-  const unsigned lane_in = (unsigned)((kact ? 8 * kq : 0) * L + 2 * jc);  // floats from the (image, chunk, tile) base
-  const size_t cstride = (size_t)L;
-  const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr, has_res2 = a.res2 != nullptr;
-  const int half = lane >> 5, px = lane & 31;  // store phase: lane = (8-channel half, pixel)
-
-  f32x2 raw[8], nxt[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) nxt[c] = f32x2{0.f, 0.f};
-// addresses = uniform base (SGPR pair: image, channel chunk, tile) + 32-bit lane offset: one VGPR per stream
-#define PG_PW_ISSUE(IT, J, DST)                                                                        \
-  {                                                                                                    \
-    const int ni_ = (IT) / tpi;                                                                        \
-    const int t0_ = ((IT) - ni_ * tpi) * 32;                                                           \
-    const bool ok_ = kact && t0_ + 2 * jc < L;                                                         \
-    /* every lane loads from a valid address (its own when ok_, the tile's first otherwise): no branches */ \
-    const unsigned lo_ = ok_ ? lane_in : 0u;                                                           \
-    const float* sb_ = a.in + ((size_t)ni_ * a.Cin + (J) * a.CIB) * cstride + t0_;                     \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                    \
-      const f32x2 t_ = *reinterpret_cast<const f32x2*>(sb_ + c * cstride + lo_);                       \
-      DST[c] = f32x2{ok_ ? t_[0] : 0.f, ok_ ? t_[1] : 0.f};                                            \
-    }                                                                                                  \
-  }
-#define PG_PW_MFMA(ACT)                                                                   \
-  _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                         \
-    float e_[8];                                                                          \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) e_[c] = pg_apply_act(raw[c][n], ACT);   \
-    u32x4 h_, m_, l_;                                                                     \
-    split8t(e_, h_, m_, l_);                                                              \
-    const bf16x8 bh = __builtin_bit_cast(bf16x8, h_);                                     \
-    const bf16x8 bm = __builtin_bit_cast(bf16x8, m_);                                     \
-    const bf16x8 bo = __builtin_bit_cast(bf16x8, l_);                                     \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                      \
-      f32x4 c = acc[m][n];                                                                \
-      c = MFMA16B(af[m][2], bh, c);                                                       \
-      c = MFMA16B(af[m][0], bo, c);                                                       \
-      c = MFMA16B(af[m][1], bm, c);                                                       \
-      c = MFMA16B(af[m][1], bh, c);                                                       \
-      c = MFMA16B(af[m][0], bm, c);                                                       \
-      c = MFMA16B(af[m][0], bh, c);                                                       \
-      acc[m][n] = c;                                                                      \
-    }                                                                                     \
-  }
-
-  PG_PW_ISSUE(gw, 0, raw)
-  for (int it = gw; it < nitems; it += GW) {
-    f32x4 acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < nchunk; ++j) {
-      const bool lastj = j + 1 == nchunk;
-      const int it2 = lastj ? it + GW : it, j2 = lastj ? 0 : j + 1;
-      if (it2 < nitems) PG_PW_ISSUE(it2, j2, nxt)
-      bf16x8 af[MT][3];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) af[m][pc] = wl[((j * MT + m) * 3 + pc) * 64];
-      switch (a.in_act) { /* wave-uniform */
-        case PG_ACT_RELU: PG_PW_MFMA(PG_ACT_RELU) break;
-        case PG_ACT_ELU:  PG_PW_MFMA(PG_ACT_ELU) break;
-        case PG_ACT_GELU: PG_PW_MFMA(PG_ACT_GELU) break;
-        default:          PG_PW_MFMA(PG_ACT_NONE) break;
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) raw[c] = nxt[c];
-    }
-    // ---- epilogue: v = out_act(acc + bias) (+ res | * act'(dact_src)), transposed through the wave's own
-    // scratch: lanes 0-31 take channels 0-7 of a 16-channel tile, lanes 32-63 channels 8-15, lane & 31 =
-    // pixel, so a store covers two runs of 128 contiguous bytes
-    const int n_img = it / tpi;
-    const int t0 = (it - n_img * tpi) * 32;
-    const bool sok = t0 + px < L;
-    const size_t so = ((size_t)n_img * a.Cout + co0) * cstride + t0;   // uniform
-    const unsigned lo = sok ? (unsigned)(8 * half * L + px) : 0u;        // lane part
-    const int cvalid = a.Cout - co0 - 8 * half;
-    float* outp = a.out + so;
-    // up to three operand streams: derivative source, residual, second residual (a residual may be a
-    // batch-strided channel slice: res_bs); v = out_act(acc + bias) * act'(o0) + o1 + o2
-    const size_t so_c = (size_t)co0 * cstride + t0;
-    const float* st0 = has_ds ? a.dact_src + so : nullptr;
-    const float* st1 = has_res ? a.res + (size_t)n_img * a.res_bs + so_c : nullptr;
-    const float* st2 = has_res2 ? a.res2 + (size_t)n_img * a.res2_bs + so_c : nullptr;
-    const int dsel = has_ds ? a.dact : PG_ACT_NONE;
-    // MS = false: at most one of the streams (one buffer); MS = true: its own instantiation (MT = 4), because
-    // two more operand buffers spill in the narrower kernels
-    constexpr int NB = MS ? 8 : 1;
-    float o0[8], o1[NB], o2[NB];
-    const float* sts = st0 ? st0 : st1;  // the single stream of the MS = false kernels
-#define PG_PW_REQUEST(M)                                                       \
-  _Pragma("unroll") for (int c = 0; c < 8; ++c) {                              \
-    const int cc = (M) * 16 + c;                                               \
-    const size_t off_ = (size_t)(cc < cvalid ? cc : 0) * cstride;              \
-    if constexpr (MS) {                                                        \
-      if (st0) o0[c] = (st0 + off_)[lo];                                       \
-      if (st1) o1[c] = (st1 + off_)[lo];                                       \
-      if (st2) o2[c] = (st2 + off_)[lo];                                       \
-    } else {                                                                   \
-      if (sts) o0[c] = (sts + off_)[lo];                                       \
-    }                                                                          \
-  }
-    PG_PW_REQUEST(0)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<f32x2*>(ep + (kq * 4 + r) * PW_EPS + 2 * jc) = f32x2{acc[m][0][r], acc[m][1][r]};
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      float v[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) v[c] = ep[(8 * half + c) * PW_EPS + px] + bl[m * 16 + 8 * half + c];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      switch (a.out_act) { /* wave-uniform */
-        case PG_ACT_RELU:
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = pg_apply_act(v[c], PG_ACT_RELU);
-          break;
-        case PG_ACT_ELU:
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = pg_apply_act(v[c], PG_ACT_ELU);
-          break;
-        case PG_ACT_GELU:
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = pg_apply_act(v[c], PG_ACT_GELU);
-          break;
-        default: break;
-      }
-      switch (dsel) {
-        case PG_ACT_RELU:
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(o0[c], PG_ACT_RELU);
-          break;
-        case PG_ACT_ELU:
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(o0[c], PG_ACT_ELU);
-          break;
-        case PG_ACT_GELU:
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(o0[c], PG_ACT_GELU);
-          break;
-        case PG_ACT_ELU_OUT:
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] *= pg_act_grad(o0[c], PG_ACT_ELU_OUT);
-          break;
-        default: break;
-      }
-      if constexpr (MS) {
-        if (st1) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = fmaf(o1[c], a.res_scale, v[c]);
-        }
-        if (st2) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] += o2[c];
-        }
-      } else {
-        if (st1) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = fmaf(o0[c], a.res_scale, v[c]);
-        }
-      }
-      // the next tile's operand is requested BEFORE this tile's stores (loads and stores retire in order)
-      __builtin_amdgcn_sched_barrier(0);
-      if (m + 1 < MT) PG_PW_REQUEST(m + 1)
-      __builtin_amdgcn_sched_barrier(0);
-      if (sok) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int cc = m * 16 + c;
-          if (cc < cvalid) (outp + (size_t)cc * cstride)[lo] = v[c];
-        }
-      }
-    }
-#undef PG_PW_REQUEST
-  }
-#undef PG_PW_ISSUE
-#undef PG_PW_MFMA
-}
 
 // ---- weight pack: A fragments of the three bf16 pieces ------------------------------------------
 // wfrag (16-byte units) [co chunk][channel chunk][k step][co tile m][piece][lane]: the 8 bf16 of
@@ -818,35 +143,6 @@ int b3_rows(int T, int OH, int OW, int hr, int hc) {
   return (OH + nt_rows - 1) / nt_rows;
 }
 
-template <int MT, int CG = 1, bool MS = false, bool W9 = false>
-void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
-  // the LDS opt-in is set once per instantiation by a function-local static initialiser: thread-safe
-  // (the library is entered from the main thread and from the autograd thread)
-#define PG_B3_L(NTV)                                                                                  \
-  {                                                                                                   \
-    static const hipError_t attr_##NTV = hipFuncSetAttribute(                                         \
-        reinterpret_cast<const void*>(conv_b3_kernel<MT, NTV, CG, MS, W9>),                           \
-        hipFuncAttributeMaxDynamicSharedMemorySize, CG == 1 ? 80 * 1024 : 160 * 1024);                \
-    (void)attr_##NTV;                                                                                 \
-    hipLaunchKernelGGL((conv_b3_kernel<MT, NTV, CG, MS, W9>), grid, dim3(B3_THREADS * CG), shmem, st, a); \
-  }
-  switch (nt) {
-    case 1: PG_B3_L(1) break;
-    case 2: PG_B3_L(2) break;
-    case 3: PG_B3_L(3) break;
-    default: PG_B3_L(4) break;
-  }
-#undef PG_B3_L
-}
-
-template <int MT, bool MS = false>
-void b3_pw_launch(const B3Args& a, dim3 grid, size_t shmem, hipStream_t st) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_pw_kernel<MT, MS>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  (void)attr;
-  hipLaunchKernelGGL((conv_b3_pw_kernel<MT, MS>), grid, dim3(64 * PW_WAVES), shmem, st, a);
-}
-
 void tap_extent(int T, const int* dr, const int* dc, int& min_dr, int& hr, int& min_dc, int& hc) {
   int a0 = dr[0], a1 = dr[0], b0 = dc[0], b1 = dc[0];
   for (int t = 1; t < T; ++t) {
@@ -919,6 +215,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.res2_bs = res2_bs > 0 ? res2_bs : (long)Cout * OH * OW;
   a.N = N; a.Cin = Cin; a.IH = IH; a.IW = IW; a.Cout = Cout; a.OH = OH; a.OW = OW; a.T = T;
   a.in_act = in_act; a.dact = dact; a.out_act = out_act;
+  // the instantiations with the GELU paths live in conv_b3_gelu.hip (conv_b3_kernels.h says why)
+  const bool gelu = in_act == PG_ACT_GELU || out_act == PG_ACT_GELU || dact == PG_ACT_GELU;
   { const char* e = getenv("PG_B3_DBG"); a.dbg = e ? atoi(e) : 0; }
   int hr, hc;
   tap_extent(T, tap_dr, tap_dc, a.min_dr, hr, a.min_dc, hc);
@@ -963,13 +261,9 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
       if (gx < 1) gx = 1;
       const dim3 grid((unsigned)gx, (unsigned)chunks_y);
       if (twice) { a.res2 = nullptr; a.res_scale = 2.f; }
-      if (ms_pw) b3_pw_launch<4, true>(a, grid, shmem, st);
-      else switch (pl.MT) {
-        case 1: b3_pw_launch<1>(a, grid, shmem, st); break;
-        case 2: b3_pw_launch<2>(a, grid, shmem, st); break;
-        case 3: b3_pw_launch<3>(a, grid, shmem, st); break;
-        default: b3_pw_launch<4>(a, grid, shmem, st); break;
-      }
+      const B3Launch l = {1, pl.MT, 0, 1, ms_pw ? 1 : 0, 0, grid, shmem};
+      if (gelu) pg_b3_dispatch_gelu(a, l, st);
+      else b3_dispatch<false>(a, l, st);
       PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, 1x1)");
       return 0;
     }
@@ -1005,29 +299,9 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   dim3 grid((unsigned)gx, (unsigned)chunks_y);
   PG_REQUIRE(!ms || pl.MT == 4, PG_ESHAPE,
              "pg_conv2d_mfma_ex(bf16x3): the multi-stream epilogue is instantiated for >= 64 output channels");
-  if (CG == 2) {
-    if (ms) b3_launch<4, 2, true>(a, nt, grid, shmem, st);
-    else b3_launch<4, 2>(a, nt, grid, shmem, st);
-    PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, wide)");
-    return 0;
-  }
-  if (pl.w9) {
-    if (ms) b3_launch<4, 1, true, true>(a, nt, grid, shmem, st);
-    else b3_launch<4, 1, false, true>(a, nt, grid, shmem, st);
-    PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, 9 weight slots)");
-    return 0;
-  }
-  if (ms) {
-    b3_launch<4, 1, true>(a, nt, grid, shmem, st);
-    PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, multi-stream epilogue)");
-    return 0;
-  }
-  switch (pl.MT) {
-    case 1: b3_launch<1>(a, nt, grid, shmem, st); break;
-    case 2: b3_launch<2>(a, nt, grid, shmem, st); break;
-    case 3: b3_launch<3>(a, nt, grid, shmem, st); break;
-    default: b3_launch<4>(a, nt, grid, shmem, st); break;
-  }
+  const B3Launch l = {0, pl.MT, nt, CG, ms ? 1 : 0, pl.w9, grid, shmem};
+  if (gelu) pg_b3_dispatch_gelu(a, l, st);
+  else b3_dispatch<false>(a, l, st);
   PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3)");
   return 0;
 }
