@@ -48,10 +48,6 @@ __device__ __forceinline__ void pg_gelu_parts(float x, float& cdf, float& e) {
   e = __expf(-z * z);
   const float q = 0.5f * p * e;  // Phi(-|x|)
   cdf = x >= 0.f ? 1.f - q : q;
-  // One element at a time: left to itself the scheduler interleaves the 8-16 independent chains of an unrolled
-  // activation loop (6 temporaries each) and the convolution kernels, already at 256 registers, spill 48 of them
-  // (PixelSNAIL 12.3 -> 11.4 k img/s, although it never takes the GELU path).
-  __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ float pg_gelu(float x) {
   float cdf, e;
