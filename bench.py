@@ -614,7 +614,7 @@ def main():
                     "flop_per_launch": c["flop_per_launch"],
                     # per-launch HBM bytes of this kernel averaged over its launches INSIDE the model step
                     # (profiles/r03_snail_traffic.json, batch 512: forward, data-gradient and 1x1 launches)
-                    "traffic": measured_traffic(512, "conv_b3_kernel<4, 4, 1, false>", ("r03_snail_traffic.json",)),
+                    "traffic": measured_traffic(512, "conv_b3_kernel<false, 4, 4, 1, false, false>", ("r03_snail_traffic.json",)),
                     "traffic_profile_batch": 512,
                     "other_kernels": {"conv_wgrad_b3_kernel<4> + wgrad_reduce_kernel": w,
                                       "attn_fwd_k4_kernel": a["fwd"], "attn_dq_k4_kernel": a["dq"],

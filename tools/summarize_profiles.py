@@ -20,7 +20,7 @@ RUNS = {
     "igpt": dict(batch=1024, cal="head_fwd_kernel", read_b=lambda n: n * 784 * 16 * 4, write_b=lambda n: n * 784 * 48 * 4,
                  dominant="attn_bwd_m44_kernel"),
     "snail": dict(batch=512, cal="gated_fwd4_kernel", read_b=lambda n: 3 * n * 64 * 1024 * 4,
-                  write_b=lambda n: n * 64 * 1024 * 4, dominant="conv_b3_kernel<4, 4, 1, false>"),
+                  write_b=lambda n: n * 64 * 1024 * 4, dominant="conv_b3_kernel<false, 4, 4, 1, false, false>"),
 }
 
 
