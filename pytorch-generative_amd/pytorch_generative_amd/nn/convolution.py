@@ -154,9 +154,10 @@ class Conv2d(nn.Conv2d):
         xs = ops.phase_split(x)
         _, _, _, h, w = xs.shape
         out = res
+        wph = ops.phase_weights(self.weight)  # [2 pr + pc] = weight[:, :, (1 - pr)::2, (1 - pc)::2], one copy
         for pr in (0, 1):
             for pc in (0, 1):
-                wsel = self.weight[:, :, (1 - pr)::2, (1 - pc)::2].contiguous()
+                wsel = wph[2 * pr + pc]
                 spec = _PHASE_SPECS[(pr, pc)]
                 last = (pr, pc) == (1, 1)
                 out = ops.conv2d_taps(xs[2 * pr + pc], wsel, self.bias if last else None, spec,
@@ -184,16 +185,24 @@ class ConvTranspose2d(nn.ConvTranspose2d):
             raise ValueError("pytorch_generative_amd.nn.ConvTranspose2d supports kernel 4, stride 2, padding 1")
 
     def forward(self, x, *, in_act=None):
-        wt = self.weight.transpose(0, 1)  # (Cout, Cin, 4, 4)
+        # output phase 0 uses kernel rows (3, 1) at offsets (-1, 0), phase 1 rows (2, 0) at (0, +1):
+        # [2 pr + pc] = weight.transpose(0, 1)[:, :, (1 - pr)::2, (1 - pc)::2].flip(2, 3), one copy for all four
+        wph = ops.phase_weights(self.weight, transposed=True)
         phases = []
+        xs = [x] * 4
         for pr in (0, 1):
-            # output phase 0 uses kernel rows (3, 1) at offsets (-1, 0), phase 1 rows (2, 0) at
-            # (0, +1): strided slices + flip (no index tensors: hipGraph-capturable)
             for pc in (0, 1):
-                wsel = wt[:, :, (1 - pr)::2, (1 - pc)::2].flip(2, 3).contiguous()
+                k = 2 * pr + pc
                 spec = _PHASE_SPECS[(1 - pr, 1 - pc)]
-                phases.append(ops.conv2d_taps(x, wsel, self.bias, spec, out_hw=x.shape[2:],
-                                              in_act=_ACTS[in_act]))
+                if k == 0 and x.requires_grad:
+                    # x has four readers: the other three read pass-through aliases, whose gradients the first
+                    # convolution's data-gradient kernel adds in its epilogue (ops.conv2d_taps, n_skip)
+                    y, *al = ops.conv2d_taps(x, wph[k], self.bias, spec, out_hw=x.shape[2:], in_act=_ACTS[in_act],
+                                             n_skip=3)
+                    xs = [x] + list(al)
+                else:
+                    y = ops.conv2d_taps(xs[k], wph[k], self.bias, spec, out_hw=x.shape[2:], in_act=_ACTS[in_act])
+                phases.append(y)
         return ops.phase_merge(torch.stack(phases))
 
 

@@ -1469,6 +1469,48 @@ class _PhaseMerge(torch.autograd.Function):
         return dxs
 
 
+class _PhaseWeights(torch.autograd.Function):
+    """The four 2x2 phase kernels of a 4x4 / stride-2 weight with ONE copy kernel each way.
+
+    transposed=False (Conv2d, weight (Co, Ci, 4, 4)): out[2 pr + pc] = w[:, :, (1 - pr)::2, (1 - pc)::2].
+    transposed=True (ConvTranspose2d, weight (Ci, Co, 4, 4)): out[2 pr + pc] =
+    w.transpose(0, 1)[:, :, (1 - pr)::2, (1 - pc)::2].flip(2, 3).
+    Written as slices these are four strided copies forward and, per slice, a zero fill, a strided copy and an add
+    into the weight's gradient backward (~300 tiny ATen launches per beta-VAE step)."""
+
+    @staticmethod
+    def forward(ctx, w, transposed):
+        if w.dim() != 4 or tuple(w.shape[2:]) != (4, 4):
+            raise ValueError("phase_weights: expected a (*, *, 4, 4) weight")
+        ctx.transposed, ctx.shape = bool(transposed), tuple(w.shape)
+        a, b = w.shape[:2]
+        v = w.contiguous().view(a, b, 2, 2, 2, 2)  # (a, b, i, ur, j, vr): tap u = 2 i + ur, v = 2 j + vr
+        if transposed:
+            p = v.permute(3, 5, 1, 0, 2, 4).flip(4, 5)  # (ur, vr, Co, Ci, 1 - i, 1 - j)
+        else:
+            p = v.permute(3, 5, 0, 1, 2, 4)             # (ur, vr, Co, Ci, i, j)
+        p = p.contiguous()
+        # phase (pr, pc) reads taps with ur = 1 - pr, vr = 1 - pc
+        return tuple(p[1 - pr, 1 - pc] for pr in (0, 1) for pc in (0, 1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        a, b = ctx.shape[:2]
+        like = next(g for g in grads if g is not None)
+        gs = [g if g is not None else torch.zeros_like(like) for g in grads]
+        # back into (ur, vr, ...) order: entry [ur][vr] is phase (1 - ur, 1 - vr) = index 2 (1 - ur) + (1 - vr)
+        dp = torch.stack([gs[3], gs[2], gs[1], gs[0]]).view(2, 2, *like.shape)
+        if ctx.transposed:
+            dv = dp.flip(4, 5).permute(3, 2, 4, 0, 5, 1)  # (Ci, Co, i, ur, j, vr)
+        else:
+            dv = dp.permute(2, 3, 4, 0, 5, 1)             # (Co, Ci, i, ur, j, vr)
+        return dv.reshape(a, b, 4, 4), None
+
+
+def phase_weights(w, transposed=False):
+    return _PhaseWeights.apply(w, transposed)
+
+
 def phase_split(x):
     return _PhaseSplit.apply(x)
 

@@ -1,0 +1,34 @@
+"""ops.phase_weights (the four stride-2 phase kernels of a 4x4 weight, one copy each way) against the strided
+slices it replaces (nn/convolution.py: Conv2d._forward_down2, ConvTranspose2d.forward): values and gradients."""
+import pytest
+import torch
+
+from pytorch_generative_amd import ops
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_phase_weights_equal_the_slices(transposed):
+    torch.manual_seed(0)
+    w = torch.randn(5, 3, 4, 4, requires_grad=True)
+    w2 = w.detach().clone().requires_grad_(True)
+    outs = ops.phase_weights(w, transposed)
+    src = w2.transpose(0, 1) if transposed else w2
+    refs = []
+    for pr in (0, 1):
+        for pc in (0, 1):
+            r = src[:, :, (1 - pr)::2, (1 - pc)::2]
+            refs.append((r.flip(2, 3) if transposed else r).contiguous())
+    coef = [torch.randn_like(r) for r in refs]
+    sum((o * c).sum() for o, c in zip(outs, coef)).backward()
+    sum((o * c).sum() for o, c in zip(refs, coef)).backward()
+    assert all(torch.equal(o, r) for o, r in zip(outs, refs))
+    assert torch.equal(w.grad, w2.grad)
+
+
+def test_phase_weights_with_an_unused_phase():
+    w = torch.randn(2, 2, 4, 4, requires_grad=True)
+    outs = ops.phase_weights(w)
+    (outs[1].sum() * 2.0).backward()  # three of the four gradients are None
+    ref = torch.zeros(2, 2, 4, 4)
+    ref[:, :, 1::2, 0::2] = 2.0  # phase (0, 1): rows (1 - 0)::2, cols (1 - 1)::2
+    assert torch.equal(w.grad, ref)
