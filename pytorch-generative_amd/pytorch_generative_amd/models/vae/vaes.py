@@ -63,7 +63,10 @@ class ResidualBlock(nn.Module):
         )
 
     def forward(self, x):
-        return self._net[3](self._net[1](x, in_act="relu"), in_act="relu", res=x)
+        # x has two readers (the 3x3 convolution and the residual add): the add reads a pass-through alias whose
+        # gradient the 3x3 convolution's data-gradient kernel adds in its epilogue (ops.conv2d_taps, n_skip)
+        h, res = self._net[1](x, in_act="relu", n_skip=1)
+        return self._net[3](h, in_act="relu", res=res)
 
 
 class ResidualStack(nn.Module):
