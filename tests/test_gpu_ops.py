@@ -131,6 +131,75 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
         _util.assert_close(bg.grad, bo.grad, TOL, "conv bgrad")
 
 
+def _random_conv_case(seed):
+    import random
+
+    r = random.Random(seed)
+    kh, kw, ph, pw, crop = r.choice([(1, 1, 0, 0, None), (1, 1, 0, 0, None), (3, 3, 1, 1, None), (2, 2, 1, 1, "hw"),
+                                     (1, 3, 0, 1, None), (2, 1, 2, 0, "hw"), (2, 3, 1, 1, "hw")])
+    cin = r.choice([16, 24, 32, 40, 48, 64, 96, 128])
+    cout = r.choice([16, 24, 32, 36, 48, 64, 96, 128])
+    h = r.choice([6, 10, 12, 16, 18, 20, 28, 32, 36])
+    w = r.choice([8, 12, 16, 20, 24, 28, 32, 36, 64])
+    n = r.choice([1, 2, 3, 5, 9])
+    in_act = r.choice([None, "relu", "elu", "gelu"])
+    active = "B" if (kh, kw) == (3, 3) and r.random() < 0.3 else None
+    return (n, cin, h, w, cout, kh, kw, ph, pw, crop, active, in_act, r.random() < 0.5, r.random() < 0.8)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_conv_random_shapes(dev, seed):
+    """Seeded random shapes through whatever kernel the dispatch picks (1x1 barrier-free, staged, 9-slot, fp32-MFMA,
+    VALU; x-copy / shifted-dy / fp32 weight gradients): forward, data gradient, weight and bias gradient."""
+    test_conv_fwd_dgrad_wgrad(dev, _random_conv_case(1000 + seed))
+
+
+SKIP_CASES = [
+    # (N, C, H, W, Cmid, k, in_act): x -> conv1 (k x k, C -> Cmid, n_skip = 2) -> conv2 (1x1, Cmid -> C, res, res2)
+    (3, 64, 28, 28, 32, 1, "relu"),   # PixelCNN's block: barrier-free 1x1 kernel, multi-stream epilogues both ways
+    (3, 64, 16, 16, 64, 2, "elu"),    # staged kernel with the multi-stream epilogue (2x2 taps)
+    (2, 128, 16, 20, 64, 1, None),    # 128 channels: data gradient on the staged kernel
+    (3, 64, 32, 32, 32, 3, "gelu"),   # 3x3 data gradient with 64 output channels: 9-weight-slot plan + GELU derivative
+    (3, 32, 16, 16, 32, 1, "relu"),   # < 64 channels: the add fallback
+    (4, 64, 8, 8, 32, 3, "relu"),     # < 256 pixels per image: fp32-MFMA kernels, add fallback
+]
+
+
+@pytest.mark.parametrize("case", SKIP_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_skip_aliases_and_two_residuals(dev, case):
+    """y, x1, x2 = conv1(x, n_skip=2); z = conv2(y, res=x1, res2=x2) against conv2(conv1(act(x))) + 2 x: the
+    pass-through aliases (skip gradients added in conv1's data-gradient epilogue) and the two-residual epilogue."""
+    from pytorch_generative_amd import nn as pg_nn
+
+    n, c, h, w, cmid, k, in_act = case
+    torch.manual_seed(0)
+    pad = 1 if k > 1 else 0
+    conv1 = pg_nn.Conv2d(c, cmid, k, padding=pad)
+    conv2 = pg_nn.Conv2d(cmid, c, 1)
+    x = _rand(n, c, h, w, seed=1)
+    g = _rand(n, c, h, w, seed=2)
+    act_fn = {None: lambda t: t, "relu": F.relu, "elu": F.elu, "gelu": F.gelu}[in_act]
+    # oracle
+    xo = x.clone().requires_grad_(True)
+    w1, b1 = conv1.weight.detach().clone().requires_grad_(True), conv1.bias.detach().clone().requires_grad_(True)
+    w2, b2 = conv2.weight.detach().clone().requires_grad_(True), conv2.bias.detach().clone().requires_grad_(True)
+    yo = F.conv2d(act_fn(xo), w1, b1, padding=pad)[:, :, :h, :w]
+    zo = F.conv2d(yo, w2, b2) + xo + xo
+    zo.backward(g)
+    # HIP path
+    conv1, conv2 = conv1.to(dev), conv2.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    y, x1, x2 = conv1(xg, crop=(h, w), in_act=in_act, n_skip=2)
+    z = conv2(y, res=x1, res2=x2)
+    _util.assert_close(z, zo, TOL, "fwd")
+    z.backward(g.to(dev))
+    _util.assert_close(xg.grad, xo.grad, TOL, "dx")
+    _util.assert_close(conv1.weight.grad, w1.grad, TOL, "dw1")
+    _util.assert_close(conv1.bias.grad, b1.grad, TOL, "db1")
+    _util.assert_close(conv2.weight.grad, w2.grad, TOL, "dw2")
+    _util.assert_close(conv2.bias.grad, b2.grad, TOL, "db2")
+
+
 def test_conv_weight_grad_sink_accumulates(dev):
     """With a `_pg_grad` sink the wgrad kernel accumulates into it and autograd sees None."""
     from pytorch_generative_amd import nn as pg_nn
