@@ -50,17 +50,23 @@ class BottleneckBlock(nn.Module):
             pg_nn.Conv2d(bottleneck_channels, out_channels, kernel_size=1),
         )
 
-    def forward(self, x):
+    def forward(self, x, n_alias=0):
+        """n_alias > 0 (extension) returns (out, x_1, .., x_n): pass-through aliases of x for the caller's other
+        readers of x (ops.conv2d_taps, n_skip): their gradients are added in the first convolution's data-gradient
+        epilogue instead of by autograd's gradient-sum kernels."""
         res = None
-        if self._is_residual:
-            # x has two readers (the first convolution and the residual add): the add reads a pass-through alias,
-            # whose gradient the first convolution's data-gradient kernel adds in its epilogue (ops.conv2d_taps)
-            h, res = self._net[1](x, in_act="gelu", n_skip=1)
+        k = n_alias + (1 if self._is_residual else 0)
+        if k:
+            # the block's own residual add reads the first alias
+            h, *al = self._net[1](x, in_act="gelu", n_skip=k)
+            if self._is_residual:
+                res, al = al[0], al[1:]
         else:
-            h = self._net[1](x, in_act="gelu")
+            h, al = self._net[1](x, in_act="gelu"), []
         h = self._net[3](h, in_act="gelu")
         h = self._net[5](h, in_act="gelu")
-        return self._net[7](h, in_act="gelu", res=res)
+        out = self._net[7](h, in_act="gelu", res=res)
+        return (out, *al) if n_alias else out
 
 
 class TopDownBlock(nn.Module):
@@ -79,14 +85,22 @@ class TopDownBlock(nn.Module):
     def forward(self, x, mixin=None):
         c = self._latent_channels
         n, _, h, w = x.shape
-        prior = self._prior(x)  # [p_mean | p_log_std | p_h]
+        # x has three readers (the prior's first convolution, the concatenation, the residual add): the last two
+        # read pass-through aliases handed out by the first
+        prior, x_cat, x = self._prior(x, n_alias=2)  # prior = [p_mean | p_log_std | p_h]
         eps = vaes.draw_noise((n, c, h, w), x.device)
         if mixin is None:  # generation: sample from the prior
             z, kl_div = ops.gaussian_head_prior(prior, eps, c), None
+            p_h = prior[:, 2 * c:]
         else:              # training: sample from the approximate posterior
-            post = self._posterior(torch.cat((x, mixin), dim=1))
-            z, kl_div = ops.gaussian_head_pair(post, prior, eps, c)
-        x_ph = ops.add(x, prior[:, 2 * c:].contiguous())
+            post = self._posterior(torch.cat((x_cat, mixin), dim=1))
+            # p_h = prior[:, 2c:] comes out of the head function: its gradient goes back into the prior's
+            # gradient with one copy (no slice backward + full-size add)
+            z, kl_div, p_h = ops.gaussian_head_pair(post, prior, eps, c, split_rest=True)
+        if self._latents.two_residuals_ok(z):
+            # x + p_h + latents(z): both adds in the 1x1 convolution's epilogue, p_h read in place (batch-strided)
+            return self._out(self._latents(z, res=x, res2=p_h)), kl_div
+        x_ph = ops.add(x, p_h.contiguous())
         return self._out(self._latents(z, res=x_ph)), kl_div
 
 

@@ -197,7 +197,8 @@ class _ConvTaps(torch.autograd.Function):
         out = torch.empty((n, cout, oh, ow), device=x.device, dtype=torch.float32)
         mfma = _use_mfma(lib, cin, cout, spec, (oh, ow), iw)
         if res2 is not None:
-            res2 = _chk(res2, "conv2d.res2")
+            # a channel slice of a wider tensor is read with its batch stride (bf16x3 epilogue), no copy
+            res2 = res2 if _dense_per_image(res2) else _chk(res2, "conv2d.res2")
             if res is None or tuple(res2.shape) != (n, cout, oh, ow):
                 raise ValueError("conv2d: res2 needs res and the output's shape")
             if not (mfma == CONV_FMT_B3 and cout >= 64):
@@ -217,7 +218,7 @@ class _ConvTaps(torch.autograd.Function):
                 lib.pg_conv2d_mfma_ex(
                     x.data_ptr(), wfrag.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih,
                     iw, cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, 0, ACT_NONE,
-                    out_act, mfma, _p(res2), 0, 0, _stream(),
+                    out_act, mfma, _p(res2), 0, res2.stride(0) if res2 is not None else 0, _stream(),
                 ),
                 "pg_conv2d_mfma",
             )
@@ -1310,7 +1311,10 @@ class _GaussHead(torch.autograd.Function):
     """mode 0: (q, eps) -> z, kl vs N(0,1); mode 1: (q, p, eps) -> z, kl(q||p); mode 2: (p, eps) -> z."""
 
     @staticmethod
-    def forward(ctx, q, p, eps, latent, mode):
+    def forward(ctx, q, p, eps, latent, mode, split_rest=False):
+        """split_rest (mode 1, p wider than 2 * latent channels): third output = p[:, 2 * latent:] (a view); its
+        gradient is written into dp's channel range by ONE copy instead of autograd's slice backward (zero fill +
+        strided copy) and a full-size add with this function's own dp."""
         lib = _lib.load()
         ref = q if q is not None else p
         n, _, h, w = ref.shape
@@ -1337,10 +1341,15 @@ class _GaussHead(torch.autograd.Function):
         ctx.save_for_backward(*[t for t in (q, p, eps) if t is not None])
         ctx.cfg = (q is not None, p is not None, latent, mode)
         ctx.mark_non_differentiable(kl) if mode == 2 else None
+        ctx.split_rest = bool(split_rest)
+        if split_rest:
+            if p is None or p.shape[1] <= 2 * latent:
+                raise ValueError("gauss head: split_rest needs p with more than 2 * latent channels")
+            return z, kl, p[:, 2 * latent:]
         return z, kl
 
     @staticmethod
-    def backward(ctx, dz, dkl):
+    def backward(ctx, dz, dkl, d_rest=None):
         lib = _lib.load()
         has_q, has_p, latent, mode = ctx.cfg
         saved = list(ctx.saved_tensors)
@@ -1355,15 +1364,22 @@ class _GaussHead(torch.autograd.Function):
         dq = dp = None
         if q is not None:
             dq = torch.empty_like(q) if q.shape[1] == 2 * latent else torch.zeros_like(q)
+        rest_direct = ctx.split_rest and d_rest is not None
         if p is not None:
-            dp = torch.empty_like(p) if p.shape[1] == 2 * latent else torch.zeros_like(p)
+            dp = torch.empty_like(p) if (p.shape[1] == 2 * latent or rest_direct) else torch.zeros_like(p)
         _lib.check(
             lib.pg_gauss_head_bwd(_p(q), _p(p), eps.data_ptr(), _p(dz), _p(dkl), _p(dq), _p(dp), n,
                                   latent, L, 0 if q is None else q.shape[1] * L,
                                   0 if p is None else p.shape[1] * L, mode, _stream()),
             "pg_gauss_head_bwd",
         )
-        return dq, dp, None, None, None
+        if rest_direct:  # dp[:, 2 * latent:] = d_rest: rows of (C - 2 latent) * L floats, batch-strided on either side
+            d_rest = d_rest if _dense_per_image(d_rest) else _chk(d_rest, "gauss.d_rest")
+            rest = p.shape[1] - 2 * latent
+            dst = dp[:, 2 * latent:]
+            _lib.check(lib.pg_copy_rows(d_rest.data_ptr(), dst.data_ptr(), n, rest * L, d_rest.stride(0), dst.stride(0),
+                                        0, _stream()), "pg_copy_rows")
+        return dq, dp, None, None, None, None
 
 
 def gaussian_head_unit(h, eps, latent_channels):
@@ -1371,9 +1387,10 @@ def gaussian_head_unit(h, eps, latent_channels):
     return _GaussHead.apply(h, None, eps, latent_channels, 0)
 
 
-def gaussian_head_pair(q, p, eps, latent_channels):
-    """Returns (z ~ q, KL(q || p) per sample); q, p hold [mean | log_std | ...] along channels."""
-    return _GaussHead.apply(q, p, eps, latent_channels, 1)
+def gaussian_head_pair(q, p, eps, latent_channels, split_rest=False):
+    """Returns (z ~ q, KL(q || p) per sample); q, p hold [mean | log_std | ...] along channels.
+    split_rest=True also returns p[:, 2 * latent_channels:] (see _GaussHead.forward)."""
+    return _GaussHead.apply(q, p, eps, latent_channels, 1, split_rest)
 
 
 def gaussian_head_prior(p, eps, latent_channels):
