@@ -50,13 +50,18 @@ class BottleneckBlock(nn.Module):
             pg_nn.Conv2d(bottleneck_channels, out_channels, kernel_size=1),
         )
 
-    def forward(self, x, n_alias=0):
+    def forward(self, x, n_alias=0, x2=None):
         """n_alias > 0 (extension) returns (out, x_1, .., x_n): pass-through aliases of x for the caller's other
         readers of x (ops.conv2d_taps, n_skip): their gradients are added in the first convolution's data-gradient
-        epilogue instead of by autograd's gradient-sum kernels."""
+        epilogue instead of by autograd's gradient-sum kernels. x2 (extension): the block reads cat((x, x2), dim=1)
+        without that tensor being written (Conv2d.forward_cat2)."""
         res = None
         k = n_alias + (1 if self._is_residual else 0)
-        if k:
+        if x2 is not None:
+            if k:
+                raise ValueError("BottleneckBlock: x2 is for the non-residual block without aliases")
+            h, al = self._net[1].forward_cat2(x, x2, in_act="gelu"), []
+        elif k:
             # the block's own residual add reads the first alias
             h, *al = self._net[1](x, in_act="gelu", n_skip=k)
             if self._is_residual:
@@ -93,7 +98,7 @@ class TopDownBlock(nn.Module):
             z, kl_div = ops.gaussian_head_prior(prior, eps, c), None
             p_h = prior[:, 2 * c:]
         else:              # training: sample from the approximate posterior
-            post = self._posterior(torch.cat((x_cat, mixin), dim=1))
+            post = self._posterior(x_cat, x2=mixin)  # the block of cat((x, mixin)), concatenation not materialised
             # p_h = prior[:, 2c:] comes out of the head function: its gradient goes back into the prior's
             # gradient with one copy (no slice backward + full-size add)
             z, kl_div, p_h = ops.gaussian_head_pair(post, prior, eps, c, split_rest=True)

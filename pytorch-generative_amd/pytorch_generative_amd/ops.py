@@ -1524,6 +1524,28 @@ class _PhaseWeights(torch.autograd.Function):
         return dv.reshape(a, b, 4, 4), None
 
 
+class _SplitInChannels(torch.autograd.Function):
+    """(w[:, :c1], w[:, c1:]) as two contiguous tensors; backward = one concatenation (as slices: two zero fills, two
+    strided copies and an add into the weight's gradient)."""
+
+    @staticmethod
+    def forward(ctx, w, c1):
+        if not 0 < c1 < w.shape[1]:
+            raise ValueError("split_in_channels: split point outside the weight's input channels")
+        return w[:, :c1].contiguous(), w[:, c1:].contiguous()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        ga = torch.zeros_like(gb[:, :1]).expand(-1, 0, -1, -1) if ga is None else ga
+        return torch.cat((ga, gb), dim=1), None
+
+
+def split_in_channels(w, c1):
+    return _SplitInChannels.apply(w, int(c1))
+
+
 def phase_weights(w, transposed=False):
     return _PhaseWeights.apply(w, transposed)
 

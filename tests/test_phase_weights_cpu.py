@@ -32,3 +32,18 @@ def test_phase_weights_with_an_unused_phase():
     ref = torch.zeros(2, 2, 4, 4)
     ref[:, :, 1::2, 0::2] = 2.0  # phase (0, 1): rows (1 - 0)::2, cols (1 - 1)::2
     assert torch.equal(w.grad, ref)
+
+
+def test_split_in_channels_equals_the_slices():
+    torch.manual_seed(1)
+    w = torch.randn(4, 6, 1, 1, requires_grad=True)
+    w2 = w.detach().clone().requires_grad_(True)
+    a, b = ops.split_in_channels(w, 2)
+    ca, cb = torch.randn_like(a), torch.randn_like(b)
+    ((a * ca).sum() + (b * cb).sum()).backward()
+    ((w2[:, :2] * ca).sum() + (w2[:, 2:] * cb).sum()).backward()
+    assert torch.equal(a, w2[:, :2]) and torch.equal(b, w2[:, 2:]) and torch.equal(w.grad, w2.grad)
+    w3 = torch.randn(4, 6, 1, 1, requires_grad=True)
+    _, b3 = ops.split_in_channels(w3, 2)
+    (b3 * cb).sum().backward()  # the first half never used
+    assert torch.equal(w3.grad[:, 2:], cb) and float(w3.grad[:, :2].abs().max()) == 0.0
