@@ -1535,10 +1535,7 @@ class _SplitInChannels(torch.autograd.Function):
         return w[:, :c1].contiguous(), w[:, c1:].contiguous()
 
     @staticmethod
-    def backward(ctx, ga, gb):
-        if ga is None and gb is None:
-            return None, None
-        ga = torch.zeros_like(gb[:, :1]).expand(-1, 0, -1, -1) if ga is None else ga
+    def backward(ctx, ga, gb):  # autograd materialises an unused half's gradient as zeros
         return torch.cat((ga, gb), dim=1), None
 
 
