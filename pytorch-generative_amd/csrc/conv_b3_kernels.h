@@ -600,8 +600,9 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
     const int t0 = (it - n_img * tpi) * 32;
     const bool sok = t0 + px < L;
     const size_t so = ((size_t)n_img * a.Cout + co0) * cstride + t0;   // uniform
-    const unsigned lo = sok ? (unsigned)(8 * half * L + px) : 0u;        // lane part
     const int cvalid = a.Cout - co0 - 8 * half;
+    // lane part; lanes whose 8-channel half lies entirely beyond Cout (Cout % 64 in 1..8) address the chunk's first channel
+    const unsigned lo = (sok && cvalid > 0) ? (unsigned)(8 * half * L + px) : 0u;
     float* outp = a.out + so;
     // up to three operand streams: derivative source, residual, second residual (a residual may be a
     // batch-strided channel slice: res_bs); v = out_act(acc + bias) * act'(o0) + o1 + o2

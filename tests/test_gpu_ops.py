@@ -71,6 +71,7 @@ CONV_CASES = [
     (3, 48, 14, 22, 96, 1, 1, 0, 0, None, None, "gelu", True, True),    # 16-channel chunks, partial co chunk, L = 308
     (600, 64, 28, 28, 32, 1, 1, 0, 0, None, None, "relu", False, True),  # PixelCNN 64 -> 32 at bench batch, ragged tiles
     (2, 32, 16, 16, 16, 1, 1, 0, 0, None, None, None, False, False),    # one output tile, no bias
+    (2, 32, 16, 16, 72, 1, 1, 0, 0, None, None, "relu", True, True),      # second co chunk holds 8 channels: one lane half idle
     # the "shifted dy" bf16x3 weight-gradient kernel (32 output channels per workgroup, full tap grids, W % 4 == 0)
     (6, 32, 64, 64, 32, 3, 3, 1, 1, None, None, "gelu", False, True),   # VD-VAE 64x64: one row per tile
     (4, 64, 64, 64, 64, 3, 3, 1, 1, None, None, "relu", False, True),   # 64 -> 64 on 64-wide rows: x copies overflow LDS
