@@ -161,8 +161,40 @@ def load():
     got = lib.pg_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"libpg_hip.so ABI version {got} != expected {ABI_VERSION}")
+    if os.environ.get("PG_TRACE"):
+        lib = _Traced(lib, os.environ["PG_TRACE"])
     _lib = lib
     return lib
+
+
+class _Traced:
+    """PG_TRACE=<path prefix>: one line per C-ABI call (name + scalar arguments, pointers in hex), flushed BEFORE the
+    call — with AMD_SERIALIZE_KERNEL=3 the last line of <prefix>.<pid> names the launch a GPU fault came from."""
+
+    def __init__(self, lib, prefix):
+        self._lib = lib
+        self._out = open(f"{prefix}.{os.getpid()}", "a", buffering=1)
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("pg_") or name in ("pg_last_error", "pg_abi_version"):
+            return fn
+        out = self._out
+
+        def call(*args):
+            shown = []
+            for a in args:
+                if isinstance(a, int):
+                    shown.append(hex(a) if a > 1 << 32 else str(a))
+                elif isinstance(a, ctypes.Array):
+                    shown.append(str(list(a)))
+                else:
+                    shown.append(repr(a))
+            out.write(f"{name}({', '.join(shown)})\n")
+            return fn(*args)
+
+        setattr(self, name, call)
+        return call
 
 
 def check(rc, what):

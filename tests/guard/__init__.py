@@ -1,0 +1,58 @@
+"""Guard-page allocator harness for the GPU tests (TEST INFRASTRUCTURE — the package never imports this).
+
+`PG_GUARD=1 python -m pytest tests -m gpu` routes every torch device allocation through
+tests/guard/libpg_guard.so (pg_guard_alloc.cpp): each tensor sits flush against an unmapped page, the slack on its
+other side holds canary bytes. An out-of-bounds access of any kernel then either faults at the launch that did it
+(run with AMD_SERIALIZE_KERNEL=3 to get the guilty Python stack) or is reported by the per-test canary check that
+tests/conftest.py installs.
+
+    PG_GUARD_SIDE=end|start   which edge of the tensor touches the guard page (overruns | underruns)
+    PG_GUARD_ALIGN=512|16     512 = what torch's caching allocator guarantees in production, 16 = strict
+    PG_GUARD_POISON=0         do not fill fresh tensors with NaN bytes
+"""
+
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libpg_guard.so")
+SRC = os.path.join(HERE, "pg_guard_alloc.cpp")
+_lib = None
+
+
+def build(force=False):
+    if not force and os.path.exists(SO) and os.path.getmtime(SO) > os.path.getmtime(SRC):
+        return SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "-O2", "-fPIC", "-shared", "-std=c++17", SRC, "-o", SO], check=True)
+    return SO
+
+
+def enabled():
+    return os.environ.get("PG_GUARD") == "1"
+
+
+def install():
+    """Makes the guard allocator torch's device allocator. Must run before the first device allocation."""
+    global _lib
+    import torch
+
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise RuntimeError(f"{SO} missing: run __graft_entry__.build() (or tests.guard.build()) first")
+    alloc = torch.cuda.memory.CUDAPluggableAllocator(SO, "pg_guard_malloc", "pg_guard_free")
+    torch.cuda.memory.change_current_allocator(alloc)
+    _lib = ctypes.CDLL(SO)
+    _lib.pg_guard_report.restype = ctypes.c_char_p
+    _lib.pg_guard_live.restype = ctypes.c_long
+    return _lib
+
+
+def check_all():
+    """Verifies the canaries of every live tensor; returns (violations so far, report text)."""
+    if _lib is None:
+        return 0, ""
+    n = _lib.pg_guard_check_all()
+    return n, _lib.pg_guard_report().decode()

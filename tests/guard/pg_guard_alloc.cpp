@@ -1,0 +1,217 @@
+// Guard-page device allocator for the GPU parity tests (TEST INFRASTRUCTURE, never loaded by the package).
+//
+// Plugged into torch with torch.cuda.memory.CUDAPluggableAllocator (tests/guard/__init__.py, PG_GUARD=1): every
+// tensor of a test run then lives in its OWN virtual-memory mapping,
+//
+//     [ unmapped guard | mapped pages ............................ | unmapped guard ]
+//                        ^ canary bytes      ^ the tensor (flush against the far edge)
+//
+// so that an out-of-bounds access of a kernel is no longer absorbed by the caching allocator's 2-20 MB segments:
+//   * a read or write past the flush edge hits an unmapped page -> "Memory access fault by GPU" at the launch that
+//     did it (run with AMD_SERIALIZE_KERNEL=3 so the Python stack printed at the abort is the guilty call);
+//   * a write on the slack side lands in the canary bytes, which are verified when the tensor is freed and by
+//     pg_guard_check_all(); violations are counted and described (pg_guard_violations / pg_guard_report).
+// PG_GUARD_SIDE=end (default) puts the tensor's END on the guard (overruns), =start its START (underruns).
+// PG_GUARD_ALIGN (default 512) is the rounding of sizes / addresses: 512 is what torch's caching allocator
+// guarantees in production; 16 is the strict setting (every byte past numel() is a fault).
+//
+// hipGraph capture: nothing may be mapped, synchronised or unmapped while a stream captures, so allocations made
+// during a capture come from a plain arena (no guards) that is never recycled, and frees are deferred for ever —
+// the eager warm-up iterations in front of every capture run the same kernels on guarded tensors.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct Block {
+  void* va;          // reserved range (guard + mapped + guard)
+  size_t va_bytes;
+  void* mapped;      // first mapped byte
+  size_t mapped_bytes;
+  hipMemGenericAllocationHandle_t handle;
+  size_t user_bytes;   // rounded size handed to torch
+  size_t asked_bytes;  // size torch asked for
+  unsigned long serial;
+};
+
+std::mutex g_mu;
+std::unordered_map<void*, Block> g_live;
+size_t g_gran = 0;
+size_t g_align = 512;
+bool g_end_side = true;
+bool g_poison = true;
+int g_violations = 0;
+unsigned long g_serial = 0;
+std::string g_report;
+char* g_arena = nullptr;
+size_t g_arena_bytes = 0, g_arena_used = 0;
+const size_t kCanaryCheck = 64 << 10;  // canary bytes verified next to the tensor (the rest of the slack is filled too)
+const unsigned char kCanary = 0xCB;
+
+void die(const char* what, hipError_t e) {
+  fprintf(stderr, "[pg_guard] %s failed: %s\n", what, hipGetErrorString(e));
+  abort();
+}
+#define GCHECK(call)                        \
+  do {                                      \
+    hipError_t e_ = (call);                 \
+    if (e_ != hipSuccess) die(#call, e_);   \
+  } while (0)
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void init_once(int device) {
+  if (g_gran) return;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  GCHECK(hipMemGetAllocationGranularity(&g_gran, &prop, hipMemAllocationGranularityMinimum));
+  if (const char* a = getenv("PG_GUARD_ALIGN")) g_align = (size_t)atol(a);
+  if (g_align < 16) g_align = 16;
+  if (const char* s = getenv("PG_GUARD_SIDE")) g_end_side = strcmp(s, "start") != 0;
+  if (const char* s = getenv("PG_GUARD_POISON")) g_poison = atoi(s) != 0;
+  size_t arena_mb = 4096;
+  if (const char* s = getenv("PG_GUARD_ARENA_MB")) arena_mb = (size_t)atol(s);
+  g_arena_bytes = arena_mb << 20;
+  GCHECK(hipMalloc((void**)&g_arena, g_arena_bytes));
+  fprintf(stderr, "[pg_guard] active: granularity %zu B, align %zu, tensors flush against the %s guard, capture arena %zu MB\n",
+          g_gran, g_align, g_end_side ? "END" : "START", arena_mb);
+}
+
+bool capturing(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return st != hipStreamCaptureStatusNone;
+}
+
+// Verifies the canary bytes of one block (device must be idle). Returns the number of damaged bytes.
+size_t check_block(const Block& b, void* user) {
+  size_t slack = b.mapped_bytes - b.user_bytes;
+  size_t n = slack < kCanaryCheck ? slack : kCanaryCheck;
+  if (!n) return 0;
+  // canary region adjacent to the tensor
+  char* from = g_end_side ? (char*)user - n : (char*)user + b.user_bytes;
+  std::vector<unsigned char> host(n);
+  GCHECK(hipMemcpy(host.data(), from, n, hipMemcpyDeviceToHost));
+  size_t bad = 0, first = n, last = 0;
+  for (size_t i = 0; i < n; i++)
+    if (host[i] != kCanary) {
+      bad++;
+      if (i < first) first = i;
+      last = i;
+    }
+  if (bad) {
+    char line[256];
+    long off0 = g_end_side ? (long)first - (long)n : (long)(b.user_bytes + first);
+    long off1 = g_end_side ? (long)last - (long)n : (long)(b.user_bytes + last);
+    snprintf(line, sizeof line,
+             "allocation #%lu (%zu bytes asked, %zu given): %zu canary bytes overwritten, offsets %ld..%ld relative to the tensor start\n",
+             b.serial, b.asked_bytes, b.user_bytes, bad, off0, off1);
+    g_report += line;
+    fprintf(stderr, "[pg_guard] VIOLATION %s", line);
+    g_violations++;
+  }
+  return bad;
+}
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) void* pg_guard_malloc(ssize_t size, int device, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  GCHECK(hipSetDevice(device));
+  init_once(device);
+  if (size <= 0) size = 1;
+  if (capturing(stream)) {
+    size_t need = round_up((size_t)size, 512);
+    if (g_arena_used + need > g_arena_bytes) {
+      fprintf(stderr, "[pg_guard] capture arena exhausted (PG_GUARD_ARENA_MB)\n");
+      abort();
+    }
+    void* p = g_arena + g_arena_used;
+    g_arena_used += need;
+    return p;
+  }
+  Block b = {};
+  b.asked_bytes = (size_t)size;
+  b.user_bytes = round_up((size_t)size, g_align);
+  b.mapped_bytes = round_up(b.user_bytes, g_gran);
+  b.va_bytes = b.mapped_bytes + 2 * g_gran;
+  b.serial = ++g_serial;
+  GCHECK(hipMemAddressReserve(&b.va, b.va_bytes, g_gran, nullptr, 0));
+  b.mapped = (char*)b.va + g_gran;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  GCHECK(hipMemCreate(&b.handle, b.mapped_bytes, &prop, 0));
+  GCHECK(hipMemMap(b.mapped, b.mapped_bytes, 0, b.handle, 0));
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  GCHECK(hipMemSetAccess(b.mapped, b.mapped_bytes, &acc, 1));
+  size_t slack = b.mapped_bytes - b.user_bytes;
+  void* user = g_end_side ? (char*)b.mapped + slack : b.mapped;
+  if (slack) {
+    void* canary = g_end_side ? b.mapped : (char*)b.mapped + b.user_bytes;
+    GCHECK(hipMemset(canary, kCanary, slack));
+  }
+  // poison the tensor itself (0xFF.. = a NaN) so that reads of never-written memory show up (PG_GUARD_POISON=0: off)
+  if (g_poison) GCHECK(hipMemset(user, 0xFF, b.user_bytes));
+  GCHECK(hipStreamSynchronize(nullptr));  // torch's side streams are non-blocking: the fills must have landed
+  g_live[user] = b;
+  return user;
+}
+
+__attribute__((visibility("default"))) void pg_guard_free(void* ptr, ssize_t size, int device, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_arena && (char*)ptr >= g_arena && (char*)ptr < g_arena + g_arena_bytes) return;  // capture arena: never recycled
+  auto it = g_live.find(ptr);
+  if (it == g_live.end()) {
+    fprintf(stderr, "[pg_guard] free of an unknown pointer %p\n", ptr);
+    return;
+  }
+  if (capturing(stream)) return;  // a graph may keep using it: stays mapped (and checked by pg_guard_check_all)
+  GCHECK(hipSetDevice(device));
+  GCHECK(hipDeviceSynchronize());
+  Block b = it->second;
+  check_block(b, ptr);
+  g_live.erase(it);
+  GCHECK(hipMemUnmap(b.mapped, b.mapped_bytes));
+  GCHECK(hipMemRelease(b.handle));
+  GCHECK(hipMemAddressFree(b.va, b.va_bytes));
+}
+
+// Verifies the canaries of every live allocation (after a device sync). Returns the violation count so far.
+__attribute__((visibility("default"))) int pg_guard_check_all() {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (!g_gran) return 0;
+  GCHECK(hipDeviceSynchronize());
+  for (auto& kv : g_live)
+    if (check_block(kv.second, kv.first)) {
+      // re-arm so the same damage is reported once
+      size_t slack = kv.second.mapped_bytes - kv.second.user_bytes;
+      void* canary = g_end_side ? kv.second.mapped : (char*)kv.second.mapped + kv.second.user_bytes;
+      GCHECK(hipMemset(canary, kCanary, slack));
+    }
+  return g_violations;
+}
+
+__attribute__((visibility("default"))) int pg_guard_violations() { return g_violations; }
+__attribute__((visibility("default"))) const char* pg_guard_report() { return g_report.c_str(); }
+__attribute__((visibility("default"))) long pg_guard_live() { return (long)g_live.size(); }
+
+}  // extern "C"
