@@ -1,6 +1,7 @@
 """bench.py — training throughput of the hot path on MI355X (driver contract: see README/DESIGN).
 
     python bench.py --gpus 1 --steps K --warmup W          # single GPU
+    python bench.py --gpus N --steps K --warmup W          # spawns its own N ranks (one per GPU) when no launcher did
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -111,9 +112,7 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        if self.world != args.gpus:  # under torch.distributed.run the launcher's world size wins
             args.gpus = self.world
         assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
         # debugging hooks (1-GPU dev box): PG_FORCE_DEVICE pins every rank to one GPU and
@@ -212,7 +211,11 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
     env.barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=env.device, dtype=torch.float64)
+    per_rank = [elapsed]
     if env.world > 1:
+        every = [torch.zeros_like(t) for _ in range(env.world)]
+        dist.all_gather(every, t)
+        per_rank = [float(e.item()) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     loss_val = float(loss.item())
@@ -221,9 +224,13 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
     rec = {
         "images_per_s": value, "ms_per_step": elapsed / steps * 1e3, "per_gpu_batch": batch,
         "global_batch": batch * env.world, "launch": launch, "graph_fallback": fallback,
+        # each rank's own clock between the two barriers (the job's rate uses the MAX)
+        "per_rank_images_per_s": {"min": batch * steps / max(per_rank), "max": batch * steps / min(per_rank)},
         "grad_exchange": None if reducer is None else
         f"{reducer.transport} all-reduce of the flat gradient ({opt.flat_grad.numel() * 4 / 1e6:.2f} MB), "
-        + ("inside the step graph" if launch == "hipGraph replay" and reducer.capturable else "eager launch"),
+        + ("ONE message inside the step graph, stream-ordered between backward and grad-norm/Adam; not overlapped "
+           "with compute (the norm needs every gradient, DESIGN.md section 5)"
+           if launch == "hipGraph replay" and reducer.capturable else "eager launch between two graphs"),
         "loss_nats_per_image": loss_val, "bits_per_dim": loss_val / (dims * LN2),
         # whole step against the per-image algorithmic work of SURVEY.md §8(d)
         "step_hbm_gbps_algorithmic": value * w["mbytes"] * 1e6 / 1e9,
@@ -476,6 +483,33 @@ OTHER_CONFIGS = [  # (record key, workload, per-GPU batch, BASELINE.json config)
 ]
 
 
+def _self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU ourselves (the same command with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), forward rank 0's JSON line, return the
+    worst exit code. Equivalent to `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...`."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -491,9 +525,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no batch-64 / PixelSNAIL records)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="images/s of the same headline at --gpus 1: adds scaling_efficiency_vs_n1 to the line")
     ap.add_argument("--require-graph", action="store_true",
                     help="exit non-zero if hipGraph capture fails on any rank instead of falling back to eager")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_spawn(args.gpus))
     env = Env(args)
     graph_on = not args.no_graph
 
@@ -559,7 +597,11 @@ def main():
             },
             "loss_nats_per_image": head["loss_nats_per_image"],
             "bits_per_dim": head["bits_per_dim"],
+            "grad_exchange": head["grad_exchange"],
+            "per_rank_images_per_s": head["per_rank_images_per_s"],
         }
+        if args.n1_value:  # the driver computes efficiency itself; this is a convenience for manual runs
+            out["scaling_efficiency_vs_n1"] = head["images_per_s"] / (env.world * args.n1_value)
         if "imagegpt_b64" in extras:
             b64 = extras["imagegpt_b64"]
             out["imagegpt_b64"] = {"what": "same model and step at the reference's default per-GPU batch 64 "

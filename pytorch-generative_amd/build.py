@@ -11,9 +11,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
+# PG_ABLATE=1: the timing-only ablation build (-DPG_ABLATE: PG_B3_DBG / PG_WB_DBG are compiled in) as a SEPARATE
+# library, lib/libpg_hip_ablate.so, for tools/exp — the production library never contains those switches
+ABLATE = os.environ.get("PG_ABLATE") == "1"
+OBJ = os.path.join(HERE, "build_ablate" if ABLATE else "build")
 LIB_DIR = os.path.join(HERE, "pytorch_generative_amd", "lib")
-LIB = os.path.join(LIB_DIR, "libpg_hip.so")
+LIB = os.path.join(LIB_DIR, "libpg_hip_ablate.so" if ABLATE else "libpg_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950",
@@ -24,7 +27,7 @@ FLAGS = [
     "-munsafe-fp-atomics",  # global_atomic_add_f32 instead of a CAS loop
     "-Wall",
     "-Wno-unused-function",
-]
+] + (["-DPG_ABLATE"] if ABLATE else [])
 
 
 def _sources():

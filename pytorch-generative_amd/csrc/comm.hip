@@ -107,7 +107,9 @@ PG_EXPORT int pg_comm_init(int rank, int world, const char id[PG_COMM_ID_BYTES])
   if (int rc = bind_rccl()) return rc;
   ncclUniqueId u;
   memcpy(u.internal, id, PG_COMM_ID_BYTES);
-  PG_NCCL(g_rccl.CommInitRank(&g_comm, world, u, rank), "pg_comm_init");  // on the calling thread's current device
+  ncclComm_t comm = nullptr;  // published only on success: a refused id must leave no communicator behind
+  PG_NCCL(g_rccl.CommInitRank(&comm, world, u, rank), "pg_comm_init");  // on the calling thread's current device
+  g_comm = comm;
   g_rank = rank;
   g_world = world;
   return 0;

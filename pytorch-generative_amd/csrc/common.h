@@ -209,3 +209,13 @@ __device__ __forceinline__ void pg_stage_rows_vec4(float* __restrict__ lds, int 
     }
   }
 }
+
+// Phase-ablation switches of the bf16x3 kernels (PG_B3_DBG / PG_WB_DBG: skip loads / commit / MFMA / epilogue —
+// WRONG results, timing only) exist only in builds made with -DPG_ABLATE (`PG_ABLATE=1 python build.py`, which
+// writes lib/libpg_hip_ablate.so for tools/exp); in the production library the predicate is a compile-time false
+// and the environment variables are not read.
+#ifdef PG_ABLATE
+#define PG_DBG_BIT(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define PG_DBG_BIT(flags, bit) false
+#endif

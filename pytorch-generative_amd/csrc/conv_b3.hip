@@ -154,6 +154,12 @@ void tap_extent(int T, const int* dr, const int* dc, int& min_dr, int& hr, int& 
 
 }  // namespace
 
+#ifdef PG_ABLATE
+// ablation builds only (not in include/pg_hip.h): destination of conv_b3_kernel's per-wave phase clocks
+static long long* g_b3_prof = nullptr;
+PG_EXPORT void pg_b3_set_prof(void* p) { g_b3_prof = (long long*)p; }
+#endif
+
 // ---- interface used by conv_mfma.hip's exported entry points --------------------------------------
 int pg_b3_applicable(int Kc, int M, int T, int OH, int OW, int hr, int hc) {
   if (OW > 256 || OH * OW < 256) return 0;
@@ -217,7 +223,12 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.in_act = in_act; a.dact = dact; a.out_act = out_act;
   // the instantiations with the GELU paths live in conv_b3_gelu.hip (conv_b3_kernels.h says why)
   const bool gelu = in_act == PG_ACT_GELU || out_act == PG_ACT_GELU || dact == PG_ACT_GELU;
+#ifdef PG_ABLATE
   { const char* e = getenv("PG_B3_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.prof = g_b3_prof;
+#else
+  a.dbg = 0;
+#endif
   int hr, hc;
   tap_extent(T, tap_dr, tap_dc, a.min_dr, hr, a.min_dc, hc);
   const B3Plan pl = b3_plan(Cin, Cout, T);

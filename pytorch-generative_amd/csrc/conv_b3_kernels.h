@@ -28,10 +28,29 @@ struct B3Args {
   int w_off16, b_off, ep_off, dump16;  // LDS offsets: weights (16-byte units), bias / epilogue scratch (floats), dump entry
   int xslots, wslab4;             // staging slots per step; float4 per step's weight slab
   int in_act, dact, out_act;
-  int dbg;                        // ablation switches (PG_B3_DBG), 0 in production
+  int dbg;                        // ablation switches (PG_B3_DBG; -DPG_ABLATE builds only), 0 otherwise
   int g_tapoff[B3_MAXG];          // per group: tap offset in tile pixels
   int g_cg[B3_MAXG];              // per group: channel group of the chunk
+#ifdef PG_ABLATE
+  long long* prof;                // per wave: cycles in {MFMA loop, barrier 1, commit, issue, epilogue, barrier 2, total, steps}
+#endif
 };
+
+// phase clocks of conv_b3_kernel (ablation builds only: tools/exp/b3_phase_prof.py)
+#ifdef PG_ABLATE
+#define PG_PROF_DECL long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pc_ = clock64(); const long long pstart_ = pc_;
+#define PG_PROF_MARK(I) { const long long n_ = clock64(); pt_[I] += n_ - pc_; pc_ = n_; }
+#define PG_PROF_DUMP(WAVES, WAVE, STEPS)                                                              \
+  if (a.prof && (threadIdx.x & 63) == 0) {                                                            \
+    pt_[6] = clock64() - pstart_; pt_[7] = (STEPS);                                                   \
+    long long* d_ = a.prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (WAVES) + (WAVE)) * 8;  \
+    for (int i_ = 0; i_ < 8; ++i_) d_[i_] = pt_[i_];                                                  \
+  }
+#else
+#define PG_PROF_DECL
+#define PG_PROF_MARK(I)
+#define PG_PROF_DUMP(WAVES, WAVE, STEPS)
+#endif
 
 // Which instantiation takes a launch: decided by the host code of conv_b3.hip, executed in the translation unit
 // that holds the instantiations for GL (conv_b3.hip: GL = false; conv_b3_gelu.hip: GL = true).
@@ -218,7 +237,7 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       if (i < a.wslab4) wv[k] = ws_[i];                                                    \
     }                                                                                      \
     const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
-    if (!((a.dbg & 1) && (STEP) > 0))                                                      \
+    if (!(PG_DBG_BIT(a.dbg, 1) && (STEP) > 0))                                                      \
     _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                       \
       if (s_goff[k] >= 0) {                                                                \
         const float* p_ = src_ + s_goff[k];                                                \
@@ -267,10 +286,12 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
   PG_B3_COMMIT_ALL()
   __syncthreads();
   if (nsteps > 1) PG_B3_ISSUE(1)
+  PG_PROF_DECL
   for (int step = 0; step < nsteps; ++step) {
     const int tl = step / nchunk;
     const bool more = step + 1 < nsteps;
-    if (!(a.dbg & 4))
+    PG_PROF_MARK(5)
+    if (!PG_DBG_BIT(a.dbg, 4))
     for (int ks = 0; ks < a.ksteps; ++ks) {
       bf16x8 af[MT][3];
 #pragma unroll
@@ -296,11 +317,15 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
         }
       }
     }
+    PG_PROF_MARK(0)
     __syncthreads();  // every wave is done with the tiles: the next commit may overwrite them
-    if (more && !((a.dbg & 2))) PG_B3_COMMIT_ALL()
+    PG_PROF_MARK(1)
+    if (more && !PG_DBG_BIT(a.dbg, 2)) PG_B3_COMMIT_ALL()
+    PG_PROF_MARK(2)
     if (step + 2 < nsteps) PG_B3_ISSUE(step + 2)
+    PG_PROF_MARK(3)
     const bool last_chunk = (step + 1) % nchunk == 0;
-    if (last_chunk && !(a.dbg & 8)) {
+    if (last_chunk && !PG_DBG_BIT(a.dbg, 8)) {
       // ---- epilogue: v = out_act(acc + bias) * act'(dact_src) + res + res2; per-wave transposition
       // scratch of its own (the tiles already hold the next step). The derivative comes BEFORE the
       // residuals: in a data gradient res / res2 are pass-through gradients of the same tensor (skip
@@ -476,8 +501,10 @@ if constexpr (GL) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    PG_PROF_MARK(4)
     if (more) __syncthreads();  // the commit is visible before the next MFMA loop
   }
+  PG_PROF_DUMP(THREADS / 64, wave_all, nsteps)
 #undef PG_B3_ISSUE
 #undef PG_B3_COMMIT_X
 #undef PG_B3_COMMIT_ALL

@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
   for (int t = 0; t < T; ++t) b_base[t] = a.x_off16 + a.tap_base[t] + wi * a.xpb * 16;
 
   int tile = blockIdx.x;
-  if (tile < a.total_tiles && !(a.dbg & 1)) PG_WB_ISSUE(tile)
+  if (tile < a.total_tiles && !PG_DBG_BIT(a.dbg, 1)) PG_WB_ISSUE(tile)
   for (; tile < a.total_tiles; tile += gridDim.x) {
     __syncthreads();  // the previous tile's fragment reads are done
     // every prefetch register is "used" here on every path: ONE s_waitcnt vmcnt(0) lands at this
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
       asm volatile("" :: "v"(xv[k][0].x), "v"(xv[k][0].y), "v"(xv[k][0].z), "v"(xv[k][0].w),
                          "v"(xv[k][1].x), "v"(xv[k][1].y), "v"(xv[k][1].z), "v"(xv[k][1].w),
                          "v"(xe[k][0]), "v"(xe[k][1]));
-    if (!(a.dbg & 2)) {
+    if (!PG_DBG_BIT(a.dbg, 2)) {
 #pragma unroll
     for (int k = 0; k < WB_DS; ++k) {
       if (d_goff[k] >= 0) {
@@ -297,9 +297,9 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     }
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < a.total_tiles && !(a.dbg & 1)) PG_WB_ISSUE(tile + (int)gridDim.x)
+    if (tile + (int)gridDim.x < a.total_tiles && !PG_DBG_BIT(a.dbg, 1)) PG_WB_ISSUE(tile + (int)gridDim.x)
     // ---- MFMA over the tile's K steps
-    if (!(a.dbg & 4))
+    if (!PG_DBG_BIT(a.dbg, 4))
     for (int ks = 0; ks < a.ksteps; ++ks) {
       const bf16x8* Lk = L + ks * 64;
       bf16x8 af[MR][3];
@@ -658,8 +658,12 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   a.dslots = wb_co * a.dpb; a.xslots = WB_CI * a.xpb;
   a.x_off16 = 3 * (2 * MR) * a.dpb * 16;
   a.in_act = in_act; a.has_bias = has_bias;
+#ifdef PG_ABLATE
   static const int dbg = []() { const char* e = getenv("PG_WB_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
+#else
+  a.dbg = 0;
+#endif
   const int xplane = 2 * a.xpb * 16;
   for (int t = 0; t < T; ++t) a.tap_base[t] = copy_of[t] * 3 * xplane + (tap_dr[t] - min_dr) * PBR * 16;
   for (int t = T; t < WB_MAXT; ++t) a.tap_base[t] = 0;

@@ -6,6 +6,7 @@ from pytorch_generative_amd.nn.convolution import (
     Conv2d,
     ConvTranspose2d,
     GatedActivation,
+    GatedConv,
     NCHWLayerNorm,
 )
 from pytorch_generative_amd.nn.utils import VectorQuantizer
@@ -17,6 +18,7 @@ __all__ = [
     "Conv2d",
     "ConvTranspose2d",
     "GatedActivation",
+    "GatedConv",
     "NCHWLayerNorm",
     "VectorQuantizer",
 ]

@@ -271,6 +271,35 @@ class GatedActivation(nn.Module):
         return ops.gated_activation(x, self._gate, res)
 
 
+class GatedConv(nn.Module):
+    """Convolution to 2 x out_channels followed by GatedActivation, as ONE operator: activation_fn(f) * sigmoid(g)
+    with f / g the two channel halves of conv(x).
+
+    BASELINE.json's north_star lists `GatedConv` on the nn surface; the reference spells it out as a convolution
+    feeding `GatedActivation` (nn/convolution.py:46-66) — GatedPixelCNNLayer's `_vstack_1xN` / `_hstack_Nx1` -> gate
+    (models/autoregressive/gated_pixel_cnn.py:63-96, :99-130) and PixelSNAIL's ResidualBlock
+    (pixel_snail.py:41-56: `Conv2d(n, 2n, 2, padding=1)` -> `GatedActivation(Identity)`). Parameter names are
+    `conv.weight` / `conv.bias` (+ `conv.mask` when causal).
+
+    mask_center: None = plain convolution, True / False = CausalConv2d of type A / B.
+    forward(x, crop=, in_act=, res=): `crop` / `in_act` as Conv2d.forward; `res` is added to the gated output in
+    the gate kernel.
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, padding=0, mask_center=None,
+                 activation_fn=torch.tanh, bias=True):
+        super().__init__()
+        if mask_center is None:
+            self.conv = Conv2d(in_channels, 2 * out_channels, kernel_size, padding=padding, bias=bias)
+        else:
+            self.conv = CausalConv2d(mask_center, in_channels, 2 * out_channels, kernel_size, padding=padding,
+                                     bias=bias)
+        self.gate = GatedActivation(activation_fn)
+
+    def forward(self, x, *, crop=None, in_act=None, res=None):
+        return self.gate(self.conv(x, crop=crop, in_act=in_act), res=res)
+
+
 class NCHWLayerNorm(nn.LayerNorm):
     """LayerNorm over the channel dimension of NCHW tensors (no permutes: one lane per pixel)."""
 

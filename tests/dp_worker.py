@@ -81,11 +81,60 @@ def rccl_world1(out):
                 "rccl_version": lib.pg_comm_rccl_version()}, out)
 
 
+def comm_failure_paths(out):
+    """Error behaviour of the pg_comm_* entry points (include/pg_hip.h): argument errors -> ValueError, RCCL
+    errors -> RuntimeError, and a failed init leaves NO communicator behind (the next init works)."""
+    import ctypes
+
+    import pytest
+
+    from pytorch_generative_amd import _lib
+
+    torch.cuda.set_device(0)
+    lib = _lib.load()
+    buf = torch.ones(16, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(ValueError, match="no communicator"):
+        _lib.check(lib.pg_allreduce_sum(buf.data_ptr(), 16, _lib.DTYPE_F32, st), "pg_allreduce_sum")
+    ident = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+    _lib.check(lib.pg_comm_unique_id(ident), "pg_comm_unique_id")
+    with pytest.raises(ValueError, match="bad rank"):
+        _lib.check(lib.pg_comm_init(1, 1, ident.raw), "pg_comm_init")
+    assert lib.pg_comm_world() == 0
+    # an id no rank 0 ever issued: RCCL's bootstrap must refuse it (zeroed address family), not hang
+    bad = bytes(_lib.COMM_ID_BYTES)
+    bad_id_error = None
+    try:
+        _lib.check(lib.pg_comm_init(0, 1, bad), "pg_comm_init")
+    except RuntimeError as e:
+        bad_id_error = str(e)
+    if bad_id_error is None:  # this RCCL accepted the id for a world of one: a communicator exists, drop it
+        _lib.check(lib.pg_comm_destroy(), "pg_comm_destroy")
+    assert lib.pg_comm_world() == 0, "a failed pg_comm_init left a communicator behind"
+    _lib.check(lib.pg_comm_init(0, 1, ident.raw), "pg_comm_init")  # ... and the next good init works
+    assert lib.pg_comm_world() == 1
+    with pytest.raises(ValueError, match="already exists"):
+        _lib.check(lib.pg_comm_init(0, 1, ident.raw), "pg_comm_init")
+    with pytest.raises(ValueError, match="root"):
+        _lib.check(lib.pg_broadcast(buf.data_ptr(), 16, _lib.DTYPE_F32, 3, st), "pg_broadcast")
+    with pytest.raises(ValueError, match="dtype"):
+        _lib.check(lib.pg_allreduce_sum(buf.data_ptr(), 16, 7, st), "pg_allreduce_sum")
+    _lib.check(lib.pg_allreduce_sum(buf.data_ptr(), 16, _lib.DTYPE_F32, st), "pg_allreduce_sum")
+    torch.cuda.synchronize()
+    assert torch.equal(buf.cpu(), torch.ones(16))
+    _lib.check(lib.pg_comm_destroy(), "pg_comm_destroy")
+    _lib.check(lib.pg_comm_destroy(), "pg_comm_destroy")  # idempotent
+    assert lib.pg_comm_world() == 0
+    torch.save({"bad_id_error": bad_id_error}, out)
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     kind = sys.argv[3] if len(sys.argv) > 3 else "igpt"
     if mode == "rccl1":
         return rccl_world1(out)
+    if mode == "commfail":
+        return comm_failure_paths(out)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)

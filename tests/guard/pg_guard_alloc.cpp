@@ -113,12 +113,21 @@ size_t check_block(const Block& b, void* user) {
       last = i;
     }
   if (bad) {
-    char line[256];
+    char line[384];
     long off0 = g_end_side ? (long)first - (long)n : (long)(b.user_bytes + first);
     long off1 = g_end_side ? (long)last - (long)n : (long)(b.user_bytes + last);
     snprintf(line, sizeof line,
              "allocation #%lu (%zu bytes asked, %zu given): %zu canary bytes overwritten, offsets %ld..%ld relative to the tensor start\n",
              b.serial, b.asked_bytes, b.user_bytes, bad, off0, off1);
+    {  // what was written: the first and the last damaged bytes
+      size_t len = strlen(line);
+      if (len && line[len - 1] == '\n') line[--len] = 0;
+      len += snprintf(line + len, sizeof line - len, "; bytes at %ld:", off0);
+      for (size_t i = first; i < first + 8 && i <= last; i++) len += snprintf(line + len, sizeof line - len, " %02x", host[i]);
+      len += snprintf(line + len, sizeof line - len, " ... at %ld:", off1 - 7 > off0 ? off1 - 7 : off0);
+      for (size_t i = (last >= first + 7 ? last - 7 : first); i <= last; i++) len += snprintf(line + len, sizeof line - len, " %02x", host[i]);
+      snprintf(line + len, sizeof line - len, "\n");
+    }
     g_report += line;
     fprintf(stderr, "[pg_guard] VIOLATION %s", line);
     g_violations++;

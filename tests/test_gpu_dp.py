@@ -93,6 +93,43 @@ def test_rccl_world_of_one_captured_in_the_step_graph(tmp_path):
         assert abs(a - b) <= 2e-6 * abs(b)
 
 
+def test_comm_failure_paths(tmp_path):
+    """pg_comm_* error behaviour (tests/dp_worker.py commfail; its own process: the communicator is per-process
+    state): argument errors raise ValueError, a refused id RuntimeError, and a failed init leaves no communicator."""
+    out = str(tmp_path / "commfail.pt")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "dp_worker.py"), "commfail", out], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-4000:]
+    assert os.path.exists(out)
+
+
+def test_bench_py_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` as ONE bare command (no torch.distributed.run, no WORLD_SIZE): bench.py starts
+    a process per rank itself and rank 0 prints one JSON line with n_gpus == 2. On this 1-GPU box both ranks are
+    pinned to device 0 and talk over gloo (RCCL refuses two ranks on one device); with 2+ GPUs the same command
+    runs rank r on device r over RCCL."""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, PG_FORCE_DEVICE="0", PG_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--batch", "64", "--no-extras", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-4000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 5 and rec["config"]["global_batch"] == 128
+    assert rec["value"] > 0 and rec["scaling"] == "weak"
+    assert "all-reduce of the flat gradient" in rec["grad_exchange"]
+    lo, hi = rec["per_rank_images_per_s"]["min"], rec["per_rank_images_per_s"]["max"]
+    assert 0 < lo <= hi and rec["value"] <= 2 * hi * 1.001
+
+
 def test_train_py_two_workers_through_trainer(tmp_path):
     """`train.py --gpus 2` end to end on one GPU (PG_FORCE_DEVICE=0, gloo): the spawned workers run the
     model module's reproduce() -> recipes.run -> Trainer(n_gpus=2) -> GraphedTrainStep + FlatGradAllReduce.

@@ -383,6 +383,48 @@ def test_gated_activation(dev, kind):
     _util.assert_close(xg.grad, xo.grad, 1e-5, "gate grad")
 
 
+GATED_CONV_CASES = [
+    # (N, Cin, H, W, Cout, k, pad, mask_center, kind, in_act, use_res)
+    (3, 64, 32, 32, 64, 2, 1, None, "identity", "elu", True),    # PixelSNAIL ResidualBlock (pixel_snail.py:41-56)
+    (2, 128, 16, 16, 128, 3, 1, False, "tanh", None, False),     # GatedPixelCNN-style masked stack (type B)
+    (2, 16, 12, 12, 8, 3, 1, True, "tanh", None, False),         # type A, narrow: fp32-MFMA / VALU kernels
+    (2, 64, 28, 28, 32, 1, 0, None, "tanh", "relu", True),       # 1x1
+]
+
+
+@pytest.mark.parametrize("case", GATED_CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_gated_conv(dev, case):
+    """nn.GatedConv (north_star's operator name) = convolution to 2 Cout channels + GatedActivation (+ residual)
+    against the same composition in torch on the CPU: output, dx, dweight, dbias."""
+    from torch import nn as tnn
+
+    from pytorch_generative_amd import nn as pg_nn
+
+    n, cin, h, w, cout, k, pad, mc, kind, in_act, use_res = case
+    torch.manual_seed(0)
+    fn = torch.tanh if kind == "tanh" else tnn.Identity()
+    m = pg_nn.GatedConv(cin, cout, k, padding=pad, mask_center=mc, activation_fn=fn)
+    x, g = _rand(n, cin, h, w, seed=1), _rand(n, cout, h, w, seed=2)
+    res = _rand(n, cout, h, w, seed=3) if use_res else None
+    act_fn = {None: lambda t: t, "relu": F.relu, "elu": F.elu}[in_act]
+    mask = m.conv.mask if mc is not None else torch.ones_like(m.conv.weight)
+    xo = x.clone().requires_grad_(True)
+    wo = (m.conv.weight.detach() * mask).clone().requires_grad_(True)
+    bo = m.conv.bias.detach().clone().requires_grad_(True)
+    yo = oops.gated_activation(F.conv2d(act_fn(xo), wo, bo, padding=pad)[:, :, :h, :w], kind)
+    if use_res:
+        yo = yo + res
+    yo.backward(g)
+    m = m.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    yg = m(xg, crop=(h, w), in_act=in_act, res=None if res is None else res.to(dev))
+    _util.assert_close(yg, yo, TOL, "gated conv")
+    yg.backward(g.to(dev))
+    _util.assert_close(xg.grad, xo.grad, TOL, "dx")
+    _util.assert_close(m.conv.weight.grad, wo.grad, TOL, "dw")
+    _util.assert_close(m.conv.bias.grad, bo.grad, TOL, "db")
+
+
 def test_add_and_broadcast_add(dev):
     from pytorch_generative_amd import ops
 
