@@ -75,7 +75,34 @@ def build(force=False, verbose=True):
             print(f"[build] linked {LIB} from {len(objs)} objects")
     elif verbose:
         print(f"[build] {LIB} up to date")
+    if (rebuilt or force) and not ABLATE:
+        _check_resources(verbose)
     return LIB
+
+
+def _check_resources(verbose):
+    """No kernel of the production library may spill a vector register or use scratch memory: the register /
+    scratch / LDS table of every kernel is read back from the code objects (tools/kernel_resources.py) and the build
+    FAILS on the first spilled VGPR (PG_ALLOW_SPILLS=1 turns the failure into a report, for experiments)."""
+    import importlib.util
+
+    path = os.path.join(HERE, "..", "tools", "kernel_resources.py")
+    if not os.path.exists(path):
+        return
+    spec = importlib.util.spec_from_file_location("pg_kernel_resources", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        rows = mod.check(max_spill=0, verbose=verbose)
+        scratch = [r for r in rows if r["scratch_B"]]
+        if scratch:
+            raise RuntimeError("kernels using scratch memory:\n" + mod.render(scratch))
+    except RuntimeError as e:
+        if os.environ.get("PG_ALLOW_SPILLS") == "1":
+            sys.stderr.write(f"[build] WARNING (PG_ALLOW_SPILLS=1): {e}\n")
+        else:
+            os.remove(LIB)  # a library with spilling kernels must not be picked up by accident
+            raise
 
 
 if __name__ == "__main__":

@@ -509,13 +509,17 @@ void launch_one(int which, const AttnArgs& a, dim3 grid, dim3 block, hipStream_t
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DK, DV>), grid, block, (size_t)b.kt2 * C::RS2 * sizeof(float), st, b);
 }
 
+// Instantiated head dims of these VALU kernels (padded up): d_k <= 4 with d_v <= 32, d_k <= 16 with d_v <= 16 — the
+// register-resident "row owner" formulation holds 2 x (d_k + d_v) operand values (+ as many accumulators in dK/dV) per
+// lane, which beyond these sizes no longer fits the register file (round 3 shipped <64, 64> with 1 755 spilled
+// registers). Larger head dims run on the matrix-core kernels of attention_k4.hip (multiples of 16, L % 16 == 0);
+// ops.causal_attention zero-pads other shapes to the next such size.
 template <int DK>
 int launch_dv(int which, const AttnArgs& a, dim3 grid, dim3 block, hipStream_t st) {
   const int dv = a.dv_dim;
   if (dv <= 4) launch_one<DK, 4>(which, a, grid, block, st);
   else if (dv <= 16) launch_one<DK, 16>(which, a, grid, block, st);
-  else if (dv <= 32) launch_one<DK, 32>(which, a, grid, block, st);
-  else if (dv <= 64) launch_one<DK, 64>(which, a, grid, block, st);
+  else if (DK == 4 && dv <= 32) launch_one<4, 32>(which, a, grid, block, st);
   else return PG_ESHAPE;
   return 0;
 }
@@ -532,7 +536,6 @@ int launch_attn(int which, AttnArgs& a, hipStream_t st) {
   const int dk = a.dk_dim;
   if (dk <= 4) return launch_dv<4>(which, a, grid, block, st);
   if (dk <= 16) return launch_dv<16>(which, a, grid, block, st);
-  if (dk <= 64) return launch_dv<64>(which, a, grid, block, st);
   return PG_ESHAPE;
 }
 
@@ -575,7 +578,7 @@ PG_EXPORT int pg_causal_attn_fwd(const float* q, const float* k, const float* v,
   a.scale = 1.f / sqrtf((float)dk);
   a.scale2 = a.scale * 1.44269504088896340736f;
   rc = launch_any(K_FWD, a, (hipStream_t)stream);
-  PG_REQUIRE(rc == 0, rc, "pg_causal_attn_fwd: unsupported head dims");
+  PG_REQUIRE(rc == 0, rc, "pg_causal_attn_fwd: head dims (%d, %d) at L = %d are not instantiated: pad them to multiples of 16 and L to a multiple of 16 (ops.causal_attention does)", dk, dv, L);
   PG_LAUNCH_CHECK("pg_causal_attn_fwd");
   return 0;
 }
@@ -603,12 +606,12 @@ int attn_bwd_impl(int which_mask, const float* q, const float* k, const float* v
   }
   if (which_mask & 1) {
     rc = launch_any(K_DQ, a, (hipStream_t)stream);
-    PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: unsupported head dims");
+    PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: head dims (%d, %d) at L = %d are not instantiated (see pg_causal_attn_fwd)", dk_dim, dv_dim, L);
     PG_LAUNCH_CHECK("pg_causal_attn_bwd(dq)");
   }
   if (which_mask & 2) {
     rc = launch_any(K_DKV, a, (hipStream_t)stream);
-    PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: unsupported head dims");
+    PG_REQUIRE(rc == 0, rc, "pg_causal_attn_bwd: head dims (%d, %d) at L = %d are not instantiated (see pg_causal_attn_fwd)", dk_dim, dv_dim, L);
     PG_LAUNCH_CHECK("pg_causal_attn_bwd(dkv)");
   }
   return 0;

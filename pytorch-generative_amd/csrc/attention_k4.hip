@@ -520,11 +520,14 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
-// Returns 1 if these kernels took the launch: (d_k, d_v) in {(4, 16), (4, 32), (32, 32)}, L % 16 == 0,
-// 16-byte aligned planes; else 0.
+// Returns 1 if these kernels took the launch: d_k = 4 with d_v in {16, 32, 64}, or d_k in {16, 32, 64} with d_v in
+// {16, 32, 64}; L % 16 == 0; 16-byte aligned planes; else 0. (Round 4: everything beyond (4, 16 / 32) and (32, 32)
+// — the shapes that used to run on VALU kernels spilling up to 1 755 registers.)
 int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st) {
-  const bool small_k = a.dk_dim == 4 && (a.dv_dim == 16 || a.dv_dim == 32);
-  const bool big_k = a.dk_dim == 32 && a.dv_dim == 32;
+  const int dk = a.dk_dim, dv = a.dv_dim;
+  const bool dv_ok = dv == 16 || dv == 32 || dv == 64;
+  const bool small_k = dk == 4 && dv_ok;
+  const bool big_k = (dk == 16 || dk == 32 || dk == 64) && dv_ok;
   if (!(small_k || big_k) || (a.L % 16) != 0 || a.L < 16) return 0;
   if (which > PG_ATTN_DKV) return 0;
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) % 4 != 0) return 0;
@@ -537,22 +540,39 @@ int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st) {
   // A lone wave keeps its SIMD's matrix pipe ~50 % busy (score -> exp -> P.V is one dependent chain
   // per 16-query group), so below ~3 waves per SIMD the blocks are halved to 32 rows: twice the
   // waves, each half as long (measured at batch 128: 1 wave per SIMD ran 2x over the MFMA bound).
-  // d_k = 32 always takes 32-row blocks: with 64 rows the resident operands (q / k / v / dO fragments of
-  // four groups) do not fit the register file.
+  // Rows per block otherwise follow the register file: the resident operands (q / k / v / dO fragments of every
+  // 16-row group of the block) must fit — 32 rows from d_k = 16 on, 16 rows when d_k or d_v is 64.
   static const int force_qb = []() { const char* e = getenv("PG_ATTN_K4_QB"); return e ? atoi(e) : 0; }();
-  int qb = (!big_k && (long)units * (((a.L + 63) / 64 + 1) / 2) >= 3 * 1024) ? 4 : 2;
-  if (!big_k && (force_qb == 2 || force_qb == 4)) qb = force_qb;
+  int qb;
+  if (small_k && dv <= 32) {
+    qb = ((long)units * (((a.L + 63) / 64 + 1) / 2) >= 3 * 1024) ? 4 : 2;
+    if (force_qb == 2 || force_qb == 4) qb = force_qb;
+  } else if (small_k) {
+    qb = 2;
+  } else {
+    qb = (dk == 64 || dv == 64) ? 1 : 2;
+  }
   const int NB = (a.L + 16 * qb - 1) / (16 * qb);
   const int npair = (NB + 1) / 2;
   // units in groups of 64 (8 per XCD); every group has 8 * 8 * npair workgroups
   const int groups = (units + 63) / 64;
   dim3 grid((unsigned)(groups * 64 * npair));
-  if (big_k) {
-    k4_launch<8, 2, 2>(which, a, grid, st);
-  } else if (a.dv_dim == 32) {
-    if (qb == 4) k4_launch<1, 2, 4>(which, a, grid, st); else k4_launch<1, 2, 2>(which, a, grid, st);
+  if (small_k) {
+    if (dv == 64) k4_launch<1, 4, 2>(which, a, grid, st);
+    else if (dv == 32) { if (qb == 4) k4_launch<1, 2, 4>(which, a, grid, st); else k4_launch<1, 2, 2>(which, a, grid, st); }
+    else { if (qb == 4) k4_launch<1, 1, 4>(which, a, grid, st); else k4_launch<1, 1, 2>(which, a, grid, st); }
+  } else if (dk == 16) {
+    if (dv == 16) k4_launch<4, 1, 2>(which, a, grid, st);
+    else if (dv == 32) k4_launch<4, 2, 2>(which, a, grid, st);
+    else k4_launch<4, 4, 1>(which, a, grid, st);
+  } else if (dk == 32) {
+    if (dv == 16) k4_launch<8, 1, 2>(which, a, grid, st);
+    else if (dv == 32) k4_launch<8, 2, 2>(which, a, grid, st);
+    else k4_launch<8, 4, 1>(which, a, grid, st);
   } else {
-    if (qb == 4) k4_launch<1, 1, 4>(which, a, grid, st); else k4_launch<1, 1, 2>(which, a, grid, st);
+    if (dv == 16) k4_launch<16, 1, 1>(which, a, grid, st);
+    else if (dv == 32) k4_launch<16, 2, 1>(which, a, grid, st);
+    else k4_launch<16, 4, 1>(which, a, grid, st);
   }
   return 1;
 }

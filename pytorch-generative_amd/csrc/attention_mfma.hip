@@ -840,11 +840,15 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a
     f32x4 kq[4];  // K^T values of the transposed tile's registers: kq[t][s] = K[kb0 + 16 t + g + 4 s][jc]
     f32x4 acck[4], accv[4];
     int kidx[4];
+    // per-lane row selectors of the block set-up, opaque so that the 64-bit row pointers (v + g L, k + jc L) are
+    // formed here, once per block, instead of living in registers across the block loop
+    int g_row = g, jc_row = jc;
+    asm volatile("" : "+v"(g_row), "+v"(jc_row));
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       kidx[t] = kb0 + 16 * t + qi;
       const bool ok = kidx[t] < L;
-      vf[t] = ok ? vp[(size_t)g * L + kidx[t]] : 0.f;
+      vf[t] = ok ? vp[(size_t)g_row * L + kidx[t]] : 0.f;
       float k4[4];
       load_row4(k4, kp, L, kidx[t]);
 #pragma unroll
@@ -853,7 +857,7 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a
 #pragma unroll
       for (int sl = 0; sl < 4; ++sl) {
         const int kk = kb0 + 16 * t + g + 4 * sl;
-        const float kv = kp[(size_t)jc * L + (kk < L ? kk : L - 1)];
+        const float kv = kp[(size_t)jc_row * L + (kk < L ? kk : L - 1)];
         kq[t][sl] = kk < L ? kv : 0.f;
       }
       acck[t] = zero4;
@@ -962,8 +966,12 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_m44_kernel(const PgAttnArgs a
           v4[i] = gsum(accv[t][i]);
         }
         if (g == 0) {
-          store_rows4(dkp + (size_t)jc * L, L, kb0 + 16 * t + d.qb4, a.vec, k4[0], k4[1], k4[2], k4[3]);
-          store_rows4(dvp + (size_t)jc * L, L, kb0 + 16 * t + d.qb4, a.vec, v4[0], v4[1], v4[2], v4[3]);
+          // the lane's channel row, opaque to the optimiser: with a visible jc it keeps the two per-lane 64-bit row
+          // pointers alive across the whole block loop — at the kernel's 128 registers that was 6 spilled VGPRs
+          int jcs = jc;
+          asm volatile("" : "+v"(jcs));
+          store_rows4(dkp + (size_t)jcs * L, L, kb0 + 16 * t + d.qb4, a.vec, k4[0], k4[1], k4[2], k4[3]);
+          store_rows4(dvp + (size_t)jcs * L, L, kb0 + 16 * t + d.qb4, a.vec, v4[0], v4[1], v4[2], v4[3]);
         }
       }
     }

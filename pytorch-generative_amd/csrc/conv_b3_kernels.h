@@ -174,11 +174,13 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
   }
   const int pw = wave * (NT * 16) + lane;  // store phase: lane = pixel
   const bool sok = (lane < NT * 16) && pw < npx;
-  size_t so_rel;
+  // addresses of the epilogue = uniform base (image, channel: scalar registers) + this 32-bit lane offset (the
+  // lane's pixel inside the image); lanes that store nothing address pixel 0 of the tile's first row
+  unsigned lane_px;
   {
     const int pc = sok ? pw : 0;
     const int r = pc / a.OW;
-    so_rel = (size_t)co0 * L + (size_t)((row0 + r) * a.OW + (pc - r * a.OW));
+    lane_px = (unsigned)((row0 + r) * a.OW + (pc - r * a.OW));
   }
   // per group g = 4 ks + kq: where it lives — plane of its channel group + tap offset (LDS table)
   int* gtab = reinterpret_cast<int*>(lds + a.b_off + B3_CO_CHUNK * CG);
@@ -218,6 +220,9 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
   const int wt = CG == 1 ? tid : tid & (B3_THREADS - 1);
   const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) +
                          (size_t)(CG == 1 ? blockIdx.y : blockIdx.y * CG + (tid >> 8)) * nchunk * a.wslab4;
+  // 64 output channels: the slab (ksteps x 4 tiles x 3 pieces x 64 lanes) is a whole number of 256-thread rounds,
+  // so the weight slots are predicated by a uniform count instead of one lane mask per slot
+  const int nwk = a.wslab4 >> 8;
   float xv[XS][8];
   float4 wv[WS];
 #pragma unroll
@@ -234,7 +239,7 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
     const float4* ws_ = wsrc_b + (size_t)ch_ * a.wslab4;                                   \
     _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                    \
       const int i = wt + k * B3_THREADS;                                                   \
-      if (i < a.wslab4) wv[k] = ws_[i];                                                    \
+      if (MT == 4 ? k < nwk : i < a.wslab4) wv[k] = ws_[i];                                \
     }                                                                                      \
     const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
     if (!(PG_DBG_BIT(a.dbg, 1) && (STEP) > 0))                                                      \
@@ -270,7 +275,7 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
                     (CG == 1 ? 0 : (tid >> 8) * a.wslab4);                                 \
     _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                    \
       const int i = wt + k * B3_THREADS;                                                   \
-      if (i < a.wslab4) wdst_[i] = wv[k];                                                  \
+      if (MT == 4 ? k < nwk : i < a.wslab4) wdst_[i] = wv[k];                              \
     }                                                                                      \
   }
 
@@ -331,9 +336,17 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       // residuals: in a data gradient res / res2 are pass-through gradients of the same tensor (skip
       // connections), which the activation derivative of the convolution's own input does not touch.
       const int n_img = n_first + tl * nstep;
-      const size_t so = so_rel + (size_t)n_img * a.Cout * L;
+      // Lv: the plane size as a value the optimiser cannot see through — with a visible L it hoists the 64 per-channel
+      // byte offsets (cc * L * 4) out of the step loop into 128 scalar registers, which then live in spilled lanes
+      // (v_readlane in front of every store; the kernel carried ~400 scalar spills)
+      int Lv = L;
+      asm volatile("" : "+s"(Lv));
+      const size_t so = ((size_t)n_img * a.Cout + co0) * Lv;   // uniform
       float* ep = lds + a.ep_off + wave_all * (16 * EPS);
       const int cvalid = a.Cout - co0;
+      const bool fullc = cvalid >= MT * 16;   // every channel of the chunk exists: no per-channel store predicate
+      int cvalid_p = cvalid;                  // the partial path's copy, opaque for the same reason as Lv
+      asm volatile("" : "+s"(cvalid_p));
       float* outp = a.out + so;
       const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr, has_res2 = a.res2 != nullptr;
 #define PG_B3_TILE_BODY(M)                                                                       \
@@ -351,9 +364,14 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
   }
 #define PG_B3_TILE_STORE(M)                                                   \
   if (sok) {                                                                  \
-    _Pragma("unroll") for (int c = 0; c < 16; ++c) {                          \
-      const int cc = (M) * 16 + c;                                            \
-      if (cc < cvalid) outp[(size_t)cc * L] = v[c];                           \
+    if (fullc) {                                                              \
+      _Pragma("unroll") for (int c = 0; c < 16; ++c)                          \
+        (outp + (size_t)((M) * 16 + c) * Lv)[lane_px] = v[c];                 \
+    } else {                                                                  \
+      _Pragma("unroll") for (int c = 0; c < 16; ++c) {                        \
+        const int cc = (M) * 16 + c;                                          \
+        if (cc < cvalid_p) (outp + (size_t)cc * Lv)[lane_px] = v[c];            \
+      }                                                                       \
     }                                                                         \
   }
       if (!has_res && !has_ds) {
@@ -369,64 +387,70 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
         // m + 1 are therefore requested BEFORE the stores of tile m (single buffer: right after tile
         // m's values have been used); the wait in front of their use then covers the loads only.
         const float* st0 = has_ds ? a.dact_src + so : nullptr;
-        const float* st1 = has_res ? a.res + so_rel + (size_t)n_img * a.res_bs : nullptr;
-        const float* st2 = has_res2 ? a.res2 + so_rel + (size_t)n_img * a.res2_bs : nullptr;
+        const float* st1 = has_res ? a.res + (size_t)co0 * Lv + (size_t)n_img * a.res_bs : nullptr;
+        const float* st2 = has_res2 ? a.res2 + (size_t)co0 * Lv + (size_t)n_img * a.res2_bs : nullptr;
         const int dsel = has_ds ? a.dact : PG_ACT_NONE;
         // half tiles (8 channels) at a time: 24 operand registers instead of 48 (the kernel is at its
         // register limit; with whole-tile buffers this instantiation spilled 33 dwords)
-        float o0[8], o1[8], o2[8];
+        constexpr int HQ = 4, NH = 16 / HQ;
+        float o0[HQ], o1[HQ], o2[HQ];
 #define PG_B3_REQUEST(M, H)                                                                \
-  _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                          \
-    const int cc = (M) * 16 + (H) * 8 + c;                                                 \
-    const size_t off_ = (size_t)(cc < cvalid ? cc : 0) * L;                                \
-    if (st0) o0[c] = st0[off_];                                                            \
-    if (st1) o1[c] = st1[off_];                                                            \
-    if (st2) o2[c] = st2[off_];                                                            \
+  _Pragma("unroll") for (int c = 0; c < HQ; ++c) {                                          \
+    const int cc = (M) * 16 + (H) * HQ + c;                                                 \
+    const size_t off_ = (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv;                    \
+    if (st0) o0[c] = (st0 + off_)[lane_px];                                                \
+    if (st1) o1[c] = (st1 + off_)[lane_px];                                                \
+    if (st2) o2[c] = (st2 + off_)[lane_px];                                                \
   }
         PG_B3_REQUEST(0, 0)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           PG_B3_TILE_BODY(m)
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
+          for (int hh = 0; hh < NH; ++hh) {
             switch (dsel) {
               case PG_ACT_RELU:
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_RELU);
+                for (int c = 0; c < HQ; ++c) v[hh * HQ + c] *= pg_act_grad(o0[c], PG_ACT_RELU);
                 break;
               case PG_ACT_ELU:
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_ELU);
+                for (int c = 0; c < HQ; ++c) v[hh * HQ + c] *= pg_act_grad(o0[c], PG_ACT_ELU);
                 break;
               case PG_ACT_GELU:
 if constexpr (GL) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_GELU);
+                for (int c = 0; c < HQ; ++c) v[hh * HQ + c] *= pg_act_grad(o0[c], PG_ACT_GELU);
                 }
                 break;
               case PG_ACT_ELU_OUT:
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[hh * 8 + c] *= pg_act_grad(o0[c], PG_ACT_ELU_OUT);
+                for (int c = 0; c < HQ; ++c) v[hh * HQ + c] *= pg_act_grad(o0[c], PG_ACT_ELU_OUT);
                 break;
               default: break;
             }
             if (st1) {
 #pragma unroll
-              for (int c = 0; c < 8; ++c) v[hh * 8 + c] += o1[c];
+              for (int c = 0; c < HQ; ++c) v[hh * HQ + c] += o1[c];
             }
             if (st2) {
 #pragma unroll
-              for (int c = 0; c < 8; ++c) v[hh * 8 + c] += o2[c];
+              for (int c = 0; c < HQ; ++c) v[hh * HQ + c] += o2[c];
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (hh == 0) { PG_B3_REQUEST(m, 1) }
+            if (hh + 1 < NH) { PG_B3_REQUEST(m, hh + 1) }
             else if (m + 1 < MT) { PG_B3_REQUEST(m + 1, 0) }
             __builtin_amdgcn_sched_barrier(0);
             if (sok) {
+              if (fullc) {
 #pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                const int cc = m * 16 + hh * 8 + c;
-                if (cc < cvalid) outp[(size_t)cc * L] = v[hh * 8 + c];
+                for (int c = 0; c < HQ; ++c) (outp + (size_t)(m * 16 + hh * HQ + c) * Lv)[lane_px] = v[hh * HQ + c];
+              } else {
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                  const int cc = m * 16 + hh * HQ + c;
+                  if (cc < cvalid_p) (outp + (size_t)cc * Lv)[lane_px] = v[hh * HQ + c];
+                }
               }
             }
           }
@@ -437,7 +461,7 @@ if constexpr (GL) {
           // before any store, a derivative source behind a residual per tile (res + res -> * act')
         const float* op1 = (has_res ? a.res : a.dact_src) + so;
         const float* op2 = (has_res && has_ds) ? a.dact_src + so : nullptr;
-        constexpr int MH = MT > 2 ? 2 : MT;
+        constexpr int MH = GL ? 1 : (MT > 2 ? 2 : MT);  // GELU instantiations: one tile of operands in flight (registers)
         float ov[MH][16];
         const int dsel = has_ds ? a.dact : PG_ACT_NONE;
 #pragma unroll
@@ -448,7 +472,7 @@ if constexpr (GL) {
 #pragma unroll
               for (int c = 0; c < 16; ++c) {
                 const int cc = (m + mm) * 16 + c;
-                ov[mm][c] = op1[(size_t)(cc < cvalid ? cc : 0) * L];
+                ov[mm][c] = (op1 + (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv)[lane_px];
               }
           }
           PG_B3_TILE_BODY(m)
@@ -460,7 +484,7 @@ if constexpr (GL) {
 #pragma unroll
               for (int c = 0; c < 16; ++c) {
                 const int cc = m * 16 + c;
-                sv[c] = op2[(size_t)(cc < cvalid ? cc : 0) * L];
+                sv[c] = (op2 + (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv)[lane_px];
               }
             }
           } else {
@@ -553,7 +577,6 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
   const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds) + lane;
   const bool kact = kq < a.cgs;  // K groups beyond the chunk's channels are zero (weights packed as zero too)
   const unsigned lane_in = (unsigned)((kact ? 8 * kq : 0) * L + 2 * jc);  // floats from the (image, chunk, tile) base
-  const size_t cstride = (size_t)L;
   const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr, has_res2 = a.res2 != nullptr;
   const int half = lane >> 5, px = lane & 31;  // store phase: lane = (8-channel half, pixel)
 
@@ -568,9 +591,9 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
     const bool ok_ = kact && t0_ + 2 * jc < L;                                                         \
     /* every lane loads from a valid address (its own when ok_, the tile's first otherwise): no branches */ \
     const unsigned lo_ = ok_ ? lane_in : 0u;                                                           \
-    const float* sb_ = a.in + ((size_t)ni_ * a.Cin + (J) * a.CIB) * cstride + t0_;                     \
+    const float* sb_ = a.in + ((size_t)ni_ * a.Cin + (J) * a.CIB) * (size_t)L + t0_;                   \
     _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                    \
-      const f32x2 t_ = *reinterpret_cast<const f32x2*>(sb_ + c * cstride + lo_);                       \
+      const f32x2 t_ = *reinterpret_cast<const f32x2*>(sb_ + c * (size_t)L + lo_);                     \
       DST[c] = f32x2{ok_ ? t_[0] : 0.f, ok_ ? t_[1] : 0.f};                                            \
     }                                                                                                  \
   }
@@ -626,6 +649,9 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
     const int n_img = it / tpi;
     const int t0 = (it - n_img * tpi) * 32;
     const bool sok = t0 + px < L;
+    int Lq = L;  // opaque copy: keeps the per-channel offsets (cc * L) of the epilogue from being hoisted into scalar registers
+    asm volatile("" : "+s"(Lq));
+    const size_t cstride = (size_t)Lq;
     const size_t so = ((size_t)n_img * a.Cout + co0) * cstride + t0;   // uniform
     const int cvalid = a.Cout - co0 - 8 * half;
     // lane part; lanes whose 8-channel half lies entirely beyond Cout (Cout % 64 in 1..8) address the chunk's first channel

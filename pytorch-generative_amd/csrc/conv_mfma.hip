@@ -267,6 +267,11 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
       // lanes that store nothing still LOAD the residual / act' operands below: in a partial last
       // image group their pixel lies in an image past N, so they are pointed at the group's first
       // pixel instead (an out-of-allocation read faulted at batch 128 / 512 with 15-image tiles)
+      // Lv / cvalid_p: copies the optimiser cannot see through — with visible values it hoists the per-channel byte
+      // offsets (cc * L * 4) and store predicates (cc < cvalid) of all 64 channels out of the step loop into scalar
+      // registers, which then live in spilled lanes (v_readlane in front of every store)
+      int Lv = L;
+      asm volatile("" : "+s"(Lv));
       const size_t so = (sok ? so_rel : (size_t)co0 * L) + (size_t)n0 * a.Cout * L;
       // (scratch = the buffer's WEIGHT area, which every commit rewrites completely; the x tile's
       //  zero halo must survive)
@@ -277,6 +282,9 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
       // (a forward residual, or the act' source of a data gradient — the combinations the model
       // code produces) ALL of its values are requested up front.
       const int cvalid = a.Cout - co0;  // channels of this chunk that exist (>= 1)
+      const bool fullc = cvalid >= MT * 16;
+      int cvalid_p = cvalid;
+      asm volatile("" : "+s"(cvalid_p));
       float* outp = a.out + so;
       const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr;
 #define PG_MF_TILE_BODY(M)                                                                       \
@@ -294,9 +302,13 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
   }
 #define PG_MF_TILE_STORE(M)                                                   \
   if (sok) {                                                                  \
-    _Pragma("unroll") for (int c = 0; c < 16; ++c) {                          \
-      const int cc = (M) * 16 + c;                                            \
-      if (cc < cvalid) outp[(size_t)cc * L] = v[c];                           \
+    if (fullc) {                                                              \
+      _Pragma("unroll") for (int c = 0; c < 16; ++c) outp[(size_t)((M) * 16 + c) * Lv] = v[c]; \
+    } else {                                                                  \
+      _Pragma("unroll") for (int c = 0; c < 16; ++c) {                        \
+        const int cc = (M) * 16 + c;                                          \
+        if (cc < cvalid_p) outp[(size_t)cc * Lv] = v[c];                      \
+      }                                                                       \
     }                                                                         \
   }
       if (!has_res && !has_ds) {
@@ -310,7 +322,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
         const float* op1 = (has_res ? a.res : a.dact_src) + so;
         const float* op2 = (has_res && has_ds) ? a.dact_src + so : nullptr;  // both: second one per tile
         // (two tiles' worth at a time: 32 registers; one load batch follows stores per pair)
-        constexpr int MH = MT > 2 ? 2 : MT;
+        constexpr int MH = (MT == 4 && NT >= 3) ? 1 : (MT > 2 ? 2 : MT);  // 64 x 192+ px tiles: one tile of operands in flight (registers: no spills)
         float ov[MH][16];
         const int dsel = has_ds ? a.dact : PG_ACT_NONE;
 #pragma unroll
@@ -321,7 +333,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
 #pragma unroll
               for (int c = 0; c < 16; ++c) {
                 const int cc = (m + mm) * 16 + c;
-                ov[mm][c] = op1[(size_t)(cc < cvalid ? cc : 0) * L];
+                ov[mm][c] = op1[(size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv];
               }
           }
           PG_MF_TILE_BODY(m)
@@ -333,7 +345,7 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
 #pragma unroll
               for (int c = 0; c < 16; ++c) {
                 const int cc = m * 16 + c;
-                sv[c] = op2[(size_t)(cc < cvalid ? cc : 0) * L];
+                sv[c] = op2[(size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv];
               }
             }
           } else {

@@ -1014,12 +1014,58 @@ def set_deterministic(on=True):
 
 def causal_attention_qkv(qkv, n_heads, embed_channels, value_channels, mask_center):
     """causal_attention on the merged [q | k | v] tensor."""
+    L = qkv.shape[2] * qkv.shape[3]
+    if n_heads and embed_channels % n_heads == 0 and value_channels % n_heads == 0 and not attention_dims_native(
+            embed_channels // n_heads, value_channels // n_heads, L):
+        # head dims / L the kernels do not instantiate: the padded route of causal_attention on the two halves
+        return causal_attention(qkv[:, :embed_channels].contiguous(), qkv[:, embed_channels:].contiguous(), n_heads,
+                                embed_channels, value_channels, mask_center)
     return _CausalAttentionQKV.apply(qkv, n_heads, embed_channels, value_channels, bool(mask_center))
 
 
+def attention_dims_native(dk, dv, L):
+    """True if the kernels take these head dims / sequence length as they are (csrc/attention*.hip): d_k = d_v = 4
+    and the small VALU shapes at any L, everything else as multiples of 16 with L % 16 == 0."""
+    if (dk <= 4 and dv <= 32) or (dk <= 16 and dv <= 16):
+        return True
+    return dk in (4, 16, 32, 64) and dv in (16, 32, 64) and L % 16 == 0 and L >= 16
+
+
+def _pad16(d):
+    for v in (16, 32, 64):
+        if d <= v:
+            return v
+    raise ValueError(f"attention: head dim {d} > 64 is not supported")
+
+
 def causal_attention(q, kv, n_heads, embed_channels, value_channels, mask_center):
-    """softmax(mask(q k^T / sqrt(d_k))) v over raster-ordered pixels; kv = cat(k, v) on dim 1."""
-    return _CausalAttention.apply(q, kv, n_heads, embed_channels, value_channels, bool(mask_center))
+    """softmax(mask(q k^T / sqrt(d_k))) v over raster-ordered pixels; kv = cat(k, v) on dim 1.
+
+    Head dims / sequence lengths the kernels do not instantiate (attention_dims_native) are ZERO-PADDED to the next
+    instantiated size — exact: padded channels add nothing to q.k and come out of P.V as zeros, padded positions lie
+    behind every real query (the causal mask hides them) and their own rows are dropped; the 1 / sqrt(d_k) of the
+    REAL d_k is folded into q. The copies are ATen plumbing around the same HIP kernels (no model of the reference
+    takes this route: PixelSNAIL is 4 / 32, ImageGPT 4 / 4 or 32 / 32)."""
+    n, e, h, w = q.shape
+    L = h * w
+    if embed_channels % n_heads or value_channels % n_heads:
+        raise ValueError("attention: channels not divisible by n_heads")
+    dk, dv = embed_channels // n_heads, value_channels // n_heads
+    if attention_dims_native(dk, dv, L):
+        return _CausalAttention.apply(q, kv, n_heads, embed_channels, value_channels, bool(mask_center))
+    dk_p = 4 if dk <= 4 else _pad16(dk)
+    dv_p = _pad16(dv)
+    L_p = -(-L // 16) * 16
+    pad = torch.nn.functional.pad
+    scale = (dk_p / dk) ** 0.5  # the kernel divides by sqrt(dk_p)
+    q4 = pad(q.reshape(n, n_heads, dk, L) * scale, (0, L_p - L, 0, dk_p - dk))
+    k4 = pad(kv[:, :embed_channels].reshape(n, n_heads, dk, L), (0, L_p - L, 0, dk_p - dk))
+    v4 = pad(kv[:, embed_channels:].reshape(n, n_heads, dv, L), (0, L_p - L, 0, dv_p - dv))
+    kv_p = torch.cat((k4.reshape(n, n_heads * dk_p, 1, L_p), v4.reshape(n, n_heads * dv_p, 1, L_p)), dim=1)
+    o_p = _CausalAttention.apply(q4.reshape(n, n_heads * dk_p, 1, L_p).contiguous(), kv_p, n_heads,
+                                 n_heads * dk_p, n_heads * dv_p, bool(mask_center))
+    o = o_p.reshape(n, n_heads, dv_p, L_p)[:, :, :dv, :L]
+    return o.reshape(n, value_channels, h, w)
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 """Guard-page allocator harness for the GPU tests (TEST INFRASTRUCTURE — the package never imports this).
 
 `PG_GUARD=1 python -m pytest tests -m gpu` routes every torch device allocation through
-tests/guard/libpg_guard.so (pg_guard_alloc.cpp): each tensor sits flush against an unmapped page, the slack on its
+tests/guard/libpg_guard.so (pg_guard_alloc.hip): each tensor sits flush against an unmapped page, the slack on its
 other side holds canary bytes. An out-of-bounds access of any kernel then either faults at the launch that did it
 (run with AMD_SERIALIZE_KERNEL=3 to get the guilty Python stack) or is reported by the per-test canary check that
 tests/conftest.py installs.
@@ -17,7 +17,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libpg_guard.so")
-SRC = os.path.join(HERE, "pg_guard_alloc.cpp")
+SRC = os.path.join(HERE, "pg_guard_alloc.hip")
 _lib = None
 
 
@@ -25,7 +25,7 @@ def build(force=False):
     if not force and os.path.exists(SO) and os.path.getmtime(SO) > os.path.getmtime(SRC):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.run([hipcc, "-O2", "-fPIC", "-shared", "-std=c++17", SRC, "-o", SO], check=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17", SRC, "-o", SO], check=True)
     return SO
 
 

@@ -31,9 +31,32 @@
 
 namespace {
 
+// Fills and checks go through KERNELS, not hipMemset / hipMemcpy: the copy engines' handling of pointers into
+// hipMemMap'ed ranges at non-zero offsets proved unreliable on this runtime (the first version of this harness
+// read back canaries that no kernel had touched as damaged, and missed a deliberate stray write).
+__global__ void guard_fill_kernel(unsigned char* p, unsigned char v, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+// res[0] = damaged bytes, res[1] = first damaged index, res[2] = last damaged index, res[3..10] = first 8 damaged bytes' values (at first..)
+__global__ void guard_check_kernel(const unsigned char* p, unsigned char v, size_t n, unsigned long long* res) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (p[i] != v) {
+      atomicAdd(&res[0], 1ull);
+      atomicMin(&res[1], (unsigned long long)i);
+      atomicMax(&res[2], (unsigned long long)i);
+    }
+}
+__global__ void guard_peek_kernel(const unsigned char* p, size_t first, size_t last, unsigned long long* res) {
+  const int t = threadIdx.x;
+  if (t < 8 && first + t <= last) res[3 + t] = p[first + t];
+  if (t >= 8 && t < 16 && last >= (size_t)(15 - t)) res[3 + t] = p[last - (15 - t)];
+}
+unsigned long long* g_res = nullptr;  // 19 words of plain device memory
+
 struct Block {
-  void* va;          // reserved range (guard + mapped + guard)
+  void* va;          // reserved range: END side [mapped | guard], START side [guard][mapped] (two reservations)
   size_t va_bytes;
+  void* lead_guard;  // START side: the separately reserved guard granule in front of the mapping (or null)
   void* mapped;      // first mapped byte
   size_t mapped_bytes;
   hipMemGenericAllocationHandle_t handle;
@@ -49,6 +72,7 @@ size_t g_align = 512;
 bool g_end_side = true;
 bool g_poison = true;
 int g_violations = 0;
+long g_unguarded = 0;  // START side: blocks whose leading guard reservation could not be placed
 unsigned long g_serial = 0;
 std::string g_report;
 char* g_arena = nullptr;
@@ -83,6 +107,7 @@ void init_once(int device) {
   if (const char* s = getenv("PG_GUARD_ARENA_MB")) arena_mb = (size_t)atol(s);
   g_arena_bytes = arena_mb << 20;
   GCHECK(hipMalloc((void**)&g_arena, g_arena_bytes));
+  GCHECK(hipMalloc((void**)&g_res, 19 * sizeof(unsigned long long)));
   fprintf(stderr, "[pg_guard] active: granularity %zu B, align %zu, tensors flush against the %s guard, capture arena %zu MB\n",
           g_gran, g_align, g_end_side ? "END" : "START", arena_mb);
 }
@@ -101,38 +126,40 @@ size_t check_block(const Block& b, void* user) {
   size_t slack = b.mapped_bytes - b.user_bytes;
   size_t n = slack < kCanaryCheck ? slack : kCanaryCheck;
   if (!n) return 0;
-  // canary region adjacent to the tensor
-  char* from = g_end_side ? (char*)user - n : (char*)user + b.user_bytes;
-  std::vector<unsigned char> host(n);
-  GCHECK(hipMemcpy(host.data(), from, n, hipMemcpyDeviceToHost));
-  size_t bad = 0, first = n, last = 0;
-  for (size_t i = 0; i < n; i++)
-    if (host[i] != kCanary) {
-      bad++;
-      if (i < first) first = i;
-      last = i;
-    }
+  const unsigned char* from = g_end_side ? (unsigned char*)user - n : (unsigned char*)user + b.user_bytes;
+  unsigned long long host[19] = {0, ~0ull, 0};
+  GCHECK(hipMemcpy(g_res, host, sizeof host, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(guard_check_kernel, dim3(n >= 4096 ? 16 : 1), dim3(256), 0, nullptr, from, kCanary, n, g_res);
+  GCHECK(hipMemcpy(host, g_res, 3 * sizeof host[0], hipMemcpyDeviceToHost));
+  const size_t bad = (size_t)host[0];
   if (bad) {
+    const size_t first = (size_t)host[1], last = (size_t)host[2];
+    hipLaunchKernelGGL(guard_peek_kernel, dim3(1), dim3(64), 0, nullptr, from, first, last, g_res);
+    GCHECK(hipMemcpy(host, g_res, sizeof host, hipMemcpyDeviceToHost));
     char line[384];
     long off0 = g_end_side ? (long)first - (long)n : (long)(b.user_bytes + first);
     long off1 = g_end_side ? (long)last - (long)n : (long)(b.user_bytes + last);
-    snprintf(line, sizeof line,
-             "allocation #%lu (%zu bytes asked, %zu given): %zu canary bytes overwritten, offsets %ld..%ld relative to the tensor start\n",
-             b.serial, b.asked_bytes, b.user_bytes, bad, off0, off1);
-    {  // what was written: the first and the last damaged bytes
-      size_t len = strlen(line);
-      if (len && line[len - 1] == '\n') line[--len] = 0;
-      len += snprintf(line + len, sizeof line - len, "; bytes at %ld:", off0);
-      for (size_t i = first; i < first + 8 && i <= last; i++) len += snprintf(line + len, sizeof line - len, " %02x", host[i]);
-      len += snprintf(line + len, sizeof line - len, " ... at %ld:", off1 - 7 > off0 ? off1 - 7 : off0);
-      for (size_t i = (last >= first + 7 ? last - 7 : first); i <= last; i++) len += snprintf(line + len, sizeof line - len, " %02x", host[i]);
-      snprintf(line + len, sizeof line - len, "\n");
-    }
+    int len = snprintf(line, sizeof line,
+                       "allocation #%lu (%zu bytes asked, %zu given): %zu canary bytes overwritten, offsets %ld..%ld "
+                       "relative to the tensor start; first bytes:",
+                       b.serial, b.asked_bytes, b.user_bytes, bad, off0, off1);
+    for (int i = 0; i < 8 && first + i <= last; i++) len += snprintf(line + len, sizeof line - len, " %02llx", host[3 + i]);
+    len += snprintf(line + len, sizeof line - len, " last bytes:");
+    for (int i = 8; i < 16; i++)
+      if (last >= (size_t)(15 - i)) len += snprintf(line + len, sizeof line - len, " %02llx", host[3 + i]);
+    snprintf(line + len, sizeof line - len, "\n");
     g_report += line;
     fprintf(stderr, "[pg_guard] VIOLATION %s", line);
     g_violations++;
   }
   return bad;
+}
+
+void fill(void* p, unsigned char v, size_t n) {
+  if (!n) return;
+  size_t blocks = (n + 256 * 64 - 1) / (256 * 64);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(guard_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, (unsigned char*)p, v, n);
 }
 
 }  // namespace
@@ -158,10 +185,36 @@ __attribute__((visibility("default"))) void* pg_guard_malloc(ssize_t size, int d
   b.asked_bytes = (size_t)size;
   b.user_bytes = round_up((size_t)size, g_align);
   b.mapped_bytes = round_up(b.user_bytes, g_gran);
-  b.va_bytes = b.mapped_bytes + 2 * g_gran;
   b.serial = ++g_serial;
-  GCHECK(hipMemAddressReserve(&b.va, b.va_bytes, g_gran, nullptr, 0));
-  b.mapped = (char*)b.va + g_gran;
+  // The mapping always starts at the BASE of its reservation (mapping at an offset inside a reservation is what the
+  // copy engines mishandled). END side: one reservation [mapped | guard granule]. START side: the guard granule in
+  // front is a reservation of its own, placed by reserving guard + mapped in one piece, releasing it and re-reserving
+  // the two parts at the same addresses.
+  if (g_end_side) {
+    b.va_bytes = b.mapped_bytes + g_gran;
+    GCHECK(hipMemAddressReserve(&b.va, b.va_bytes, g_gran, nullptr, 0));
+    b.lead_guard = nullptr;
+  } else {
+    void* whole = nullptr;
+    GCHECK(hipMemAddressReserve(&whole, b.mapped_bytes + g_gran, g_gran, nullptr, 0));
+    GCHECK(hipMemAddressFree(whole, b.mapped_bytes + g_gran));
+    void* guard = nullptr;
+    if (hipMemAddressReserve(&guard, g_gran, g_gran, whole, 0) != hipSuccess || guard != whole) {
+      (void)hipGetLastError();
+      if (guard) GCHECK(hipMemAddressFree(guard, g_gran));
+      guard = nullptr;
+    }
+    b.va_bytes = b.mapped_bytes;
+    void* want = guard ? (char*)guard + g_gran : nullptr;
+    GCHECK(hipMemAddressReserve(&b.va, b.va_bytes, g_gran, want, 0));
+    if (guard && b.va != want) {  // no guard page in front of this block: canaries only
+      GCHECK(hipMemAddressFree(guard, g_gran));
+      guard = nullptr;
+      g_unguarded++;
+    }
+    b.lead_guard = guard;
+  }
+  b.mapped = b.va;
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
@@ -174,12 +227,9 @@ __attribute__((visibility("default"))) void* pg_guard_malloc(ssize_t size, int d
   GCHECK(hipMemSetAccess(b.mapped, b.mapped_bytes, &acc, 1));
   size_t slack = b.mapped_bytes - b.user_bytes;
   void* user = g_end_side ? (char*)b.mapped + slack : b.mapped;
-  if (slack) {
-    void* canary = g_end_side ? b.mapped : (char*)b.mapped + b.user_bytes;
-    GCHECK(hipMemset(canary, kCanary, slack));
-  }
+  if (slack) fill(g_end_side ? b.mapped : (char*)b.mapped + b.user_bytes, kCanary, slack);
   // poison the tensor itself (0xFF.. = a NaN) so that reads of never-written memory show up (PG_GUARD_POISON=0: off)
-  if (g_poison) GCHECK(hipMemset(user, 0xFF, b.user_bytes));
+  if (g_poison) fill(user, 0xFF, b.user_bytes);
   GCHECK(hipStreamSynchronize(nullptr));  // torch's side streams are non-blocking: the fills must have landed
   g_live[user] = b;
   return user;
@@ -202,6 +252,7 @@ __attribute__((visibility("default"))) void pg_guard_free(void* ptr, ssize_t siz
   GCHECK(hipMemUnmap(b.mapped, b.mapped_bytes));
   GCHECK(hipMemRelease(b.handle));
   GCHECK(hipMemAddressFree(b.va, b.va_bytes));
+  if (b.lead_guard) GCHECK(hipMemAddressFree(b.lead_guard, g_gran));
 }
 
 // Verifies the canaries of every live allocation (after a device sync). Returns the violation count so far.
@@ -213,8 +264,8 @@ __attribute__((visibility("default"))) int pg_guard_check_all() {
     if (check_block(kv.second, kv.first)) {
       // re-arm so the same damage is reported once
       size_t slack = kv.second.mapped_bytes - kv.second.user_bytes;
-      void* canary = g_end_side ? kv.second.mapped : (char*)kv.second.mapped + kv.second.user_bytes;
-      GCHECK(hipMemset(canary, kCanary, slack));
+      fill(g_end_side ? kv.second.mapped : (char*)kv.second.mapped + kv.second.user_bytes, kCanary, slack);
+      GCHECK(hipStreamSynchronize(nullptr));
     }
   return g_violations;
 }
@@ -222,5 +273,6 @@ __attribute__((visibility("default"))) int pg_guard_check_all() {
 __attribute__((visibility("default"))) int pg_guard_violations() { return g_violations; }
 __attribute__((visibility("default"))) const char* pg_guard_report() { return g_report.c_str(); }
 __attribute__((visibility("default"))) long pg_guard_live() { return (long)g_live.size(); }
+__attribute__((visibility("default"))) long pg_guard_unguarded() { return g_unguarded; }
 
 }  // extern "C"

@@ -23,7 +23,18 @@ def main():
 
     pg = _lib.load()
     st = ctypes.c_void_p(0)
+    # the copy engines on guarded pointers (the tensor sits at an offset inside its mapping)
+    h = torch.arange(1000, dtype=torch.float32)
+    dv = h.to("cuda")
+    assert float(dv.sum()) == float(h.sum()), "H2D copy into a guarded tensor is wrong"
+    assert torch.equal((dv * 1).cpu(), h) and torch.equal(dv.cpu(), h), "D2H copy out of a guarded tensor is wrong"
+    small = torch.tensor([1.0, 2.0, 3.0]).to("cuda")
+    assert small.cpu().tolist() == [1.0, 2.0, 3.0] and float(small.sum()) == 6.0
+    z = torch.ones(6, device="cuda").zero_()
+    assert z.cpu().tolist() == [0.0] * 6
+    print("copies in / out of guarded tensors: ok")
     t = torch.empty(6, device="cuda")
+    assert not bool(torch.isfinite(t).any()), "fresh tensors are not poisoned"
     n, rep = guard.check_all()
     print("after empty(6):", n, rep.strip())
     t.zero_()

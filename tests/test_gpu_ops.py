@@ -266,6 +266,20 @@ ATTN_CASES = [
     (1, 3, 4, 4, 7, 9, False),     # matrix-core path, L = 63: scalar staging, ragged last group
     (1, 1, 4, 4, 32, 32, False),   # matrix-core path, L = 1024: 16 blocks = 8 waves
     (1, 2, 4, 4, 36, 36, True),    # matrix-core path, L = 1296: two workgroups per (n, head)
+    # round 4: head dims beyond (4, <= 32) / (<= 16, <= 16) on the matrix-core kernels of attention_k4.hip
+    # (instantiated for d_k in {4, 16, 32, 64} x d_v in {16, 32, 64}), other sizes zero-padded by ops.causal_attention
+    (2, 1, 64, 64, 16, 16, False),  # 64 / 64: 16-row blocks
+    (1, 2, 64, 64, 12, 12, True),   # ... strict, L = 144
+    (2, 1, 16, 64, 16, 16, True),   # 16 / 64
+    (2, 2, 4, 64, 16, 16, False),   # 4 / 64: VALU dQ / dK accumulation with 64 value channels
+    (1, 2, 64, 16, 16, 12, False),  # 64 / 16, L = 192
+    (2, 1, 64, 4, 8, 8, True),      # 64 / 4: value channels padded to 16
+    (2, 2, 16, 32, 16, 16, False),  # 16 / 32
+    (1, 2, 32, 16, 20, 20, True),   # 32 / 16, L = 400
+    (2, 1, 32, 64, 8, 8, False),    # 32 / 64
+    (2, 2, 16, 32, 7, 7, False),    # L = 49 padded to 64
+    (1, 1, 24, 40, 9, 5, True),     # 24 / 40 at L = 45: every dimension padded (32 / 64, L = 48)
+    (1, 2, 8, 20, 16, 16, False),   # d_k = 8 padded to 16, d_v = 20 to 32
 ]
 
 
