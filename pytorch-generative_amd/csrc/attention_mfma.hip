@@ -1025,8 +1025,8 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
     // bit-reproducible dQ: the fused kernel sums dQ over key blocks with fp32 LDS atomics)
     if (!pg_attn_fused_bwd_enabled() || a0.dk_dim != 4 || a0.dv_dim != 4) return 0;
   }
-  if ((a0.dk_dim == 4 && a0.dv_dim != 4) || (a0.dk_dim == 32 && a0.dv_dim == 32)) return pg_attn_k4_launch(which, a0, st);
-  if (a0.dk_dim != 4 || a0.dv_dim != 4) return 0;
+  // everything but d_k = d_v = 4: attention_k4.hip decides (d_k in {4, 16, 32, 64} x d_v in {16, 32, 64}, L % 16 == 0)
+  if (a0.dk_dim != 4 || a0.dv_dim != 4) return pg_attn_k4_launch(which, a0, st);
   PgAttnArgs a = a0;
   const int NB = (a.L + 63) / 64;
   a.lp = 64 * NB + 16;  // plane stride == 16 (mod 64): conflict-free b32 and b128 fragment reads

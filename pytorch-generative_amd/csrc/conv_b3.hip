@@ -104,6 +104,14 @@ B3Plan b3_plan(int Kc, int M, int T) {
   if (!on || Kc % 8 != 0 || Kc < 16 || M < 16 || T < 1) return best;
   const int MT = b3_mt(M);
   const int px = T == 1 ? 256 : B3_PX_CAP;
+  // 4 taps with >= 64 output channels: one 8-channel group x 4 taps = exactly one K step of 32 per chunk — the format
+  // of the pipelined kernel (conv_b3p_kernel: double-buffered 14.6 KB x tile + 12 KB weight slab). PG_CONV_B3P=0 keeps
+  // the 16-channel chunks of conv_b3_kernel (A/B).
+  static const bool p_on = []() { const char* e = getenv("PG_CONV_B3P"); return !(e && e[0] == '0'); }();
+  if (p_on && on && T == 4 && MT == 4 && Kc % 8 == 0 && Kc >= 16) {
+    B3Plan pp = {1, 8, 1, 4, 1, 4, (size_t)MT * 3 * 1024, 0};
+    return pp;
+  }
   double best_cost = 1e30;
   for (int CIB = 32; CIB >= 8; CIB >>= 1) {
     if (Kc % CIB != 0) continue;
@@ -282,6 +290,33 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.TR = TR; a.tile_h = TR + hr; a.tile_w = OW + hc;
   a.plane16 = ((a.tile_h * a.tile_w + 15) / 16) * 16;
   a.tiles_per_img = (OH + TR - 1) / TR;
+  if (T == 4 && pl.CIB == 8 && pl.MT == 4 && pl.ksteps == 1 && !pl.w9 && a.tile_h * a.tile_w <= B3P_XS * B3_THREADS) {
+    // ---- the pipelined kernel: LDS = x[2][3 pieces][plane16] | dump entry | w[2][768] | 4 x epilogue scratch | bias, taps
+    for (int g = 0; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }
+    for (int t = 0; t < 4; ++t) a.g_tapoff[t] = (tap_dr[t] - a.min_dr) * a.tile_w + (tap_dc[t] - a.min_dc);
+    a.xslots = a.tile_h * a.tile_w;
+    const size_t x16 = (size_t)2 * 3 * a.plane16;
+    a.dump16 = (int)x16;
+    a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
+    size_t shmem = ((size_t)a.w_off16 + 2 * B3P_W4) * 16;
+    a.ep_off = (int)(shmem / 4);
+    shmem += (size_t)4 * 16 * 68 * 4;
+    a.b_off = (int)(shmem / 4);
+    shmem += (B3_CO_CHUNK + 8) * sizeof(float);
+    PG_REQUIRE(shmem <= (size_t)80 * 1024, PG_ESHAPE, "pg_conv2d_mfma(bf16x3, pipelined): %zu B of LDS", shmem);
+    const int nt = (TR * OW + 63) / 64;
+    const int chunks_y = b3_chunks(Cout);
+    long want = 512 / chunks_y;  // resident workgroups: 2 per CU
+    if (want < a.tiles_per_img) want = a.tiles_per_img;
+    long gx = (want / a.tiles_per_img) * a.tiles_per_img;
+    if (gx > (long)N * a.tiles_per_img) gx = (long)N * a.tiles_per_img;
+    const dim3 grid((unsigned)gx, (unsigned)chunks_y);
+    const B3Launch l = {2, 4, nt, 1, 0, 0, grid, shmem};
+    if (gelu) pg_b3_dispatch_gelu(a, l, st);
+    else b3_dispatch<false>(a, l, st);
+    PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, pipelined)");
+    return 0;
+  }
   for (int g = 0; g < pl.groups; ++g) {
     const int t = g / pl.cgs, cg = g - t * pl.cgs;
     a.g_tapoff[g] = (tap_dr[t] - a.min_dr) * a.tile_w + (tap_dc[t] - a.min_dc);

@@ -55,7 +55,7 @@ struct B3Args {
 // Which instantiation takes a launch: decided by the host code of conv_b3.hip, executed in the translation unit
 // that holds the instantiations for GL (conv_b3.hip: GL = false; conv_b3_gelu.hip: GL = true).
 struct B3Launch {
-  int pw;            // 1: conv_b3_pw_kernel, 0: conv_b3_kernel
+  int pw;            // 2: conv_b3p_kernel (pipelined, 4 taps), 1: conv_b3_pw_kernel, 0: conv_b3_kernel
   int MT, nt, CG, ms, w9;
   dim3 grid;
   size_t shmem;
@@ -215,6 +215,8 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
     const int co = CG == 1 ? co0 + tid : blockIdx.y * CG * B3_CO_CHUNK + tid;
     lds[a.b_off + tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
   }
+
+  __syncthreads();  // the zero fill is ordered before the first commit (other threads own the same entries there)
 
   // weight slab of this thread's chunk: threads [256 c, 256 c + 256) load and commit chunk c's slab
   const int wt = CG == 1 ? tid : tid & (B3_THREADS - 1);
@@ -534,6 +536,341 @@ if constexpr (GL) {
 #undef PG_B3_COMMIT_ALL
 }
 
+// ---- the pipelined kernel for 4-tap convolutions (round 4) -----------------------------------------------
+// conv_b3_kernel runs its phases back to back: measured with its own clocks (tools/exp/b3_phase_prof.py, PixelSNAIL's
+// 2x2 64 -> 64 at N = 512) a wave spends 37 % of its life in the MFMA loop, 26 % committing the next step (activation +
+// split + LDS writes), 10 % issuing loads, 20 % in the epilogue and 7 % at its two barriers per step — and because every
+// wave of a workgroup is in the same phase between two barriers, nothing overlaps. Here a step is ONE K step of 32 =
+// 8 channels x 4 taps (CIB = 8), the x tile and the weight slab are double buffered in LDS (2 x 14.6 KB + 2 x 12 KB),
+// and a step is a single stream
+//     A fragments | B(n = 0) side(0) 24 MFMA | B(1) side(1) 24 MFMA | B(2) side(2) 24 MFMA | B(3) side(3) 24 MFMA | barrier
+// whose "side" slices are the commit of step s + 1 into the OTHER buffers (slot 0, slot 1, weights) and the issue of
+// step s + 2's loads: one barrier per step, and between barriers the waves drift apart by whole slices, so one wave's
+// VALU / LDS / load slices run under the other waves' MFMAs (bf16 MFMAs co-execute with VALU work).
+// Shapes: T = 4 taps (2 x 2 grids: PixelSNAIL's ResidualBlock, the four phase convolutions of the VAEs' 4 x 4 / stride 2
+// and transposed convolutions), >= 64 output channels per chunk (MT = 4). Epilogue: v = out_act(acc + bias) *
+// act'(dact_src) + res + res2, every operand optional, streamed in quarter tiles.
+constexpr int B3P_XS = 2;      // staging slots per thread: tile pixels (<= B3_PX_CAP = 352) over 256 threads
+constexpr int B3P_W4 = 768;    // 16-byte weight fragments per step: 4 co tiles x 3 pieces x 64 lanes
+
+template <bool GL, int NT>
+__global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a) {
+  constexpr int MT = 4, XS = B3P_XS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = blockIdx.x % a.tiles_per_img;
+  const int n_first = blockIdx.x / a.tiles_per_img, nstep = gridDim.x / a.tiles_per_img;
+  const int row0 = rt * a.TR;
+  const int rows = min(a.TR, a.OH - row0);
+  const int npx = rows * a.OW;
+  const int co0 = blockIdx.y * B3_CO_CHUNK;
+  const int L = a.OH * a.OW;
+  const int plane = a.IH * a.IW;
+  const int nchunk = a.Cin >> 3;
+  const int ntiles = n_first < a.N ? (a.N - n_first + nstep - 1) / nstep : 0;
+  const int nsteps = ntiles * nchunk;
+  if (nsteps == 0) return;
+  const int kq = lane >> 4;
+  const int xbuf16 = 3 * a.plane16;   // 16-byte entries of one x buffer (one channel group, three pieces)
+
+  int pixoff[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int p = (wave * NT + n) * 16 + (lane & 15);
+    const int pc = p < npx ? p : 0;
+    const int r = pc / a.OW;
+    pixoff[n] = r * a.tile_w + (pc - r * a.OW);
+  }
+  const int pw = wave * (NT * 16) + lane;
+  const bool sok = (lane < NT * 16) && pw < npx;
+  unsigned lane_px;
+  {
+    const int pc = sok ? pw : 0;
+    const int r = pc / a.OW;
+    lane_px = (unsigned)((row0 + r) * a.OW + (pc - r * a.OW));
+  }
+  // this lane's tap (K group kq of the single K step): offset of its B fragments inside an x buffer
+  int tapoff;
+  {
+    int* gtab = reinterpret_cast<int*>(lds + a.b_off + B3_CO_CHUNK);
+    if (tid < 4) gtab[tid] = a.g_tapoff[tid];
+    __syncthreads();
+    tapoff = gtab[kq];
+  }
+  // staging slots: tile pixel -> 8 channel loads; out-of-image pixels load the tile's first valid word and commit
+  // to the dump entry (the halo entries of both buffers are zeroed once and never written)
+  int s_goff[XS], s_loff[XS];
+  bool s_ok[XS];
+#pragma unroll
+  for (int k = 0; k < XS; ++k) {
+    int e = tid + k * B3_THREADS;
+    const bool in = e < a.xslots;
+    e = in ? e : 0;
+    const int tc = e % a.tile_w;
+    const int tr = e / a.tile_w;
+    const int ir = row0 + a.min_dr + tr, ic = a.min_dc + tc;
+    s_ok[k] = in && ir >= 0 && ir < a.IH && ic >= 0 && ic < a.IW;
+    s_goff[k] = s_ok[k] ? ir * a.IW + ic : 0;
+    s_loff[k] = s_ok[k] ? tr * a.tile_w + tc : -1;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int i = tid; i < 2 * xbuf16; i += B3_THREADS) lds16[i] = u32x4{0u, 0u, 0u, 0u};
+  if (tid < B3_CO_CHUNK) lds[a.b_off + tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
+  __syncthreads();  // the zero fill is ordered before the first commit (other threads own the same entries there)
+
+  const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * B3P_W4 + tid;
+  float xv[XS][8];
+  float4 wv0, wv1, wv2;  // (named, not an array: indexed inside the unrolled slice loop an array stays in scratch memory)
+
+  // (tile, chunk) of the step whose loads are issued next
+  int l_tl = 0, l_ch = 0;
+#define PG_P_ISSUE_X()                                                                         \
+  {                                                                                            \
+    const float* src_ = a.in + ((size_t)(n_first + l_tl * nstep) * a.Cin + l_ch * 8) * plane;  \
+    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                           \
+      const float* p_ = src_ + s_goff[k];                                                      \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = p_[(size_t)c * plane];          \
+    }                                                                                          \
+  }
+#define PG_P_ISSUE_W()                                                                         \
+  {                                                                                            \
+    const float4* ws_ = wsrc_b + (size_t)l_ch * B3P_W4;                                        \
+    wv0 = ws_[0]; wv1 = ws_[B3_THREADS]; wv2 = ws_[2 * B3_THREADS];                            \
+    if (++l_ch == nchunk) { l_ch = 0; ++l_tl; }                                                \
+  }
+#define PG_P_COMMIT_SLOT(K, BUF, ACT)                                                          \
+  {                                                                                            \
+    float e_[8];                                                                               \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) e_[c] = pg_apply_act(xv[K][c], ACT);         \
+    u32x4 h_, m_, l_;                                                                          \
+    split8t(e_, h_, m_, l_);                                                                   \
+    const int dst_ = s_ok[K] ? (BUF) * xbuf16 + s_loff[K] : a.dump16;                          \
+    const int pst_ = s_ok[K] ? a.plane16 : 0;                                                  \
+    lds16[dst_] = h_;                                                                          \
+    lds16[dst_ + pst_] = m_;                                                                   \
+    lds16[dst_ + 2 * pst_] = l_;                                                               \
+  }
+#define PG_P_COMMIT_X(K, BUF)                                                                  \
+  switch (a.in_act) { /* wave-uniform */                                                       \
+    case PG_ACT_RELU: PG_P_COMMIT_SLOT(K, BUF, PG_ACT_RELU) break;                             \
+    case PG_ACT_ELU:  PG_P_COMMIT_SLOT(K, BUF, PG_ACT_ELU) break;                              \
+    case PG_ACT_GELU: if constexpr (GL) { PG_P_COMMIT_SLOT(K, BUF, PG_ACT_GELU) } break;       \
+    default:          PG_P_COMMIT_SLOT(K, BUF, PG_ACT_NONE) break;                             \
+  }
+#define PG_P_COMMIT_W(BUF)                                                                     \
+  {                                                                                            \
+    float4* wd_ = reinterpret_cast<float4*>(lds16 + a.w_off16 + (BUF) * B3P_W4) + tid;         \
+    wd_[0] = wv0; wd_[B3_THREADS] = wv1; wd_[2 * B3_THREADS] = wv2;                            \
+  }
+
+  constexpr int EPS = 68;
+  const float* bl = lds + a.b_off;
+  const bf16x8* xl = reinterpret_cast<const bf16x8*>(lds16) + tapoff;
+  const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds16 + a.w_off16) + lane;
+
+  // prologue: step 0 committed, step 1 in the registers
+  PG_P_ISSUE_X()
+  PG_P_ISSUE_W()
+  PG_P_COMMIT_X(0, 0)
+  PG_P_COMMIT_X(1, 0)
+  PG_P_COMMIT_W(0)
+  if (nsteps > 1) {
+    PG_P_ISSUE_X()
+    PG_P_ISSUE_W()
+  }
+  __syncthreads();
+  PG_PROF_DECL
+  int chunk = 0, tl = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1, nxt = cur ^ 1;
+    const bool more = step + 1 < nsteps, more2 = step + 2 < nsteps;
+    PG_PROF_MARK(5)
+    bf16x8 af[MT][3];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) af[m][pc] = wl[cur * B3P_W4 + (m * 3 + pc) * 64];
+    const bf16x8* xb = xl + cur * xbuf16;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 bh, bm, bo;
+      if (n < NT) {
+        bh = xb[pixoff[n < NT ? n : 0]];
+        bm = xb[pixoff[n < NT ? n : 0] + a.plane16];
+        bo = xb[pixoff[n < NT ? n : 0] + 2 * a.plane16];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // side slice n: commit of step + 1 into the other buffers, issue of step + 2
+      if (n == 0) { if (more) PG_P_COMMIT_X(0, nxt) }
+      if (n == 1) { if (more) PG_P_COMMIT_X(1, nxt) }
+      if (n == 2) { if (more) PG_P_COMMIT_W(nxt) if (more2) PG_P_ISSUE_X() }
+      if (n == 3) { if (more2) PG_P_ISSUE_W() }
+      __builtin_amdgcn_sched_barrier(0);
+      if (n < NT) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 c = acc[m][n < NT ? n : 0];
+          c = MFMA16B(af[m][2], bh, c);  // small terms first
+          c = MFMA16B(af[m][0], bo, c);
+          c = MFMA16B(af[m][1], bm, c);
+          c = MFMA16B(af[m][1], bh, c);
+          c = MFMA16B(af[m][0], bm, c);
+          c = MFMA16B(af[m][0], bh, c);
+          acc[m][n < NT ? n : 0] = c;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    PG_PROF_MARK(0)
+    if (++chunk == nchunk) {
+      chunk = 0;
+      // ---- epilogue of the tile: v = out_act(acc + bias) * act'(dact_src) + res + res2, transposed through the wave's
+      // own scratch so that a store covers 256 contiguous bytes of one channel row
+      const int n_img = n_first + tl * nstep;
+      ++tl;
+      int Lv = L;
+      asm volatile("" : "+s"(Lv));
+      const size_t so = ((size_t)n_img * a.Cout + co0) * Lv;
+      float* ep = lds + a.ep_off + wave * (16 * EPS);
+      const int cvalid = a.Cout - co0;
+      const bool fullc = cvalid >= 64;
+      int cvalid_p = cvalid;
+      asm volatile("" : "+s"(cvalid_p));
+      float* outp = a.out + so;
+      const float* st0 = a.dact_src ? a.dact_src + so : nullptr;
+      const float* st1 = a.res ? a.res + (size_t)co0 * Lv + (size_t)n_img * a.res_bs : nullptr;
+      const float* st2 = a.res2 ? a.res2 + (size_t)co0 * Lv + (size_t)n_img * a.res2_bs : nullptr;
+      const bool any_op = st0 || st1 || st2;
+      const int dsel = st0 ? a.dact : PG_ACT_NONE;
+      constexpr int HQ = 4, NH = 16 / HQ;
+      float o0[HQ], o1[HQ], o2[HQ];
+#define PG_P_REQUEST(M, H)                                                                 \
+  _Pragma("unroll") for (int c = 0; c < HQ; ++c) {                                         \
+    const int cc = (M) * 16 + (H) * HQ + c;                                                \
+    const size_t off_ = (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv;                  \
+    if (st0) o0[c] = (st0 + off_)[lane_px];                                                \
+    if (st1) o1[c] = (st1 + off_)[lane_px];                                                \
+    if (st2) o2[c] = (st2 + off_)[lane_px];                                                \
+  }
+      if (any_op) { PG_P_REQUEST(0, 0) }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[m][n][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = ep[c * EPS + lane] + bl[m * 16 + c];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        switch (a.out_act) { /* wave-uniform */
+          case PG_ACT_RELU:
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_RELU);
+            break;
+          case PG_ACT_ELU:
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_ELU);
+            break;
+          case PG_ACT_GELU:
+            if constexpr (GL) {
+#pragma unroll
+              for (int c = 0; c < 16; ++c) v[c] = pg_apply_act(v[c], PG_ACT_GELU);
+            }
+            break;
+          default: break;
+        }
+        if (!any_op) {
+          if (sok) {
+            if (fullc) {
+#pragma unroll
+              for (int c = 0; c < 16; ++c) (outp + (size_t)(m * 16 + c) * Lv)[lane_px] = v[c];
+            } else {
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                const int cc = m * 16 + c;
+                if (cc < cvalid_p) (outp + (size_t)cc * Lv)[lane_px] = v[c];
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int hh = 0; hh < NH; ++hh) {
+            switch (dsel) {
+              case PG_ACT_RELU:
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) v[hh * HQ + c] *= pg_act_grad(o0[c], PG_ACT_RELU);
+                break;
+              case PG_ACT_ELU:
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) v[hh * HQ + c] *= pg_act_grad(o0[c], PG_ACT_ELU);
+                break;
+              case PG_ACT_GELU:
+                if constexpr (GL) {
+#pragma unroll
+                  for (int c = 0; c < HQ; ++c) v[hh * HQ + c] *= pg_act_grad(o0[c], PG_ACT_GELU);
+                }
+                break;
+              case PG_ACT_ELU_OUT:
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) v[hh * HQ + c] *= pg_act_grad(o0[c], PG_ACT_ELU_OUT);
+                break;
+              default: break;
+            }
+            if (st1) {
+#pragma unroll
+              for (int c = 0; c < HQ; ++c) v[hh * HQ + c] += o1[c];
+            }
+            if (st2) {
+#pragma unroll
+              for (int c = 0; c < HQ; ++c) v[hh * HQ + c] += o2[c];
+            }
+            // the next quarter's operands are requested BEFORE this quarter's stores (loads and stores retire in order)
+            __builtin_amdgcn_sched_barrier(0);
+            if (hh + 1 < NH) { PG_P_REQUEST(m, hh + 1) }
+            else if (m + 1 < MT) { PG_P_REQUEST(m + 1, 0) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (sok) {
+              if (fullc) {
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) (outp + (size_t)(m * 16 + hh * HQ + c) * Lv)[lane_px] = v[hh * HQ + c];
+              } else {
+#pragma unroll
+                for (int c = 0; c < HQ; ++c) {
+                  const int cc = m * 16 + hh * HQ + c;
+                  if (cc < cvalid_p) (outp + (size_t)cc * Lv)[lane_px] = v[hh * HQ + c];
+                }
+              }
+            }
+          }
+        }
+      }
+#undef PG_P_REQUEST
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    PG_PROF_MARK(4)
+    if (more) __syncthreads();  // the other buffers are committed; every wave is done with the current ones
+  }
+  PG_PROF_DUMP(4, wave, nsteps)
+#undef PG_P_ISSUE_X
+#undef PG_P_ISSUE_W
+#undef PG_P_COMMIT_SLOT
+#undef PG_P_COMMIT_X
+#undef PG_P_COMMIT_W
+}
+
 // ---- 1x1 convolutions: no x tile in LDS ---------------------------------------------------------------
 // With one tap a wave's B fragments are read by that wave only, so staging x through LDS buys nothing and
 // costs the workgroup barriers that keep the waves of conv_b3_kernel in lockstep (loads, split and MFMA
@@ -784,6 +1121,24 @@ void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st)
 #undef PG_B3_L
 }
 
+template <bool GL>
+void b3p_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
+#define PG_B3P_L(NTV)                                                                                 \
+  {                                                                                                   \
+    static const hipError_t attr_##NTV = hipFuncSetAttribute(                                         \
+        reinterpret_cast<const void*>(conv_b3p_kernel<GL, NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+    (void)attr_##NTV;                                                                                 \
+    hipLaunchKernelGGL((conv_b3p_kernel<GL, NTV>), grid, dim3(B3_THREADS), shmem, st, a);             \
+  }
+  switch (nt) {
+    case 1: PG_B3P_L(1) break;
+    case 2: PG_B3P_L(2) break;
+    case 3: PG_B3P_L(3) break;
+    default: PG_B3P_L(4) break;
+  }
+#undef PG_B3P_L
+}
+
 template <bool GL, int MT, bool MS = false>
 void b3_pw_launch(const B3Args& a, dim3 grid, size_t shmem, hipStream_t st) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_b3_pw_kernel<GL, MT, MS>),
@@ -795,6 +1150,10 @@ void b3_pw_launch(const B3Args& a, dim3 grid, size_t shmem, hipStream_t st) {
 
 template <bool GL>
 void b3_dispatch(const B3Args& a, const B3Launch& l, hipStream_t st) {
+  if (l.pw == 2) {  // the pipelined 4-tap kernel
+    b3p_launch<GL>(a, l.nt, l.grid, l.shmem, st);
+    return;
+  }
   if (l.pw) {
     if (l.ms) b3_pw_launch<GL, 4, true>(a, l.grid, l.shmem, st);
     else switch (l.MT) {

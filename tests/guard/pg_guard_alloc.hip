@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -72,7 +73,9 @@ size_t g_align = 512;
 bool g_end_side = true;
 bool g_poison = true;
 int g_violations = 0;
-long g_unguarded = 0;  // START side: blocks whose leading guard reservation could not be placed
+long g_unguarded = 0;
+long g_settle_retries = 0;  // fills of FRESH physical memory that did not stick (see settle())
+std::unordered_multimap<size_t, hipMemGenericAllocationHandle_t> g_pool;  // released physical allocations by size  // START side: blocks whose leading guard reservation could not be placed
 unsigned long g_serial = 0;
 std::string g_report;
 char* g_arena = nullptr;
@@ -155,6 +158,28 @@ size_t check_block(const Block& b, void* user) {
   return bad;
 }
 
+void fill(void* p, unsigned char v, size_t n);
+
+// Fresh physical memory is cleared by the driver, and that clear can land AFTER the first kernels that touch the new
+// mapping (observed: canaries written right after hipMemCreate + hipMemMap read back as zeros a moment later). A new
+// allocation is therefore written and read back until two consecutive rounds, 200 us apart, find the pattern intact;
+// physical allocations are then recycled through g_pool (no further clears, and no hipMemCreate per tensor).
+void settle(void* p, size_t n) {
+  int good = 0;
+  for (int round = 0; round < 200 && good < 2; ++round) {
+    const unsigned char pat = (unsigned char)(0xA0 + (round & 15));
+    fill(p, pat, n);
+    GCHECK(hipStreamSynchronize(nullptr));
+    usleep(200);
+    unsigned long long host[3] = {0, ~0ull, 0};
+    GCHECK(hipMemcpy(g_res, host, sizeof host, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(guard_check_kernel, dim3(n >= 65536 ? 64 : 4), dim3(256), 0, nullptr, (const unsigned char*)p, pat, n, g_res);
+    GCHECK(hipMemcpy(host, g_res, sizeof host, hipMemcpyDeviceToHost));
+    if (host[0] == 0) ++good; else { good = 0; ++g_settle_retries; }
+  }
+  if (good < 2) fprintf(stderr, "[pg_guard] WARNING: a fresh %zu-byte allocation never kept its fill pattern\n", n);
+}
+
 void fill(void* p, unsigned char v, size_t n) {
   if (!n) return;
   size_t blocks = (n + 256 * 64 - 1) / (256 * 64);
@@ -219,12 +244,23 @@ __attribute__((visibility("default"))) void* pg_guard_malloc(ssize_t size, int d
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
   prop.location.id = device;
-  GCHECK(hipMemCreate(&b.handle, b.mapped_bytes, &prop, 0));
+  bool fresh = false;
+  {
+    auto it = g_pool.find(b.mapped_bytes);
+    if (it != g_pool.end()) {
+      b.handle = it->second;
+      g_pool.erase(it);
+    } else {
+      GCHECK(hipMemCreate(&b.handle, b.mapped_bytes, &prop, 0));
+      fresh = true;
+    }
+  }
   GCHECK(hipMemMap(b.mapped, b.mapped_bytes, 0, b.handle, 0));
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   GCHECK(hipMemSetAccess(b.mapped, b.mapped_bytes, &acc, 1));
+  if (fresh) settle(b.mapped, b.mapped_bytes);
   size_t slack = b.mapped_bytes - b.user_bytes;
   void* user = g_end_side ? (char*)b.mapped + slack : b.mapped;
   if (slack) fill(g_end_side ? b.mapped : (char*)b.mapped + b.user_bytes, kCanary, slack);
@@ -250,7 +286,7 @@ __attribute__((visibility("default"))) void pg_guard_free(void* ptr, ssize_t siz
   check_block(b, ptr);
   g_live.erase(it);
   GCHECK(hipMemUnmap(b.mapped, b.mapped_bytes));
-  GCHECK(hipMemRelease(b.handle));
+  g_pool.emplace(b.mapped_bytes, b.handle);  // recycled, never released (test runs are short-lived)
   GCHECK(hipMemAddressFree(b.va, b.va_bytes));
   if (b.lead_guard) GCHECK(hipMemAddressFree(b.lead_guard, g_gran));
 }
@@ -274,5 +310,6 @@ __attribute__((visibility("default"))) int pg_guard_violations() { return g_viol
 __attribute__((visibility("default"))) const char* pg_guard_report() { return g_report.c_str(); }
 __attribute__((visibility("default"))) long pg_guard_live() { return (long)g_live.size(); }
 __attribute__((visibility("default"))) long pg_guard_unguarded() { return g_unguarded; }
+__attribute__((visibility("default"))) long pg_guard_settle_retries() { return g_settle_retries; }
 
 }  // extern "C"

@@ -32,6 +32,8 @@ def main():
     assert small.cpu().tolist() == [1.0, 2.0, 3.0] and float(small.sum()) == 6.0
     z = torch.ones(6, device="cuda").zero_()
     assert z.cpu().tolist() == [0.0] * 6
+    big = torch.arange(3_000_000, dtype=torch.float32)
+    assert torch.equal(big.to("cuda").cpu(), big) and float((big.to("cuda") * 0 + 1).sum()) == 3_000_000.0
     print("copies in / out of guarded tensors: ok")
     t = torch.empty(6, device="cuda")
     assert not bool(torch.isfinite(t).any()), "fresh tensors are not poisoned"
@@ -57,7 +59,8 @@ def main():
     print("after a deliberate 64-byte stray write:", n2 - n1, rep.strip()[-300:])
     assert n2 - n1 == 1
     del t, a, b, c, d
-    print("live allocations:", lib.pg_guard_live())
+    lib.pg_guard_settle_retries.restype = ctypes.c_long
+    print("live allocations:", lib.pg_guard_live(), " fills of fresh memory that did not stick:", lib.pg_guard_settle_retries())
     if len(sys.argv) > 1 and sys.argv[1] == "fault":
         # read 4 KB past the guarded edge: must fault (the process dies with the HSA memory-fault message)
         big = torch.zeros(1024, device="cuda")
