@@ -81,6 +81,11 @@ WORKLOADS = {
     "pixel_cnn": dict(ctor="PixelCNN", kw=dict(in_channels=1, out_channels=1, n_residual=15,
                                                residual_channels=32, head_channels=32),
                       chw=(1, 28, 28), lr=1e-3, decay=0.999977, gflop=0.964, mbytes=31.6),
+    # BASELINE.json configs[2] names PixelCNN++ with the discretized-mixture-of-logistics loss; the reference has no such
+    # model: the paper's configuration (Salimans et al. 2017: 160 filters, 5 gated resnets per
+    # level, 10 mixture components), images mapped to [-1, 1], loss = ops.dmol_loss_sum_mean
+    "pixel_cnn_pp": dict(ctor="PixelCNNpp", kw=dict(in_channels=3, n_filters=160, n_resnet=5, n_mix=10),
+                         chw=(3, 32, 32), lr=1e-3, decay=0.999995, gflop=0.0, mbytes=0.0),
     # BASELINE.json configs[4]: VAE conv stacks + KL on 64x64x3 (ELBO loss, vae.py:149-159)
     "beta_vae": dict(ctor="BetaVAE", kw=dict(in_channels=3, out_channels=3, beta=4.0, latent_channels=16,
                                              strides=[2, 2, 2, 2], hidden_channels=64, residual_channels=32),
@@ -159,6 +164,9 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
         def loss_fn(xx, preds):  # ELBO: recon.mean() + kl.mean()
             recon, klm = ops.elbo_terms(preds[0], xx, preds[1])
             return recon + klm
+    elif name == "pixel_cnn_pp":
+        x = x * 2.0 - 1.0  # the network and the logistic mixture see [-1, 1]
+        loss_fn = lambda xx, preds: ops.dmol_loss_sum_mean(preds, xx, w["kw"]["n_mix"])  # noqa: E731
     else:
         loss_fn = lambda xx, preds: ops.bce_with_logits_sum_mean(preds, xx)  # noqa: E731
 
@@ -478,6 +486,7 @@ CEILINGS = {"pixel_cnn": 163e3, "gated_pixel_cnn": 7.4e3, "beta_vae": 100e3, "vd
 OTHER_CONFIGS = [  # (record key, workload, per-GPU batch, BASELINE.json config)
     ("pixel_cnn", "pixel_cnn", 1024, "configs[0]"),
     ("gated_pixel_cnn", "gated_pixel_cnn", 512, "configs[2]"),
+    ("pixel_cnn_pp", "pixel_cnn_pp", 64, "configs[2]"),
     ("beta_vae", "beta_vae", 1024, "configs[4]"),
     ("vd_vae", "vd_vae", 512, "configs[4]"),
 ]
@@ -569,7 +578,8 @@ def main():
             r = run(name, batch, steps=max(5, args.steps // 4))
             others[key] = {"baseline_config": cfg, "images_per_s": r["images_per_s"], "ms_per_step": r["ms_per_step"],
                            "per_gpu_batch": batch, "launch": r["launch"],
-                           "frac_of_fp32_compute_ceiling": r["images_per_s"] / env.world / CEILINGS[key],
+                           "frac_of_fp32_compute_ceiling": (r["images_per_s"] / env.world / CEILINGS[key]
+                                                            if key in CEILINGS else None),
                            "loss_nats_per_image": r["loss_nats_per_image"]}
         extras["other_configs"] = others
 

@@ -114,8 +114,53 @@ class PixelCNNpp(base.AutoregressiveModel):
         assert not u and not ul
         return self._out(hul, in_act="elu")
 
-    def _sample(self, n_samples):
-        raise NotImplementedError("PixelCNNpp: sampling from the logistic mixture is not implemented on this path")
+    @staticmethod
+    def sample_from_mixture(params, n_mix):
+        """One draw per image from the discretized logistic mixture at ONE pixel: params (N, 10 K) in the channel
+        layout of the loss (mixture logits, then per sub-pixel means / log-scales / coefficients) -> (N, 3) in
+        [-1, 1]. The published sampler (Salimans et al. 2017, section 2.1-2.2 and the authors' implementation):
+        component by the Gumbel-max trick, a logistic variate by inverse CDF, then G and B shifted by their
+        linear dependence on the already drawn sub-pixels (eq. 3), each clamped to the image range."""
+        n, k = params.shape[0], n_mix
+        logits = params[:, :k]
+        rest = params[:, k:].reshape(n, 3, 3 * k)
+        u = torch.rand_like(logits).clamp_(1e-5, 1.0 - 1e-5)
+        sel = torch.argmax(logits - torch.log(-torch.log(u)), dim=1)                       # (N,)
+        pick = lambda t: t.gather(2, sel.view(n, 1, 1).expand(n, 3, 1)).squeeze(2)          # noqa: E731  (N, 3)
+        means = pick(rest[:, :, :k])
+        log_scales = pick(rest[:, :, k:2 * k]).clamp(min=-7.0)
+        coeffs = torch.tanh(pick(rest[:, :, 2 * k:]))
+        v = torch.rand_like(means).clamp_(1e-5, 1.0 - 1e-5)
+        x = means + torch.exp(log_scales) * (torch.log(v) - torch.log1p(-v))
+        x0 = x[:, 0].clamp(-1.0, 1.0)
+        x1 = (x[:, 1] + coeffs[:, 0] * x0).clamp(-1.0, 1.0)
+        x2 = (x[:, 2] + coeffs[:, 1] * x0 + coeffs[:, 2] * x1).clamp(-1.0, 1.0)
+        return torch.stack((x0, x1, x2), dim=1)
+
+    @torch.no_grad()
+    def sample(self, n_samples=None, conditioned_on=None, *, image_size=None):
+        """Raster-order sampling as base.AutoregressiveModel.sample (reference models/base.py:97-120: one full
+        forward per pixel, only the unknown entries replaced), with the draw made from the logistic mixture.
+        Images live in [-1, 1]; entries of `conditioned_on` below -1 are the unknown ones. `image_size` (H, W)
+        is needed when the model has not seen a batch yet. (The strided levels make the network non-row-causal
+        for ops.RowDecode: full forwards only.)"""
+        if conditioned_on is not None:
+            canvas = conditioned_on.clone()
+        else:
+            assert n_samples is not None, 'Must provided one, and only one, of "n_samples" or "conditioned_on"'
+            h, w = image_size if image_size is not None else (int(self._h), int(self._w))
+            canvas = torch.full((n_samples, 3, h, w), -2.0, device=self.device)
+        n, _, h, w = canvas.shape
+        unknown = canvas < -1.0
+        canvas = torch.where(unknown, torch.zeros_like(canvas), canvas)  # any finite value: later pixels are never read
+        for row in range(h):
+            for col in range(w):
+                if not bool(unknown[:, :, row, col].any()):
+                    continue
+                params = self.forward(canvas)[:, :, row, col]
+                drawn = self.sample_from_mixture(params, self._n_mix)
+                canvas[:, :, row, col] = torch.where(unknown[:, :, row, col], drawn, canvas[:, :, row, col])
+        return canvas
 
 
 def dmol_loss(x, _, preds, n_mix=10):

@@ -1,14 +1,15 @@
-"""Guard-page allocator harness for the GPU tests (TEST INFRASTRUCTURE — the package never imports this).
+"""Canary allocator harness for the GPU tests (TEST INFRASTRUCTURE — the package never imports this).
 
 `PG_GUARD=1 python -m pytest tests -m gpu` routes every torch device allocation through
-tests/guard/libpg_guard.so (pg_guard_alloc.hip): each tensor sits flush against an unmapped page, the slack on its
-other side holds canary bytes. An out-of-bounds access of any kernel then either faults at the launch that did it
-(run with AMD_SERIALIZE_KERNEL=3 to get the guilty Python stack) or is reported by the per-test canary check that
-tests/conftest.py installs.
+tests/guard/libpg_guard.so (pg_guard_alloc.hip): each tensor is its own device allocation between two 64 KB margins of
+canary bytes, its contents poisoned with NaN bytes. An out-of-bounds WRITE of any kernel is reported by the per-test
+canary check that tests/conftest.py installs (offsets relative to the tensor, the bytes written); a read of
+never-written memory shows up as NaN in the test's own comparison.
 
-    PG_GUARD_SIDE=end|start   which edge of the tensor touches the guard page (overruns | underruns)
-    PG_GUARD_ALIGN=512|16     512 = what torch's caching allocator guarantees in production, 16 = strict
-    PG_GUARD_POISON=0         do not fill fresh tensors with NaN bytes
+    PG_GUARD_ALIGN=512|16       rounding of sizes: 512 = what torch's caching allocator guarantees, 16 = strict
+    PG_GUARD_MARGIN_KB=64       canary bytes on each side
+    PG_GUARD_POISON=0           do not fill fresh tensors with NaN bytes
+    PG_GUARD_MODE=vmm           experimental guard PAGES (out-of-bounds reads fault); unreliable on ROCm 7.2, see the .hip
 """
 
 import ctypes

@@ -109,3 +109,36 @@ def test_pixelcnnpp_oracle_is_autoregressive_and_upsampling_forms_agree():
         z[:, :, ::2, ::2] = t
         b = opp._shifted(z, p, key, kind)
         assert torch.allclose(a, b, atol=1e-12), key
+
+
+def test_mixture_sampler_follows_the_conditioning_chain():
+    """PixelCNNpp.sample_from_mixture (pure torch, runs on any device): with one dominant component of tiny scale the
+    draw is the component's mean, G shifted by coeff0 * R, B by coeff1 * R + coeff2 * G (eq. 3), all clamped."""
+    import math
+
+    from pytorch_generative_amd.models.autoregressive.pixel_cnn_pp import PixelCNNpp
+
+    torch.manual_seed(0)
+    n, k = 64, 3
+    params = torch.zeros(n, 10 * k)
+    params[:, 0], params[:, 1:k] = 50.0, -50.0                     # component 0 always wins the Gumbel-max draw
+    means = torch.tensor([0.3, -0.2, 0.1])
+    coeff_raw = torch.tensor([0.5, -0.7, 0.9])
+    for c in range(3):
+        base = k + c * 3 * k
+        params[:, base] = means[c]
+        params[:, base + 1:base + k] = 5.0                          # the other components' means: must not be used
+        params[:, base + k:base + 2 * k] = -20.0                    # log-scales (clamped at -7 by the sampler)
+        params[:, base + 2 * k] = coeff_raw[c]
+    x = PixelCNNpp.sample_from_mixture(params, k)
+    assert x.shape == (n, 3) and float(x.abs().max()) <= 1.0
+    c0, c1, c2 = (math.tanh(float(v)) for v in coeff_raw)
+    tol = 12 * math.exp(-7.0)                                       # |logit(u)| <= 11.5 for u in [1e-5, 1 - 1e-5]
+    assert float((x[:, 0] - means[0]).abs().max()) <= tol
+    assert float((x[:, 1] - (means[1] + c0 * x[:, 0])).abs().max()) <= tol
+    assert float((x[:, 2] - (means[2] + c1 * x[:, 0] + c2 * x[:, 1])).abs().max()) <= 2 * tol
+    wide = params.clone()
+    for c in range(3):
+        wide[:, k + c * 3 * k + k:k + c * 3 * k + 2 * k] = 3.0      # huge scale: draws pile up on the clamps
+    y = PixelCNNpp.sample_from_mixture(wide, k)
+    assert float(y.abs().max()) <= 1.0 and float((y.abs() == 1.0).float().mean()) > 0.5

@@ -70,9 +70,10 @@ def main():
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
-    sys.path.insert(0, REF)
-    from pytorch_generative import models as ref_models  # the reference itself
-    sys.path.remove(REF)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _ref  # loads /root/reference's package with its torchvision / tensorboard imports bypassed
+
+    ref_models = _ref.load().models  # the reference itself
     import bench
     from oracle import models as omodels
     import torch.nn.functional as F
