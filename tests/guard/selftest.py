@@ -49,13 +49,13 @@ def main():
     x = torch.ones(16, device="cuda")
     y = torch.ones(16, device="cuda")
     victim = torch.zeros(256, device="cuda")
-    _lib.check(pg.pg_add(victim.data_ptr() - 64, x.data_ptr(), y.data_ptr(), 16, st), "pg_add")
+    _lib.check(pg.pg_add(x.data_ptr(), y.data_ptr(), victim.data_ptr() - 64, 16, st), "pg_add")  # (a, b, out)
     torch.cuda.synchronize()
     n2, rep = guard.check_all()
     print("after a 64-byte stray write in front:", n2 - n1, rep.strip().splitlines()[-1][-260:] if rep.strip() else "")
     assert n2 - n1 == 1 and "offsets -64..-1" in rep
     if not vmm:
-        _lib.check(pg.pg_add(victim.data_ptr() + 1024, x.data_ptr(), y.data_ptr(), 16, st), "pg_add")
+        _lib.check(pg.pg_add(x.data_ptr(), y.data_ptr(), victim.data_ptr() + 1024, 16, st), "pg_add")
         torch.cuda.synchronize()
         n3, rep = guard.check_all()
         print("after a 64-byte stray write behind:", n3 - n2, rep.strip().splitlines()[-1][-260:])
@@ -66,7 +66,7 @@ def main():
     if vmm:
         if len(sys.argv) > 1 and sys.argv[1] == "fault":
             bigt = torch.zeros(1024, device="cuda")
-            _lib.check(pg.pg_add(x.data_ptr(), bigt.data_ptr() + 4096 + 4096, y.data_ptr(), 16, st), "pg_add")
+            _lib.check(pg.pg_add(bigt.data_ptr() + 4096 + 4096, y.data_ptr(), x.data_ptr(), 16, st), "pg_add")
             torch.cuda.synchronize()
             print("NO FAULT on an out-of-mapping read")
             return
