@@ -290,7 +290,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.TR = TR; a.tile_h = TR + hr; a.tile_w = OW + hc;
   a.plane16 = ((a.tile_h * a.tile_w + 15) / 16) * 16;
   a.tiles_per_img = (OH + TR - 1) / TR;
-  if (T == 4 && pl.CIB == 8 && pl.MT == 4 && pl.ksteps == 1 && !pl.w9 && a.tile_h * a.tile_w <= B3P_XS * B3_THREADS) {
+  if (T == 4 && pl.CIB == 8 && pl.MT == 4 && pl.ksteps == 1 && !pl.w9 && a.tile_h * a.tile_w <= B3P_PX) {
     // ---- the pipelined kernel: LDS = x[2][3 pieces][plane16] | dump entry | w[2][768] | 4 x epilogue scratch | bias, taps
     for (int g = 0; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }
     for (int t = 0; t < 4; ++t) a.g_tapoff[t] = (tap_dr[t] - a.min_dr) * a.tile_w + (tap_dc[t] - a.min_dc);
@@ -298,20 +298,24 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     const size_t x16 = (size_t)2 * 3 * a.plane16;
     a.dump16 = (int)x16;
     a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
+    // waves per workgroup: 8 (a wave owns 32 pixels, 128 registers, four waves per SIMD) unless PG_CONV_B3P_WAVES=4
+    static const int env_waves = []() { const char* e = getenv("PG_CONV_B3P_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    const int p_waves = gelu ? 4 : env_waves;  // the GELU instantiations exist for 4 waves only
+    const int px = TR * OW;
+    const int nt = p_waves == 8 ? (px + 127) / 128 : (px + 63) / 64;   // 16-pixel groups per wave
     size_t shmem = ((size_t)a.w_off16 + 2 * B3P_W4) * 16;
     a.ep_off = (int)(shmem / 4);
-    shmem += (size_t)4 * 16 * 68 * 4;
+    shmem += (size_t)p_waves * 16 * (nt * 16 + 4) * 4;
     a.b_off = (int)(shmem / 4);
     shmem += (B3_CO_CHUNK + 8) * sizeof(float);
     PG_REQUIRE(shmem <= (size_t)80 * 1024, PG_ESHAPE, "pg_conv2d_mfma(bf16x3, pipelined): %zu B of LDS", shmem);
-    const int nt = (TR * OW + 63) / 64;
     const int chunks_y = b3_chunks(Cout);
     long want = 512 / chunks_y;  // resident workgroups: 2 per CU
     if (want < a.tiles_per_img) want = a.tiles_per_img;
     long gx = (want / a.tiles_per_img) * a.tiles_per_img;
     if (gx > (long)N * a.tiles_per_img) gx = (long)N * a.tiles_per_img;
     const dim3 grid((unsigned)gx, (unsigned)chunks_y);
-    const B3Launch l = {2, 4, nt, 1, 0, 0, grid, shmem};
+    const B3Launch l = {2, 4, nt, p_waves, 0, 0, grid, shmem};
     if (gelu) pg_b3_dispatch_gelu(a, l, st);
     else b3_dispatch<false>(a, l, st);
     PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, pipelined)");

@@ -550,12 +550,23 @@ if constexpr (GL) {
 // Shapes: T = 4 taps (2 x 2 grids: PixelSNAIL's ResidualBlock, the four phase convolutions of the VAEs' 4 x 4 / stride 2
 // and transposed convolutions), >= 64 output channels per chunk (MT = 4). Epilogue: v = out_act(acc + bias) *
 // act'(dact_src) + res + res2, every operand optional, streamed in quarter tiles.
-constexpr int B3P_XS = 2;      // staging slots per thread: tile pixels (<= B3_PX_CAP = 352) over 256 threads
+constexpr int B3P_PX = 352;    // tile pixels with halo the plan allows (= B3_PX_CAP of conv_b3.hip)
 constexpr int B3P_W4 = 768;    // 16-byte weight fragments per step: 4 co tiles x 3 pieces x 64 lanes
 
-template <bool GL, int NT>
-__global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a) {
-  constexpr int MT = 4, XS = B3P_XS;
+// WV = waves per workgroup. 4: a wave owns 64 channels x 64 pixels (NT <= 4 groups of 16), 256 registers, two waves per
+// SIMD. 8 (round 4, second step): a wave owns 64 channels x 32 pixels (NT <= 2) — 32 accumulator registers instead of
+// 64, one staging slot instead of two, 128 registers: FOUR waves per SIMD. Measured with the kernel's clocks, a wave of
+// the 4-wave form spends 1536 cycles per step issuing its 96 MFMAs and ~3400 on everything else (commit VALU at ~6
+// cycles per instruction under the other wave's MFMAs, LDS and load issue, the barrier): two waves keep the matrix
+// pipe 61 % busy, and tools/exp/coexec_ubench.hip shows the pipe itself is not the limit (a second wave's plain VALU
+// stream runs under a full-rate MFMA stream). More waves per SIMD is what fills it; the price is 12 + 6 instead of
+// 12 + 12 fragment reads per 96 MFMAs of a wave pair (1.5x the LDS read traffic, still below the LDS pipe's rate).
+template <bool GL, int NT, int WV>
+__global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args a) {
+  constexpr int MT = 4, THREADS = 64 * WV;
+  constexpr int XS = (B3P_PX + THREADS - 1) / THREADS;      // staging slots per thread (2 / 1)
+  constexpr int WSL = (B3P_W4 + THREADS - 1) / THREADS;     // weight-fragment slots per thread (3 / 2)
+  static_assert(WV == 4 || (WV == 8 && NT <= 2), "8 waves: 32 pixels per wave");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -605,7 +616,7 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a)
   bool s_ok[XS];
 #pragma unroll
   for (int k = 0; k < XS; ++k) {
-    int e = tid + k * B3_THREADS;
+    int e = tid + k * THREADS;
     const bool in = e < a.xslots;
     e = in ? e : 0;
     const int tc = e % a.tile_w;
@@ -622,13 +633,13 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int i = tid; i < 2 * xbuf16; i += B3_THREADS) lds16[i] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < 2 * xbuf16; i += THREADS) lds16[i] = u32x4{0u, 0u, 0u, 0u};
   if (tid < B3_CO_CHUNK) lds[a.b_off + tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
   __syncthreads();  // the zero fill is ordered before the first commit (other threads own the same entries there)
 
   const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * B3P_W4 + tid;
   float xv[XS][8];
-  float4 wv0, wv1, wv2;  // (named, not an array: indexed inside the unrolled slice loop an array stays in scratch memory)
+  float4 wv0, wv1 = make_float4(0.f, 0.f, 0.f, 0.f), wv2 = wv1;  // (named, not an array: indexed inside the unrolled slice loop an array stays in scratch memory)
 
   // (tile, chunk) of the step whose loads are issued next
   int l_tl = 0, l_ch = 0;
@@ -643,7 +654,9 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a)
 #define PG_P_ISSUE_W()                                                                         \
   {                                                                                            \
     const float4* ws_ = wsrc_b + (size_t)l_ch * B3P_W4;                                        \
-    wv0 = ws_[0]; wv1 = ws_[B3_THREADS]; wv2 = ws_[2 * B3_THREADS];                            \
+    wv0 = ws_[0];                                                                              \
+    if (WSL > 2 || tid + THREADS < B3P_W4) wv1 = ws_[THREADS];                                 \
+    if (WSL > 2) wv2 = ws_[2 * THREADS];                                                       \
     if (++l_ch == nchunk) { l_ch = 0; ++l_tl; }                                                \
   }
 #define PG_P_COMMIT_SLOT(K, BUF, ACT)                                                          \
@@ -668,10 +681,12 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a)
 #define PG_P_COMMIT_W(BUF)                                                                     \
   {                                                                                            \
     float4* wd_ = reinterpret_cast<float4*>(lds16 + a.w_off16 + (BUF) * B3P_W4) + tid;         \
-    wd_[0] = wv0; wd_[B3_THREADS] = wv1; wd_[2 * B3_THREADS] = wv2;                            \
+    wd_[0] = wv0;                                                                              \
+    if (WSL > 2 || tid + THREADS < B3P_W4) wd_[THREADS] = wv1;                                 \
+    if (WSL > 2) wd_[2 * THREADS] = wv2;                                                       \
   }
 
-  constexpr int EPS = 68;
+  constexpr int EPS = NT * 16 + 4;  // floats per channel row of a wave's transposition scratch (== 4 mod 32: conflict free)
   const float* bl = lds + a.b_off;
   const bf16x8* xl = reinterpret_cast<const bf16x8*>(lds16) + tapoff;
   const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds16 + a.w_off16) + lane;
@@ -680,7 +695,7 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a)
   PG_P_ISSUE_X()
   PG_P_ISSUE_W()
   PG_P_COMMIT_X(0, 0)
-  PG_P_COMMIT_X(1, 0)
+  if constexpr (XS > 1) { PG_P_COMMIT_X(XS - 1, 0) }
   PG_P_COMMIT_W(0)
   if (nsteps > 1) {
     PG_P_ISSUE_X()
@@ -693,14 +708,63 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a)
     const int cur = step & 1, nxt = cur ^ 1;
     const bool more = step + 1 < nsteps, more2 = step + 2 < nsteps;
     PG_PROF_MARK(5)
-    bf16x8 af[MT][3];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) af[m][pc] = wl[cur * B3P_W4 + (m * 3 + pc) * 64];
+    if constexpr (WV == 8) {
+      // 128 registers: the whole side work runs BEFORE the step's fragments are loaded (its ~44 temporaries and the 48
+      // A-fragment registers never live together); the four waves of a SIMD drift apart by themselves, one wave's
+      // side block under the others' MFMA blocks (tools/exp/coexec_ubench.hip, mode 3)
+      if (more) {
+        PG_P_COMMIT_X(0, nxt)
+        PG_P_COMMIT_W(nxt)
+      }
+      if (more2) {
+        PG_P_ISSUE_X()
+        PG_P_ISSUE_W()
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const bf16x8* xb = xl + cur * xbuf16;
+    if constexpr (WV == 8) {
+      // B fragments of the wave's (<= 2) pixel groups stay resident, the A fragments come in two halves of two output
+      // tiles: 24 + 24 fragment registers instead of 48 + 12 at the same number of LDS reads
+      bf16x8 bf[NT][3];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < NT; ++n) {
+        bf[n][0] = xb[pixoff[n]];
+        bf[n][1] = xb[pixoff[n] + a.plane16];
+        bf[n][2] = xb[pixoff[n] + 2 * a.plane16];
+      }
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        bf16x8 ah[2][3];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) ah[m][pc] = wl[cur * B3P_W4 + ((2 * mh + m) * 3 + pc) * 64];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            f32x4 c = acc[2 * mh + m][n];
+            c = MFMA16B(ah[m][2], bf[n][0], c);  // small terms first
+            c = MFMA16B(ah[m][0], bf[n][2], c);
+            c = MFMA16B(ah[m][1], bf[n][1], c);
+            c = MFMA16B(ah[m][1], bf[n][0], c);
+            c = MFMA16B(ah[m][0], bf[n][1], c);
+            c = MFMA16B(ah[m][0], bf[n][0], c);
+            acc[2 * mh + m][n] = c;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    bf16x8 af[MT][3];
+    if constexpr (WV == 4) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) af[m][pc] = wl[cur * B3P_W4 + (m * 3 + pc) * 64];
+    }
+#pragma unroll
+    for (int n = 0; n < (WV == 8 ? 0 : 4); ++n) {
       bf16x8 bh, bm, bo;
       if (n < NT) {
         bh = xb[pixoff[n < NT ? n : 0]];
@@ -709,10 +773,12 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a)
       }
       __builtin_amdgcn_sched_barrier(0);
       // side slice n: commit of step + 1 into the other buffers, issue of step + 2
-      if (n == 0) { if (more) PG_P_COMMIT_X(0, nxt) }
-      if (n == 1) { if (more) PG_P_COMMIT_X(1, nxt) }
-      if (n == 2) { if (more) PG_P_COMMIT_W(nxt) if (more2) PG_P_ISSUE_X() }
-      if (n == 3) { if (more2) PG_P_ISSUE_W() }
+      if constexpr (WV == 4) {
+        if (n == 0) { if (more) PG_P_COMMIT_X(0, nxt) }
+        if (n == 1) { if constexpr (XS > 1) { if (more) PG_P_COMMIT_X(XS - 1, nxt) } }
+        if (n == 2) { if (more) PG_P_COMMIT_W(nxt) if (more2) PG_P_ISSUE_X() }
+        if (n == 3) { if (more2) PG_P_ISSUE_W() }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (n < NT) {
 #pragma unroll
@@ -863,7 +929,7 @@ __global__ void __launch_bounds__(B3_THREADS, 2) conv_b3p_kernel(const B3Args a)
     PG_PROF_MARK(4)
     if (more) __syncthreads();  // the other buffers are committed; every wave is done with the current ones
   }
-  PG_PROF_DUMP(4, wave, nsteps)
+  PG_PROF_DUMP(WV, wave, nsteps)
 #undef PG_P_ISSUE_X
 #undef PG_P_ISSUE_W
 #undef PG_P_COMMIT_SLOT
@@ -1122,19 +1188,25 @@ void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st)
 }
 
 template <bool GL>
-void b3p_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
-#define PG_B3P_L(NTV)                                                                                 \
+void b3p_launch(const B3Args& a, int nt, int waves, dim3 grid, size_t shmem, hipStream_t st) {
+#define PG_B3P_L(NTV, WVV)                                                                            \
   {                                                                                                   \
-    static const hipError_t attr_##NTV = hipFuncSetAttribute(                                         \
-        reinterpret_cast<const void*>(conv_b3p_kernel<GL, NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-    (void)attr_##NTV;                                                                                 \
-    hipLaunchKernelGGL((conv_b3p_kernel<GL, NTV>), grid, dim3(B3_THREADS), shmem, st, a);             \
+    static const hipError_t attr_##NTV##_##WVV = hipFuncSetAttribute(                                 \
+        reinterpret_cast<const void*>(conv_b3p_kernel<GL, NTV, WVV>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+    (void)attr_##NTV##_##WVV;                                                                         \
+    hipLaunchKernelGGL((conv_b3p_kernel<GL, NTV, WVV>), grid, dim3(64 * WVV), shmem, st, a);          \
+  }
+  if constexpr (!GL) {  // (the GELU-carrying instantiations do not fit 128 registers: 4 waves only)
+    if (waves == 8) {
+      if (nt == 1) PG_B3P_L(1, 8) else PG_B3P_L(2, 8)
+      return;
+    }
   }
   switch (nt) {
-    case 1: PG_B3P_L(1) break;
-    case 2: PG_B3P_L(2) break;
-    case 3: PG_B3P_L(3) break;
-    default: PG_B3P_L(4) break;
+    case 1: PG_B3P_L(1, 4) break;
+    case 2: PG_B3P_L(2, 4) break;
+    case 3: PG_B3P_L(3, 4) break;
+    default: PG_B3P_L(4, 4) break;
   }
 #undef PG_B3P_L
 }
@@ -1151,7 +1223,7 @@ void b3_pw_launch(const B3Args& a, dim3 grid, size_t shmem, hipStream_t st) {
 template <bool GL>
 void b3_dispatch(const B3Args& a, const B3Launch& l, hipStream_t st) {
   if (l.pw == 2) {  // the pipelined 4-tap kernel
-    b3p_launch<GL>(a, l.nt, l.grid, l.shmem, st);
+    b3p_launch<GL>(a, l.nt, l.CG, l.grid, l.shmem, st);  // (CG carries the waves per workgroup: 4 / 8)
     return;
   }
   if (l.pw) {

@@ -3,7 +3,7 @@
 // Plugged into torch with torch.cuda.memory.CUDAPluggableAllocator (tests/guard/__init__.py, PG_GUARD=1): every
 // tensor of a test run then lives in its OWN device allocation between two margins filled with a canary byte,
 //
-//     [ 64 KB canary | the tensor (poisoned with 0xFF = NaN) | 64 KB canary ]
+//     [ 64 KB canary (0xFF) | the tensor (poisoned with 0xFF = NaN) | 64 KB canary (0xFF) ]
 //
 // so that an out-of-bounds WRITE of a kernel is no longer absorbed by the caching allocator's 2-20 MB segments: the
 // margins are verified when the tensor is freed and, by the fixture tests/conftest.py installs, after every test
@@ -74,7 +74,8 @@ std::string g_report;
 char* g_arena = nullptr;
 size_t g_arena_bytes = 0, g_arena_used = 0;
 unsigned long long* g_res = nullptr;  // 19 words of plain device memory for the check kernels
-const unsigned char kCanary = 0xCB;
+const unsigned char kCanary = 0xFF;  // = the poison: a float read from a margin is a NaN, so an out-of-bounds READ whose value is used
+                                      // (even multiplied by a zero weight) turns the test's result into NaN
 
 void die(const char* what, hipError_t e) {
   fprintf(stderr, "[pg_guard] %s failed: %s\n", what, hipGetErrorString(e));
@@ -103,7 +104,7 @@ void init_once(int device) {
     prop.location.id = device;
     GCHECK(hipMemGetAllocationGranularity(&g_gran, &prop, hipMemAllocationGranularityMinimum));
   }
-  size_t arena_mb = 4096;
+  size_t arena_mb = 32768;  // captured steps allocate every activation and workspace of a training step, never recycled
   if (const char* s = getenv("PG_GUARD_ARENA_MB")) arena_mb = (size_t)atol(s);
   g_arena_bytes = arena_mb << 20;
   GCHECK(hipMalloc((void**)&g_arena, g_arena_bytes));
