@@ -300,12 +300,12 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
     // waves per workgroup: 8 (a wave owns 32 pixels, 128 registers, four waves per SIMD) unless PG_CONV_B3P_WAVES=4
     static const int env_waves = []() { const char* e = getenv("PG_CONV_B3P_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
-    const int p_waves = gelu ? 4 : env_waves;  // the GELU instantiations exist for 4 waves only
+    const int p_waves = env_waves;
     const int px = TR * OW;
     const int nt = p_waves == 8 ? (px + 127) / 128 : (px + 63) / 64;   // 16-pixel groups per wave
     size_t shmem = ((size_t)a.w_off16 + 2 * B3P_W4) * 16;
     a.ep_off = (int)(shmem / 4);
-    shmem += (size_t)p_waves * 16 * (nt * 16 + 4) * 4;
+    if (p_waves == 4) shmem += (size_t)4 * 16 * (nt * 16 + 4) * 4;  // per-wave transposition scratch (8 waves store directly)
     a.b_off = (int)(shmem / 4);
     shmem += (B3_CO_CHUNK + 8) * sizeof(float);
     PG_REQUIRE(shmem <= (size_t)80 * 1024, PG_ESHAPE, "pg_conv2d_mfma(bf16x3, pipelined): %zu B of LDS", shmem);

@@ -550,6 +550,7 @@ if constexpr (GL) {
 // Shapes: T = 4 taps (2 x 2 grids: PixelSNAIL's ResidualBlock, the four phase convolutions of the VAEs' 4 x 4 / stride 2
 // and transposed convolutions), >= 64 output channels per chunk (MT = 4). Epilogue: v = out_act(acc + bias) *
 // act'(dact_src) + res + res2, every operand optional, streamed in quarter tiles.
+typedef float f32x2p __attribute__((ext_vector_type(2)));
 constexpr int B3P_PX = 352;    // tile pixels with halo the plan allows (= B3_PX_CAP of conv_b3.hip)
 constexpr int B3P_W4 = 768;    // 16-byte weight fragments per step: 4 co tiles x 3 pieces x 64 lanes
 
@@ -594,6 +595,17 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
     const int r = pc / a.OW;
     pixoff[n] = r * a.tile_w + (pc - r * a.OW);
   }
+  // 8 waves: the epilogue stores straight from the accumulator layout (lane = 4 channels x 1 pixel of each group)
+  unsigned opx[NT];
+  bool ook[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int p = (wave * NT + n) * 16 + (lane & 15);
+    ook[n] = p < npx;
+    const int pc = ook[n] ? p : 0;
+    const int r = pc / a.OW;
+    opx[n] = (unsigned)((row0 + r) * a.OW + (pc - r * a.OW));
+  }
   const int pw = wave * (NT * 16) + lane;
   const bool sok = (lane < NT * 16) && pw < npx;
   unsigned lane_px;
@@ -637,7 +649,7 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
   if (tid < B3_CO_CHUNK) lds[a.b_off + tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
   __syncthreads();  // the zero fill is ordered before the first commit (other threads own the same entries there)
 
-  const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * B3P_W4 + tid;
+  const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * B3P_W4;  // uniform
   float xv[XS][8];
   float4 wv0, wv1 = make_float4(0.f, 0.f, 0.f, 0.f), wv2 = wv1;  // (named, not an array: indexed inside the unrolled slice loop an array stays in scratch memory)
 
@@ -647,16 +659,22 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
   {                                                                                            \
     const float* src_ = a.in + ((size_t)(n_first + l_tl * nstep) * a.Cin + l_ch * 8) * plane;  \
     _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                           \
-      const float* p_ = src_ + s_goff[k];                                                      \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = p_[(size_t)c * plane];          \
+      /* uniform channel base (scalar registers) + the slot's 32-bit offset */                 \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = (src_ + (size_t)c * plane)[(unsigned)s_goff[k]]; \
     }                                                                                          \
   }
 #define PG_P_ISSUE_W()                                                                         \
   {                                                                                            \
     const float4* ws_ = wsrc_b + (size_t)l_ch * B3P_W4;                                        \
-    wv0 = ws_[0];                                                                              \
-    if (WSL > 2 || tid + THREADS < B3P_W4) wv1 = ws_[THREADS];                                 \
-    if (WSL > 2) wv2 = ws_[2 * THREADS];                                                       \
+    if constexpr (WV == 8) { /* 768 fragments over 512 threads: three 8-byte halves each, no predicate */ \
+      const f32x2p* w2_ = reinterpret_cast<const f32x2p*>(ws_);                                  \
+      const f32x2p h0_ = w2_[(unsigned)tid], h1_ = (w2_ + THREADS)[(unsigned)tid], h2_ = (w2_ + 2 * THREADS)[(unsigned)tid]; \
+      wv0.x = h0_[0]; wv0.y = h0_[1]; wv0.z = h1_[0]; wv0.w = h1_[1]; wv1.x = h2_[0]; wv1.y = h2_[1]; \
+    } else {                                                                                   \
+      wv0 = ws_[(unsigned)tid];                                                                \
+      wv1 = (ws_ + THREADS)[(unsigned)tid];                                                    \
+      wv2 = (ws_ + 2 * THREADS)[(unsigned)tid];                                                \
+    }                                                                                          \
     if (++l_ch == nchunk) { l_ch = 0; ++l_tl; }                                                \
   }
 #define PG_P_COMMIT_SLOT(K, BUF, ACT)                                                          \
@@ -681,9 +699,12 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
 #define PG_P_COMMIT_W(BUF)                                                                     \
   {                                                                                            \
     float4* wd_ = reinterpret_cast<float4*>(lds16 + a.w_off16 + (BUF) * B3P_W4) + tid;         \
-    wd_[0] = wv0;                                                                              \
-    if (WSL > 2 || tid + THREADS < B3P_W4) wd_[THREADS] = wv1;                                 \
-    if (WSL > 2) wd_[2 * THREADS] = wv2;                                                       \
+    if constexpr (WV == 8) {                                                                   \
+      f32x2p* w2_ = reinterpret_cast<f32x2p*>(lds16 + a.w_off16 + (BUF) * B3P_W4) + tid;         \
+      w2_[0] = f32x2p{wv0.x, wv0.y}; w2_[THREADS] = f32x2p{wv0.z, wv0.w}; w2_[2 * THREADS] = f32x2p{wv1.x, wv1.y}; \
+    } else {                                                                                   \
+      wd_[0] = wv0; wd_[THREADS] = wv1; wd_[2 * THREADS] = wv2;                                \
+    }                                                                                          \
   }
 
   constexpr int EPS = NT * 16 + 4;  // floats per channel row of a wave's transposition scratch (== 4 mod 32: conflict free)
@@ -826,6 +847,88 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
     if (st1) o1[c] = (st1 + off_)[lane_px];                                                \
     if (st2) o2[c] = (st2 + off_)[lane_px];                                                \
   }
+      if constexpr (WV == 8) {
+        // direct: channel = 16 m + 4 kq + r, pixel = the lane's pixel of group n — a store instruction writes four
+        // 64-byte row segments; no LDS round trip, no waits, every lane busy (through the transposition scratch half
+        // of the lanes of a 32-pixel wave tile would idle: 983 of 5445 cycles per step, tools/exp/b3_phase_prof.py)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + m * 16 + kq * 4);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            float v[4], q0[4], q1[4], q2[4];
+            unsigned ox = opx[n];  // opaque: the lane's 64-bit row addresses are formed here, not kept across the step loop
+            asm volatile("" : "+v"(ox));
+            int krow = kq * 4;
+            asm volatile("" : "+v"(krow));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int cc = m * 16 + krow + r;
+              const size_t off_ = (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv;
+              if (st0) q0[r] = (st0 + off_)[ox];
+              if (st1) q1[r] = (st1 + off_)[ox];
+              if (st2) q2[r] = (st2 + off_)[ox];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[m][n][r] + b4[r];
+            switch (a.out_act) { /* wave-uniform */
+              case PG_ACT_RELU:
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = pg_apply_act(v[r], PG_ACT_RELU);
+                break;
+              case PG_ACT_ELU:
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = pg_apply_act(v[r], PG_ACT_ELU);
+                break;
+              case PG_ACT_GELU:
+                if constexpr (GL) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) v[r] = pg_apply_act(v[r], PG_ACT_GELU);
+                }
+                break;
+              default: break;
+            }
+            switch (dsel) {
+              case PG_ACT_RELU:
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= pg_act_grad(q0[r], PG_ACT_RELU);
+                break;
+              case PG_ACT_ELU:
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= pg_act_grad(q0[r], PG_ACT_ELU);
+                break;
+              case PG_ACT_GELU:
+                if constexpr (GL) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) v[r] *= pg_act_grad(q0[r], PG_ACT_GELU);
+                }
+                break;
+              case PG_ACT_ELU_OUT:
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= pg_act_grad(q0[r], PG_ACT_ELU_OUT);
+                break;
+              default: break;
+            }
+            if (st1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += q1[r];
+            }
+            if (st2) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += q2[r];
+            }
+            if (ook[n]) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int cc = m * 16 + krow + r;
+                if (fullc || cc < cvalid_p) (outp + (size_t)cc * Lv)[ox] = v[r];
+              }
+            }
+            acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);  // one (tile, group) at a time: 128 registers
+          }
+        }
+      } else {
       if (any_op) { PG_P_REQUEST(0, 0) }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -920,11 +1023,12 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
           }
         }
       }
-#undef PG_P_REQUEST
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#undef PG_P_REQUEST
     }
     PG_PROF_MARK(4)
     if (more) __syncthreads();  // the other buffers are committed; every wave is done with the current ones
@@ -1196,11 +1300,9 @@ void b3p_launch(const B3Args& a, int nt, int waves, dim3 grid, size_t shmem, hip
     (void)attr_##NTV##_##WVV;                                                                         \
     hipLaunchKernelGGL((conv_b3p_kernel<GL, NTV, WVV>), grid, dim3(64 * WVV), shmem, st, a);          \
   }
-  if constexpr (!GL) {  // (the GELU-carrying instantiations do not fit 128 registers: 4 waves only)
-    if (waves == 8) {
-      if (nt == 1) PG_B3P_L(1, 8) else PG_B3P_L(2, 8)
-      return;
-    }
+  if (waves == 8) {
+    if (nt == 1) PG_B3P_L(1, 8) else PG_B3P_L(2, 8)
+    return;
   }
   switch (nt) {
     case 1: PG_B3P_L(1, 4) break;

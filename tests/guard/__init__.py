@@ -48,6 +48,27 @@ def install():
     _lib = ctypes.CDLL(SO)
     _lib.pg_guard_report.restype = ctypes.c_char_p
     _lib.pg_guard_live.restype = ctypes.c_long
+    # tell the allocator when a hipGraph capture is in progress (it must then neither allocate, synchronise nor free):
+    # every capture of this code base goes through torch.cuda.graph
+    lib = _lib
+    enter, leave = torch.cuda.graph.__enter__, torch.cuda.graph.__exit__
+
+    def _enter(self):
+        torch.cuda.synchronize()
+        lib.pg_guard_capture(1)
+        try:
+            return enter(self)
+        except BaseException:
+            lib.pg_guard_capture(0)
+            raise
+
+    def _exit(self, *exc):
+        try:
+            return leave(self, *exc)
+        finally:
+            lib.pg_guard_capture(0)
+
+    torch.cuda.graph.__enter__, torch.cuda.graph.__exit__ = _enter, _exit
     return _lib
 
 

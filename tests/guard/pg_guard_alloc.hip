@@ -114,7 +114,12 @@ void init_once(int device) {
           g_poison ? "poisoned with NaN bytes" : "left as allocated", arena_mb);
 }
 
+int g_capture_depth = 0;  // set from Python around every torch.cuda.graph(...) block (tests/guard/__init__.py): a free
+                          // arrives with the stream its block was ALLOCATED on, which says nothing about a capture
+                          // running on the current stream
+
 bool capturing(hipStream_t stream) {
+  if (g_capture_depth > 0) return true;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
     (void)hipGetLastError();
@@ -266,6 +271,11 @@ __attribute__((visibility("default"))) int pg_guard_check_all() {
   return g_violations;
 }
 
+__attribute__((visibility("default"))) void pg_guard_capture(int begin) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_capture_depth += begin ? 1 : -1;
+  if (g_capture_depth < 0) g_capture_depth = 0;
+}
 __attribute__((visibility("default"))) int pg_guard_violations() { return g_violations; }
 __attribute__((visibility("default"))) const char* pg_guard_report() { return g_report.c_str(); }
 __attribute__((visibility("default"))) long pg_guard_live() { return (long)g_live.size(); }

@@ -4,6 +4,7 @@
 //   mode 2: A = MFMA, B = VALU (the question) mode 3: both roles run MFMA + VALU interleaved in blocks (24 MFMA | 48 VALU)
 //   mode 4: as 3, role B rotated by half a period (starts with its VALU block)
 //   mode 5: as 2 with s_setprio 3 on role A   mode 6: as 3 with s_setprio 1 around the MFMA blocks
+//   mode 7: as 3, role B at s_setprio 1 throughout   mode 8: as 3, role B at s_setprio 3   mode 9: as 3, priority alternates per iteration
 // out[wave] = cycles (s_memtime) of that wave's loop. Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC.
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -38,6 +39,8 @@ __global__ void __launch_bounds__(512) coexec(long long* out, int iters, int mod
   const unsigned k = blockIdx.x + 1;
   if ((mode == 0 && !roleA) || (mode == 1 && roleA)) return;
   if (mode == 5 && roleA) __builtin_amdgcn_s_setprio(3);
+  if (mode == 7 && !roleA) __builtin_amdgcn_s_setprio(1);
+  if (mode == 8 && !roleA) __builtin_amdgcn_s_setprio(3);
   const long long t0 = clock64();
   if (mode <= 2 || mode == 5) {
     if (roleA) for (int it = 0; it < iters; ++it) mfma_block(acc, a, b);
@@ -45,6 +48,7 @@ __global__ void __launch_bounds__(512) coexec(long long* out, int iters, int mod
   } else {
     if (mode == 4 && !roleA) valu_block(x, k);
     for (int it = 0; it < iters; ++it) {
+      if (mode == 9) { if (((it & 1) != 0) == roleA) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
       if (mode == 6) __builtin_amdgcn_s_setprio(1);
       mfma_block(acc, a, b);
       if (mode == 6) __builtin_amdgcn_s_setprio(0);

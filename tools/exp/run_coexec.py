@@ -4,7 +4,7 @@ lib = ctypes.CDLL(os.path.join(here, "libcoexec.so"))
 lib.coexec_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 dev = torch.device("cuda:0")
 names = ["A=MFMA alone", "B=VALU alone", "A=MFMA | B=VALU", "both: 24 MFMA then 48 VALU", "same, role B rotated", "A=MFMA prio 3 | B=VALU",
-         "both, setprio around MFMA"]
+         "both, setprio around MFMA", "both, role B prio 1", "both, role B prio 3", "both, prio alternates per iteration"]
 iters = 4000
 st = torch.cuda.current_stream().cuda_stream
 for mode, name in enumerate(names):
