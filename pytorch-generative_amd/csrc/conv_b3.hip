@@ -305,7 +305,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     const int nt = p_waves == 8 ? (px + 127) / 128 : (px + 63) / 64;   // 16-pixel groups per wave
     size_t shmem = ((size_t)a.w_off16 + 2 * B3P_W4) * 16;
     a.ep_off = (int)(shmem / 4);
-    if (p_waves == 4) shmem += (size_t)4 * 16 * (nt * 16 + 4) * 4;  // per-wave transposition scratch (8 waves store directly)
+    shmem += (size_t)p_waves * 16 * (nt * 16 + 4) * 4;  // per-wave transposition scratch
     a.b_off = (int)(shmem / 4);
     shmem += (B3_CO_CHUNK + 8) * sizeof(float);
     PG_REQUIRE(shmem <= (size_t)80 * 1024, PG_ESHAPE, "pg_conv2d_mfma(bf16x3, pipelined): %zu B of LDS", shmem);

@@ -595,16 +595,15 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
     const int r = pc / a.OW;
     pixoff[n] = r * a.tile_w + (pc - r * a.OW);
   }
-  // 8 waves: the epilogue stores straight from the accumulator layout (lane = 4 channels x 1 pixel of each group)
-  unsigned opx[NT];
-  bool ook[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int p = (wave * NT + n) * 16 + (lane & 15);
-    ook[n] = p < npx;
-    const int pc = ook[n] ? p : 0;
+  // 8 waves: store phase of the epilogue, lane & 31 = pixel of the wave's (<= 32-pixel) tile
+  unsigned opx32;
+  bool sok32;
+  {
+    const int p = wave * (NT * 16) + (lane & 31);
+    sok32 = (lane & 31) < NT * 16 && p < npx;
+    const int pc = sok32 ? p : 0;
     const int r = pc / a.OW;
-    opx[n] = (unsigned)((row0 + r) * a.OW + (pc - r * a.OW));
+    opx32 = (unsigned)((row0 + r) * a.OW + (pc - r * a.OW));
   }
   const int pw = wave * (NT * 16) + lane;
   const bool sok = (lane < NT * 16) && pw < npx;
@@ -848,86 +847,104 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
     if (st2) o2[c] = (st2 + off_)[lane_px];                                                \
   }
       if constexpr (WV == 8) {
-        // direct: channel = 16 m + 4 kq + r, pixel = the lane's pixel of group n — a store instruction writes four
-        // 64-byte row segments; no LDS round trip, no waits, every lane busy (through the transposition scratch half
-        // of the lanes of a 32-pixel wave tile would idle: 983 of 5445 cycles per step, tools/exp/b3_phase_prof.py)
+        // 32-pixel wave tiles: transposed through the wave's scratch like the 1x1 kernel does it — lanes 0-31 take channels
+        // 0-7 of a 16-channel tile, lanes 32-63 channels 8-15, lane & 31 = pixel: every lane busy, a store covers two runs
+        // of 128 contiguous bytes. (Storing straight from the accumulator layout — four 64-byte row segments per
+        // instruction, no LDS round trip — measured SLOWER: 1499 against 983 cycles per step, tools/exp/b3_phase_prof.py.)
+        const int half = lane >> 5;
+        unsigned ox = opx32;   // opaque copies: the lane's row addresses are formed here, not kept across the step loop
+        int hrow = 8 * half;
+        asm volatile("" : "+v"(ox), "+v"(hrow));
+        float q0[4], q1[4], q2[4];
+#define PG_P_REQ8(M, H)                                                                    \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                          \
+    const int cc = (M) * 16 + hrow + (H) * 4 + c;                                          \
+    const size_t off_ = (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv;                  \
+    if (st0) q0[c] = (st0 + off_)[ox];                                                     \
+    if (st1) q1[c] = (st1 + off_)[ox];                                                     \
+    if (st2) q2[c] = (st2 + off_)[ox];                                                     \
+  }
+        if (any_op) { PG_P_REQ8(0, 0) }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + m * 16 + kq * 4);
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            float v[4], q0[4], q1[4], q2[4];
-            unsigned ox = opx[n];  // opaque: the lane's 64-bit row addresses are formed here, not kept across the step loop
-            asm volatile("" : "+v"(ox));
-            int krow = kq * 4;
-            asm volatile("" : "+v"(krow));
+          for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int cc = m * 16 + krow + r;
-              const size_t off_ = (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv;
-              if (st0) q0[r] = (st0 + off_)[ox];
-              if (st1) q1[r] = (st1 + off_)[ox];
-              if (st2) q2[r] = (st2 + off_)[ox];
+            for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[m][n][r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          float v[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = ep[(8 * half + c) * EPS + (lane & 31)] + bl[m * 16 + 8 * half + c];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          switch (a.out_act) { /* wave-uniform */
+            case PG_ACT_RELU:
+#pragma unroll
+              for (int c = 0; c < 8; ++c) v[c] = pg_apply_act(v[c], PG_ACT_RELU);
+              break;
+            case PG_ACT_ELU:
+#pragma unroll
+              for (int c = 0; c < 8; ++c) v[c] = pg_apply_act(v[c], PG_ACT_ELU);
+              break;
+            case PG_ACT_GELU:
+              if constexpr (GL) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = pg_apply_act(v[c], PG_ACT_GELU);
+              }
+              break;
+            default: break;
+          }
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            if (any_op) {
+              switch (dsel) {
+                case PG_ACT_RELU:
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) v[hh * 4 + c] *= pg_act_grad(q0[c], PG_ACT_RELU);
+                  break;
+                case PG_ACT_ELU:
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) v[hh * 4 + c] *= pg_act_grad(q0[c], PG_ACT_ELU);
+                  break;
+                case PG_ACT_GELU:
+                  if constexpr (GL) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[hh * 4 + c] *= pg_act_grad(q0[c], PG_ACT_GELU);
+                  }
+                  break;
+                case PG_ACT_ELU_OUT:
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) v[hh * 4 + c] *= pg_act_grad(q0[c], PG_ACT_ELU_OUT);
+                  break;
+                default: break;
+              }
+              if (st1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[hh * 4 + c] += q1[c];
+              }
+              if (st2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[hh * 4 + c] += q2[c];
+              }
+              // the next operands are requested BEFORE these stores (loads and stores retire in order)
+              __builtin_amdgcn_sched_barrier(0);
+              if (hh == 0) { PG_P_REQ8(m, 1) }
+              else if (m + 1 < MT) { PG_P_REQ8(m + 1, 0) }
+              __builtin_amdgcn_sched_barrier(0);
             }
+            if (sok32) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[m][n][r] + b4[r];
-            switch (a.out_act) { /* wave-uniform */
-              case PG_ACT_RELU:
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = pg_apply_act(v[r], PG_ACT_RELU);
-                break;
-              case PG_ACT_ELU:
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = pg_apply_act(v[r], PG_ACT_ELU);
-                break;
-              case PG_ACT_GELU:
-                if constexpr (GL) {
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) v[r] = pg_apply_act(v[r], PG_ACT_GELU);
-                }
-                break;
-              default: break;
-            }
-            switch (dsel) {
-              case PG_ACT_RELU:
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= pg_act_grad(q0[r], PG_ACT_RELU);
-                break;
-              case PG_ACT_ELU:
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= pg_act_grad(q0[r], PG_ACT_ELU);
-                break;
-              case PG_ACT_GELU:
-                if constexpr (GL) {
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) v[r] *= pg_act_grad(q0[r], PG_ACT_GELU);
-                }
-                break;
-              case PG_ACT_ELU_OUT:
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= pg_act_grad(q0[r], PG_ACT_ELU_OUT);
-                break;
-              default: break;
-            }
-            if (st1) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += q1[r];
-            }
-            if (st2) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += q2[r];
-            }
-            if (ook[n]) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int cc = m * 16 + krow + r;
-                if (fullc || cc < cvalid_p) (outp + (size_t)cc * Lv)[ox] = v[r];
+              for (int c = 0; c < 4; ++c) {
+                const int cc = m * 16 + hrow + hh * 4 + c;
+                if (fullc || cc < cvalid_p) (outp + (size_t)cc * Lv)[ox] = v[hh * 4 + c];
               }
             }
-            acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_sched_barrier(0);  // one (tile, group) at a time: 128 registers
           }
         }
+#undef PG_P_REQ8
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       } else {
       if (any_op) { PG_P_REQUEST(0, 0) }
 #pragma unroll

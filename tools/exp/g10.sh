@@ -1,0 +1,11 @@
+#!/bin/bash
+out=gpurun_out/g10; mkdir -p $out
+timeout 240 python tools/exp/b3_phase_prof.py 512 > $out/phase_w8.log 2>&1; echo "phase_w8 rc=$?" | tee -a $out/summary.txt
+timeout 300 python -X faulthandler -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -m gpu -q -x -p no:cacheprovider > $out/tests.log 2>&1; echo "tests rc=$?" | tee -a $out/summary.txt
+b() { tag=$1; shift; env "$@" timeout 200 python bench.py --model $M --batch $B --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$M $B $tag', round(d['value'],1), 'img/s', round(d['ms_per_step'],2), 'ms')" | tee -a $out/bench.txt; }
+M=pixel_snail; B=1024
+b w8 PG_X=1; b w4 PG_CONV_B3P_WAVES=4; b old PG_CONV_B3P=0
+B=128; b w8 PG_X=1; b old PG_CONV_B3P=0
+M=beta_vae; B=1024; b w8 PG_X=1; b old PG_CONV_B3P=0
+M=vd_vae; B=512; b w8 PG_X=1; b old PG_CONV_B3P=0
+head -9 $out/phase_w8.log; tail -3 $out/tests.log | cut -c1-200; cat $out/bench.txt
