@@ -108,7 +108,9 @@ B3Plan b3_plan(int Kc, int M, int T) {
   // of the pipelined kernel (conv_b3p_kernel: double-buffered 14.6 KB x tile + 12 KB weight slab). PG_CONV_B3P=0 keeps
   // the 16-channel chunks of conv_b3_kernel (A/B).
   static const bool p_on = []() { const char* e = getenv("PG_CONV_B3P"); return !(e && e[0] == '0'); }();
-  if (p_on && on && T == 4 && MT == 4 && Kc % 8 == 0 && Kc >= 16) {
+  // (one output chunk only: with 128+ output channels the wide conv_b3_kernel, whose two chunks share ONE staged x tile,
+  // measured faster — 247 against 282 us on the 2x2 64 -> 128 at N = 512 — while 64 -> 64 runs 119 -> 108 us here)
+  if (p_on && on && T == 4 && MT == 4 && M <= B3_CO_CHUNK && Kc % 8 == 0 && Kc >= 16) {
     B3Plan pp = {1, 8, 1, 4, 1, 4, (size_t)MT * 3 * 1024, 0};
     return pp;
   }
