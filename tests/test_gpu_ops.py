@@ -591,3 +591,82 @@ def test_fused_gpt_block_matches_operator_composition(dev, n, hw):
     _util.assert_close(xa.grad, xb.grad, TOL, "block dx")
     for k, p in blk.named_parameters():
         _util.assert_close(ga[k], p.grad, TOL, f"block grad {k}")
+
+
+PROTOCOL_SHAPES = [
+    # (name, N, C, H, W, Cmid, k): conv1 k x k C -> Cmid, conv2 1x1 Cmid -> C
+    ("b3_2x2_64", 3, 64, 16, 16, 64, 2),      # bf16x3: pipelined 4-tap kernel + barrier-free 1x1, multi-stream epilogues
+    ("b3_3x3_128", 2, 128, 16, 16, 64, 3),    # bf16x3 staged kernels (9 taps; 128 -> 64 and the 1x1 back to 128)
+    ("f32_3x3_24", 2, 24, 16, 16, 40, 3),     # channel counts not multiples of 8 in one direction: fp32-MFMA kernels
+    ("small_8x8", 4, 64, 8, 8, 32, 3),        # < 256 pixels per image: fp32-MFMA, add fallbacks
+    ("valu_3ch", 2, 3, 12, 12, 16, 3),        # 3 input channels: VALU tap kernels, no fused output activations
+]
+
+
+@pytest.mark.parametrize("shape", PROTOCOL_SHAPES, ids=lambda s: s[0])
+def test_conv_protocol_matrix(dev, shape):
+    """Every combination of the fusion protocols of nn.Conv2d.forward — in_act x (out_act, out_pre_scaled / in_post) x
+    n_skip x res — through a two-convolution chain  z = conv2(A(conv1(act(x))) [+ r1]) + skips  on each dispatch class,
+    against the same composition in torch on the CPU (output, dx, both weight and bias gradients). A combination the
+    shape's kernels cannot take must raise ValueError AT FORWARD TIME (the documented contract: out_pre_scaled / in_post
+    without the matrix-core path) — never return silently wrong gradients."""
+    import itertools
+
+    from pytorch_generative_amd import nn as pg_nn
+
+    name, n, c, h, w, cmid, k = shape
+    torch.manual_seed(0)
+    pad = 1
+    conv1 = pg_nn.Conv2d(c, cmid, k, padding=pad)
+    conv2 = pg_nn.Conv2d(cmid, c, 1)
+    x = _rand(n, c, h, w, seed=1)
+    g = _rand(n, c, h, w, seed=2)
+    r1 = _rand(n, cmid, h, w, seed=3)
+    acts = {None: lambda t: t, "relu": F.relu, "elu": F.elu}
+    conv1d, conv2d = conv1.to(dev), conv2.to(dev)
+    pair_ok = conv1d.mfma_ok(x.to(dev), (h, w)) and conv2d.mfma_ok(torch.empty(n, cmid, h, w, device=dev))
+    bad, refused, ran = [], 0, 0
+    for in_act, (out_act, paired), n_skip, use_r1 in itertools.product(
+            (None, "relu", "elu"), ((None, False), ("elu", False), ("elu", True)), (0, 1, 2), (False, True)):
+        combo = f"in_act={in_act} out_act={out_act} paired={paired} n_skip={n_skip} res={use_r1}"
+        # oracle
+        xo = x.clone().requires_grad_(True)
+        ws = [t.detach().cpu().clone().requires_grad_(True) for t in (conv1.weight, conv1.bias, conv2.weight, conv2.bias)]
+        yo = F.conv2d(acts[in_act](xo), ws[0], ws[1], padding=pad)[:, :, :h, :w]
+        if out_act:
+            yo = F.elu(yo)
+        if use_r1:
+            yo = yo + r1
+        zo = F.conv2d(yo, ws[2], ws[3]) + n_skip * xo
+        zo.backward(g)
+        # HIP path
+        for m in (conv1d, conv2d):
+            m.weight.grad = m.bias.grad = None
+        xg = x.to(dev).requires_grad_(True)
+        try:
+            out = conv1d(xg, crop=(h, w), in_act=in_act, out_act=out_act, out_pre_scaled=paired, n_skip=n_skip,
+                         res=r1.to(dev) if use_r1 else None)
+            y, aliases = (out[0], list(out[1:])) if n_skip else (out, [])
+            kw = {"in_post": "elu"} if paired else {}
+            if n_skip == 2:
+                z = conv2d(y, res=aliases[0], res2=aliases[1], **kw)
+            elif n_skip == 1:
+                z = conv2d(y, res=aliases[0], **kw)
+            else:
+                z = conv2d(y, **kw)
+        except ValueError as e:
+            if not (paired and not pair_ok):  # the one documented refusal: the paired activation without matrix-core kernels
+                bad.append(f"{combo}: unexpected ValueError: {e}")
+            refused += 1
+            continue
+        z.backward(g.to(dev))
+        ran += 1
+        for what, got, want in (("z", z, zo), ("dx", xg.grad, xo.grad), ("dw1", conv1d.weight.grad, ws[0].grad),
+                                ("db1", conv1d.bias.grad, ws[1].grad), ("dw2", conv2d.weight.grad, ws[2].grad),
+                                ("db2", conv2d.bias.grad, ws[3].grad)):
+            e = _util.rel_err(got, want)
+            if not e <= 2 * TOL:
+                bad.append(f"{combo}: {what} rel err {e:.2e}")
+    assert not bad, f"{name}: {len(bad)} protocol combinations wrong:\n" + "\n".join(bad[:20])
+    assert ran >= 36, f"{name}: only {ran} combinations ran ({refused} refused)"
+    assert pair_ok or refused == 18, f"{name}: {refused} refusals, expected the 18 paired-activation combinations"
