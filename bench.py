@@ -363,7 +363,7 @@ def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
     return {"launch_ms": ms, "flop_per_launch": flop, "tflops": flop / ms / 1e9}
 
 
-def measured_traffic(batch, kernel, files=("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):
+def measured_traffic(batch, kernel, files=("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):
     """HBM bytes per launch of the headline's dominant kernel from the committed PMC profiles
     (collected in separate rocprofv3 --pmc passes, see profiles/README.md); None when no committed
     profile holds this kernel at this batch."""
@@ -422,6 +422,17 @@ def _cpu_step_timer(forward, state0, x, lr, **fwd_kw):
     return timed
 
 
+def _ref_ratio(model):
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_cpu_reference_vs_oracle.json")) as f:
+            d = json.load(f)
+        m = d["models"][model]
+        return {"ratio": m["oracle_over_reference_step_time"], "threads": d["threads"], "batch": m["batch"],
+                "timed_steps": d["timed_steps"], "where": d["where"]}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(batch=32, point_cap_s=20.0):
     """The oracle's restatement of the same ImageGPT training step on the host cores (kind 'port':
     the reference is Python and cannot travel to the GPU box; the oracle dispatches the same torch
@@ -448,15 +459,18 @@ def cpu_baseline(batch=32, point_cap_s=20.0):
         if sweep[threads] > point_cap_s:
             break
     best = min(sweep, key=sweep.get)
-    dt, loss = timed(best, 3)
+    dt, loss = timed(best, 5)
     torch.set_num_threads(default_threads)
     return {
         "value": batch / dt, "unit": "images/s", "cores": best, "cores_logical": logical,
         "cores_physical": physical, "kind": "port", "torch": torch.__version__,
         "ms_per_step": dt * 1e3, "loss_after": loss,
         "thread_sweep_ms_per_step": {str(k): v * 1e3 for k, v in sweep.items()},
-        "sample": f"oracle train step (torch-CPU fp32, ImageGPT 8/4/16), batch {batch}, 3 timed steps after "
+        "sample": f"oracle train step (torch-CPU fp32, ImageGPT 8/4/16), batch {batch}, 5 timed steps after "
                   f"1 warm-up at {best} threads (best of a sweep over {sorted(sweep)} threads, 1 timed step each)",
+        # kind "port": how the oracle's step relates to the REAL reference trainer step, timed side by side in the build
+        # container (same model, batch, threads; tools/cpu_ref_vs_oracle.py -> profiles/r04_cpu_reference_vs_oracle.json)
+        "oracle_over_reference_step_time": _ref_ratio("image_gpt"),
     }
 
 
@@ -473,16 +487,38 @@ def cpu_baseline_pixel_snail(threads, batch=8):
     state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     x = synthetic_batch(batch, 0, w["chw"])
     default_threads = torch.get_num_threads()
-    dt, loss = _cpu_step_timer(omodels.pixel_snail, state0, x, w["lr"])(threads, 2)
+    dt, loss = _cpu_step_timer(omodels.pixel_snail, state0, x, w["lr"])(threads, 5)
     torch.set_num_threads(default_threads)
     return {"value": batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
             "ms_per_step": dt * 1e3, "loss_after": loss,
-            "sample": f"oracle train step (torch-CPU fp32, PixelSNAIL cfg3), batch {batch}, 2 timed steps after "
-                      f"1 warm-up at {threads} threads"}
+            "sample": f"oracle train step (torch-CPU fp32, PixelSNAIL cfg3), batch {batch}, 5 timed steps after "
+                      f"1 warm-up at {threads} threads",
+            "oracle_over_reference_step_time": _ref_ratio("pixel_snail")}
 
 
-# fp32-compute / HBM ceilings per GPU in images/s (BASELINE.md §3 = SURVEY.md §8(d)) for the compact records
+# fp32-compute / HBM ceilings per GPU in images/s (BASELINE.md §3 = SURVEY.md §8(d)) for the compact records:
+# frac_of_fp32_compute_ceiling = images_per_s / ceiling, ceiling = 157.3 TFLOP/s / (GFLOP per image of WORKLOADS[...])
 CEILINGS = {"pixel_cnn": 163e3, "gated_pixel_cnn": 7.4e3, "beta_vae": 100e3, "vd_vae": 14.3e3}
+# dominant kernel of each compact record and its share of the step's kernel time, from the tracked rocprofv3 tables
+# (profiles/r04_<model>_kernel_stats.csv, tools/collect_profiles_r04.sh); None = read the table
+DOMINANT = {}
+
+
+def _dominant_kernel(model):
+    """(name, share of kernel time, average microseconds) of the top kernel in profiles/r04_<model>_kernel_stats.csv."""
+    import csv
+
+    try:
+        with open(os.path.join(ROOT, "profiles", f"r04_{model}_kernel_stats.csv")) as f:
+            rows = list(csv.DictReader(f))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        name = top["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        name = name[:name.find("(")] if "(" in name else name
+        return {"kernel": name, "share_of_kernel_time": float(top["TotalDurationNs"]) / tot,
+                "avg_us": float(top["AverageNs"]) / 1e3, "source": f"profiles/r04_{model}_kernel_stats.csv"}
+    except (OSError, ValueError, KeyError):
+        return None
 OTHER_CONFIGS = [  # (record key, workload, per-GPU batch, BASELINE.json config)
     ("pixel_cnn", "pixel_cnn", 1024, "configs[0]"),
     ("gated_pixel_cnn", "gated_pixel_cnn", 512, "configs[2]"),
@@ -580,7 +616,8 @@ def main():
                            "per_gpu_batch": batch, "launch": r["launch"],
                            "frac_of_fp32_compute_ceiling": (r["images_per_s"] / env.world / CEILINGS[key]
                                                             if key in CEILINGS else None),
-                           "loss_nats_per_image": r["loss_nats_per_image"]}
+                           "loss_nats_per_image": r["loss_nats_per_image"],
+                           "dominant_kernel": _dominant_kernel(name)}
         extras["other_configs"] = others
 
     if env.rank == 0:
@@ -652,22 +689,24 @@ def main():
                 c = conv_kernel_roofline(args.snail_batch, env.device)
                 a = attention_kernel_roofline(args.snail_batch, env.device, 1, 4, 32, 32, True)
                 w = wgrad_kernel_roofline(args.snail_batch, env.device)
+                b3_ceiling = BF16_PEAK_TFLOPS / 6.0  # six bf16 MFMAs per fp32 product
+                snail_traffic = measured_traffic(args.snail_batch, "conv_b3p_kernel", ("r04_snail_conv_pmc.json",))
                 out["pixel_snail"]["roofline"] = {
                     "bound": "mfma",
-                    "kernel": "conv_b3_kernel<4, 4> (pg_conv2d_mfma: 2x2 64->64 convolution, ELU prologue; "
-                              "fp32 products as 6 bf16 MFMAs)",
-                    # algorithmic fp32 flops; `peak` stays the fp32 matrix-core peak (the arithmetic the
-                    # path computes in), the bf16x3 scheme's own ceiling is bf16 peak / 6
-                    "achieved": c["tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": c["tflops"] / FP32_PEAK_TFLOPS,
-                    "bf16x3_ceiling": BF16_PEAK_TFLOPS / 6.0,
-                    "frac_of_bf16x3_ceiling": c["tflops"] / (BF16_PEAK_TFLOPS / 6.0),
+                    "kernel": "conv_b3p_kernel<2, 8> (pg_conv2d_mfma: 2x2 64->64 convolution, ELU prologue; "
+                              "fp32 products as 6 bf16 MFMAs, 8 waves per workgroup)",
+                    # algorithmic fp32 flops against the scheme's OWN ceiling: bf16 dense peak / 6 (the fp32 matrix peak,
+                    # 157.3 TF, is not this kernel's ceiling: it does not run fp32 MFMAs)
+                    "achieved": c["tflops"], "peak": b3_ceiling, "unit": "TFLOP/s",
+                    "frac": c["tflops"] / b3_ceiling,
+                    "frac_of_fp32_matrix_peak": c["tflops"] / FP32_PEAK_TFLOPS,
                     "launch_ms": c["launch_ms"],
                     "flop_per_launch": c["flop_per_launch"],
-                    # per-launch HBM bytes of this kernel averaged over its launches INSIDE the model step
-                    # (profiles/r03_snail_traffic.json, batch 512: forward, data-gradient and 1x1 launches)
-                    "traffic": measured_traffic(512, "conv_b3_kernel<false, 4, 4, 1, false, false>", ("r03_snail_traffic.json",)),
-                    "traffic_profile_batch": 512,
+                    # HBM bytes of the SAME launch (shape and batch) from separate rocprofv3 --pmc passes
+                    # (profiles/r04_snail_conv_pmc.json: calibrated on an add kernel in the same process); algorithmic =
+                    # x read once + out written once
+                    "traffic": snail_traffic,
+                    "traffic_algorithmic": 2.0 * args.snail_batch * 64 * 32 * 32 * 4,
                     "other_kernels": {"conv_wgrad_b3_kernel<4> + wgrad_reduce_kernel": w,
                                       "attn_fwd_k4_kernel": a["fwd"], "attn_dq_k4_kernel": a["dq"],
                                       "attn_dkv_k4_kernel": a["dkv"]},

@@ -204,6 +204,13 @@ class _ConvTaps(torch.autograd.Function):
             if not (mfma == CONV_FMT_B3 and cout >= 64):
                 raise ValueError("conv2d: a second residual needs the bf16x3 kernel with >= 64 output channels "
                                  "(check ops.conv_two_residuals_ok first)")
+        if out_pre_scaled and res is not None:
+            # the consumer (in_post) recovers act' from THIS output: a residual added behind the activation would change
+            # the value it reads and with it every gradient upstream (found by tests/test_gpu_ops.py::test_conv_protocol_matrix)
+            raise ValueError("conv2d: out_pre_scaled cannot be combined with a residual (the consumer's in_post derivative "
+                             "is taken from this convolution's output)")
+        if out_pre_scaled and out_act == ACT_NONE:
+            raise ValueError("conv2d: out_pre_scaled without an output activation")
         if (out_act != ACT_NONE or in_post != ACT_NONE) and not mfma:
             raise ValueError("conv2d: fused output activations need the matrix-core path "
                              "(check ops.conv_mfma_ok first)")
