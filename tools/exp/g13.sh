@@ -1,8 +1,6 @@
 #!/bin/bash
 out=gpurun_out/g13; mkdir -p $out
-timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -q -k protocol_matrix -p no:cacheprovider > $out/proto.log 2>&1; echo "proto rc=$?" | tee -a $out/summary.txt
-/usr/bin/time -v -o $out/bench.time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench rc=$?" | tee -a $out/summary.txt
-tail -12 $out/proto.log | cut -c1-250; grep -E "Elapsed|Maximum resident" $out/bench.time; tail -3 $out/bench.err | cut -c1-300; python - <<PY
+SECONDS=0; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench rc=$?" | tee -a $out/summary.txt
 import json
 d=json.loads(open("$out/bench.json").read().strip().splitlines()[-1])
 print({k:d[k] for k in ("value","ms_per_step","n_gpus")})
