@@ -298,7 +298,7 @@ def attention_kernel_roofline(batch, device, heads, dk, dv, hw, strict):
     ms = {"fwd": _event_time(fwd, stream),
           "dq": _event_time(lambda: bwd(lib.pg_causal_attn_bwd_dq), stream),
           "dkv": _event_time(lambda: bwd(lib.pg_causal_attn_bwd_dkv), stream)}
-    if dk == 4 and dv == 4 and lib.pg_attn_fused_bwd(-1) == 1:  # one fused launch (attn_bwd_m44_kernel)
+    if dk == 4 and dv in (4, 16, 32) and lib.pg_attn_fused_bwd(-1) == 1:  # one fused launch (attn_bwd_m44 / attn_bwd_k4)
         ms["bwd"] = _event_time(lambda: bwd(lib.pg_causal_attn_bwd), stream)
     pairs = batch * heads * (L * (L - 1) / 2 if strict else L * (L + 1) / 2)
     per = _attn_flops_per_pair(dk, dv)
@@ -708,8 +708,10 @@ def main():
                     "traffic": snail_traffic,
                     "traffic_algorithmic": 2.0 * args.snail_batch * 64 * 32 * 32 * 4,
                     "other_kernels": {"conv_wgrad_b3_kernel<4> + wgrad_reduce_kernel": w,
-                                      "attn_fwd_k4_kernel": a["fwd"], "attn_dq_k4_kernel": a["dq"],
-                                      "attn_dkv_k4_kernel": a["dkv"]},
+                                      "attn_fwd_k4_kernel": a["fwd"],
+                                      "attn_delta_k4 + attn_bwd_k4_kernel (fused backward)": a.get("bwd"),
+                                      "two_kernel_backward (PG_ATTN_FUSED_BWD_K4=0)": {"attn_dq_k4_kernel": a["dq"],
+                                                                                     "attn_dkv_k4_kernel": a["dkv"]}},
                 }
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()

@@ -506,6 +506,180 @@ __global__ void __launch_bounds__(64) attn_dkv_k4_kernel(const PgAttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ fused backward (d_k = 4)
+// dQ, dK, dV in ONE pass (round 4): the two-kernel backward evaluates the score tile, exp2 and dP = dO V^T twice
+// (dq kernel: 4 d_k + 2 d_v, dkv kernel: 4 d_k + 4 d_v FLOP per pair; fused: 6 d_k + 4 d_v, every product once —
+// 152 against 224 FLOP per pair at d_v = 32). Key-owner orientation as attn_dkv_k4_kernel (a wave owns a block of
+// keys, the queries stream; dV / dK accumulate in registers). dQ contracts over KEYS, which sit on the lane axis of
+// the score tile S[query 4g + r][key j]: each 16 x 16 dS tile is transposed through a 1.25 KB per-wave LDS scratch
+// (one ds_write_b128 + four ds_read_b32; rows of 20 floats: conflict free both ways), multiplied by K^T float4s on
+// the VALU (d_k = 4: an MFMA tile would be 75 % padding), summed over the block's key groups in registers and over
+// the four lane groups by two shuffles, and deposited with ONE fp32 atomic per lane and query tile into dq (zeroed
+// by the launcher). delta = sum_dv dO * O comes from a small pre-pass (attn_delta_k4_kernel). dQ's summation order
+// over key blocks depends on the schedule: pg_attn_fused_bwd(0) / ops.set_deterministic(True) keep the two-kernel
+// backward for bit-reproducible gradients, as for d_k = d_v = 4.
+template <int DVT>
+__global__ void __launch_bounds__(256) attn_delta_k4_kernel(const PgAttnArgs a) {
+  const int unit = blockIdx.y, n = unit / a.heads, h = unit - n * a.heads;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.L) return;
+  constexpr int DV = 16 * DVT;
+  const float* op = a.o + (size_t)n * a.o_bs + (size_t)h * DV * a.L + q;
+  const float* dop = a.d_o + (size_t)n * a.do_bs + (size_t)h * DV * a.L + q;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < DV; ++c) acc = fmaf(dop[(size_t)c * a.L], op[(size_t)c * a.L], acc);
+  a.delta[((size_t)n * a.heads + h) * a.L + q] = acc;
+}
+
+template <int DVT, int QB>
+__global__ void __launch_bounds__(64) attn_bwd_k4_kernel(const PgAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float scr[16 * 20];
+  const int L = a.L, NB = (L + 16 * QB - 1) / (16 * QB);
+  const K4Map mp = k4_map(a.N * a.heads, NB);
+  if (mp.unit < 0) return;
+  const int n = mp.unit / a.heads, h = mp.unit - n * a.heads;
+  const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
+  constexpr int DV = 16 * DVT, NS = 4 * DVT;
+  const float* qp = a.q + (size_t)n * a.q_bs + (size_t)h * 4 * L;
+  const float* kp = a.k + (size_t)n * a.k_bs + (size_t)h * 4 * L;
+  const float* vp = a.v + (size_t)n * a.v_bs + (size_t)h * DV * L;
+  const float* dop = a.d_o + (size_t)n * a.do_bs + (size_t)h * DV * L;
+  const float* lp = a.lse2_in + ((size_t)n * a.heads + h) * L;
+  const float* dlt = a.delta + ((size_t)n * a.heads + h) * L;
+  float* dqp = a.dq + (size_t)n * a.dq_bs + (size_t)h * 4 * L;
+  float* dkp = a.dk + (size_t)n * a.dk_bs + (size_t)h * 4 * L;
+  float* dvp = a.dv + (size_t)n * a.dv_bs + (size_t)h * DV * L;
+  const int strict = a.strict;
+  const int nqt = L >> 4;
+  float* scr_w = scr + j * 20 + 4 * g;   // this lane's dS values: row = its key, columns = its four queries
+  const float* scr_r = scr + 4 * g * 20 + j;  // transposed: rows = keys 4g .. 4g+3, column = query j
+
+  for (int pass = 0; pass < 2; ++pass) {
+    const int bb = pass == 0 ? mp.b0 : mp.b1;
+    if (bb < 0) break;
+    const int k0 = (NB - 1 - bb) * (16 * QB);
+    float kfb[QB], vfb[QB][NS];
+    float4 kr[QB][4];     // K^T row d at keys 4g .. 4g+3 of the group (unscaled: dQ is scaled once at the end)
+    f32x4 dV[QB][DVT];
+    float dk[QB][4];
+#pragma unroll
+    for (int kg = 0; kg < QB; ++kg) {
+      const int ki = min(k0 + 16 * kg + j, L - 1);
+      kfb[kg] = kp[(size_t)g * L + ki] * a.scale2;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) vfb[kg][s] = vp[(size_t)(4 * s + g) * L + ki];
+      const int kq = min(k0 + 16 * kg + 4 * g, L - 4);  // (L % 16 == 0: a group beyond L is skipped below)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) kr[kg][d] = *reinterpret_cast<const float4*>(kp + (size_t)d * L + kq);
+#pragma unroll
+      for (int t = 0; t < DVT; ++t) dV[kg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dk[kg][d] = 0.f;
+    }
+    const int qt0 = (k0 + strict) >> 4;  // first query tile that sees a key of this block
+
+#define K4B_LOAD(QQ, QFA, DOFA, DOFT, QR, NL, ND)                                                   \
+  {                                                                                                 \
+    QFA = qp[(size_t)g * L + (QQ) + j];                                                             \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) DOFA[s] = dop[(size_t)(4 * s + g) * L + (QQ) + j]; \
+    _Pragma("unroll") for (int t = 0; t < DVT; ++t)                                                 \
+        DOFT[t] = *reinterpret_cast<const float4*>(dop + (size_t)(16 * t + j) * L + (QQ) + 4 * g);   \
+    _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                   \
+        QR[d] = *reinterpret_cast<const float4*>(qp + (size_t)d * L + (QQ) + 4 * g);                 \
+    NL = *reinterpret_cast<const float4*>(lp + (QQ) + 4 * g);                                        \
+    ND = *reinterpret_cast<const float4*>(dlt + (QQ) + 4 * g);                                       \
+  }
+    float qfa, dofa[NS];
+    float4 doft[DVT], qr[4], nl4, nd4;
+    K4B_LOAD(min(qt0, nqt - 1) << 4, qfa, dofa, doft, qr, nl4, nd4)
+    for (int qt = qt0; qt < nqt; ++qt) {
+      const int qq0 = qt << 4;
+      const int qn = (qt + 1 < nqt) ? qq0 + 16 : qq0;
+      float qfa_n, dofa_n[NS];
+      float4 doft_n[DVT], qr_n[4], nl4_n, nd4_n;
+      K4B_LOAD(qn, qfa_n, dofa_n, doft_n, qr_n, nl4_n, nd4_n)
+      float dqa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kg = 0; kg < QB; ++kg) {
+        const int kk0 = k0 + 16 * kg;
+        if (kk0 + strict > qq0 + 15 || kk0 >= L) continue;  // no query of the tile sees a key of this group
+        f32x4 s4 = f32x4{-nl4.x, -nl4.y, -nl4.z, -nl4.w};
+        s4 = MFMA4(qfa, kfb[kg], s4);  // S[query 4g + r][key j] - lse2[query]
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s4[r]);
+        if (kk0 + 15 + strict > qq0) {  // diagonal tile
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kk0 + j + strict > qq0 + 4 * g + r) p[r] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) {  // dV^T[dv][key] += dO^T[dv][query] P[query][key]
+          dV[kg][t] = MFMA4(doft[t].x, p[0], dV[kg][t]);
+          dV[kg][t] = MFMA4(doft[t].y, p[1], dV[kg][t]);
+          dV[kg][t] = MFMA4(doft[t].z, p[2], dV[kg][t]);
+          dV[kg][t] = MFMA4(doft[t].w, p[3], dV[kg][t]);
+        }
+        f32x4 dp = f32x4{-nd4.x, -nd4.y, -nd4.z, -nd4.w};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) dp = MFMA4(dofa[s], vfb[kg][s], dp);
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = p[r] * dp[r];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)  // dK[key j][d] += dS^T Q: contraction over the tile's queries = this lane's registers
+          dk[kg][d] += (ds[0] * qr[d].x + ds[1] * qr[d].y) + (ds[2] * qr[d].z + ds[3] * qr[d].w);
+        // dQ[query][d] += dS K: transpose the tile (a wave's LDS operations execute in order: no barrier needed)
+        *reinterpret_cast<f32x4*>(scr_w) = ds;
+        asm volatile("" ::: "memory");
+        float tr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tr[r] = scr_r[r * 20];  // dS[query j][key 4g + r]
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          dqa[d] += (tr[0] * kr[kg][d].x + tr[1] * kr[kg][d].y) + (tr[2] * kr[kg][d].z + tr[3] * kr[kg][d].w);
+      }
+      {  // sum the four key quads of every query (lane groups), lane (g, j) deposits channel g of query qq0 + j
+        float mine = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float t = xor_sum(dqa[d]);
+          if (d == g) mine = t;
+        }
+        if (qq0 + j < L) atomicAdd(dqp + (size_t)g * L + qq0 + j, mine * a.scale);
+      }
+      qfa = qfa_n; nl4 = nl4_n; nd4 = nd4_n;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) dofa[s] = dofa_n[s];
+#pragma unroll
+      for (int t = 0; t < DVT; ++t) doft[t] = doft_n[t];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) qr[d] = qr_n[d];
+    }
+#undef K4B_LOAD
+#pragma unroll
+    for (int kg = 0; kg < QB; ++kg) {
+      if (k0 + 16 * kg >= L) continue;
+      const int ki = k0 + 16 * kg + j;
+      {
+        float mine = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float t = xor_sum(dk[kg][d]);
+          if (d == g) mine = t;
+        }
+        dkp[(size_t)g * L + ki] = mine * a.scale;
+      }
+#pragma unroll
+      for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dvp[(size_t)(16 * t + 4 * g + r) * L + ki] = dV[kg][t][r];
+    }
+  }
+}
+
 template <int DKT, int DVT, int QB>
 void k4_launch(int which, const PgAttnArgs& a, dim3 grid, hipStream_t st) {
   if (which == PG_ATTN_FWD)
@@ -529,7 +703,8 @@ int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st) {
   const bool small_k = dk == 4 && dv_ok;
   const bool big_k = (dk == 16 || dk == 32 || dk == 64) && dv_ok;
   if (!(small_k || big_k) || (a.L % 16) != 0 || a.L < 16) return 0;
-  if (which > PG_ATTN_DKV) return 0;
+  if (which == PG_ATTN_BWD && !(small_k && dv <= 32)) return 0;  // the fused backward exists for d_k = 4, d_v = 16 / 32
+  if (which > PG_ATTN_BWD) return 0;
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) % 4 != 0) return 0;
   if (!al16(a.k) || !al16(a.v) || !al16(a.q)) return 0;
   if (which != PG_ATTN_FWD) {
@@ -537,6 +712,23 @@ int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st) {
     if (!al16(a.d_o) || !al16(a.lse2_in) || !al16(a.delta)) return 0;
   }
   const int units = a.N * a.heads;
+  if (which == PG_ATTN_BWD) {
+    // delta pre-pass, dq zeroed (the kernel deposits with atomics), then the fused kernel on 32-key blocks
+    if ((a.dq_bs % 4) != 0 || (reinterpret_cast<uintptr_t>(a.dq) & 15) != 0) return 0;
+    const dim3 dgrid((unsigned)((a.L + 255) / 256), (unsigned)units);
+    if (dv == 32) hipLaunchKernelGGL((attn_delta_k4_kernel<2>), dgrid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_delta_k4_kernel<1>), dgrid, dim3(256), 0, st, a);
+    const size_t row_bytes = (size_t)a.heads * 4 * a.L * sizeof(float);
+    if ((size_t)a.dq_bs * sizeof(float) == row_bytes) (void)hipMemsetAsync(a.dq, 0, row_bytes * a.N, st);
+    else (void)hipMemset2DAsync(a.dq, (size_t)a.dq_bs * sizeof(float), 0, row_bytes, (size_t)a.N, st);
+    constexpr int FQB = 2;
+    const int NBf = (a.L + 16 * FQB - 1) / (16 * FQB);
+    const int npf = (NBf + 1) / 2;
+    const dim3 fgrid((unsigned)(((units + 63) / 64) * 64 * npf));
+    if (dv == 32) hipLaunchKernelGGL((attn_bwd_k4_kernel<2, FQB>), fgrid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_k4_kernel<1, FQB>), fgrid, dim3(64), 0, st, a);
+    return 1;
+  }
   // A lone wave keeps its SIMD's matrix pipe ~50 % busy (score -> exp -> P.V is one dependent chain
   // per 16-query group), so below ~3 waves per SIMD the blocks are halved to 32 rows: twice the
   // waves, each half as long (measured at batch 128: 1 wave per SIMD ran 2x over the MFMA bound).

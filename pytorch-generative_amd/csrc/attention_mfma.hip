@@ -1023,7 +1023,12 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   if (which == PG_ATTN_BWD) {
     // fused backward: d_k = d_v = 4 only; PG_ATTN_FUSED_BWD=0 keeps the two-kernel backward (A/B, and
     // bit-reproducible dQ: the fused kernel sums dQ over key blocks with fp32 LDS atomics)
-    if (!pg_attn_fused_bwd_enabled() || a0.dk_dim != 4 || a0.dv_dim != 4) return 0;
+    if (!pg_attn_fused_bwd_enabled()) return 0;
+    if (a0.dk_dim != 4 || a0.dv_dim != 4) {
+      // d_k = 4, d_v = 16 / 32 (PixelSNAIL): attn_bwd_k4_kernel (round 4); PG_ATTN_FUSED_BWD_K4=0 for A/B
+      static const bool k4_fused = []() { const char* e = getenv("PG_ATTN_FUSED_BWD_K4"); return !(e && e[0] == '0'); }();
+      return k4_fused ? pg_attn_k4_launch(which, a0, st) : 0;
+    }
   }
   // everything but d_k = d_v = 4: attention_k4.hip decides (d_k in {4, 16, 32, 64} x d_v in {16, 32, 64}, L % 16 == 0)
   if (a0.dk_dim != 4 || a0.dv_dim != 4) return pg_attn_k4_launch(which, a0, st);

@@ -326,6 +326,35 @@ def test_attention_m44_backward_paths(dev, case, fused):
     _util.assert_close(kvg.grad[:, e:], kvo.grad[:, e:], TOL, "attn dv")
 
 
+@pytest.mark.parametrize("case", [(2, 1, 4, 32, 32, 32, True), (3, 2, 4, 16, 16, 16, False), (1, 1, 4, 32, 20, 20, True),
+                                  (70, 1, 4, 32, 16, 16, True)],
+                         ids=lambda c: "-".join(str(int(v)) for v in c))
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_bwd", "two_kernel_bwd"])
+def test_attention_k4_backward_paths(dev, case, fused):
+    """d_k = 4, d_v = 16 / 32 (PixelSNAIL): the fused backward (attn_delta_k4_kernel + attn_bwd_k4_kernel: dQ through a
+    transposed dS tile and fp32 atomics, dK / dV in registers; round 4) and the two-kernel backward against the oracle
+    — L = 400 ends in a ragged 32-key block, 70 units span two groups of 64."""
+    from pytorch_generative_amd import ops
+
+    n, heads, dk, dv, h, w, strict = case
+    e, v = heads * dk, heads * dv
+    q = _rand(n, e, h, w, seed=1)
+    kv = _rand(n, e + v, h, w, seed=2)
+    d_o = _rand(n, v, h, w, seed=3)
+    qo, kvo = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    oops.causal_attention_core(qo, kvo[:, :e], kvo[:, e:], heads, strict).backward(d_o)
+    was = ops.set_deterministic(not fused)
+    try:
+        qg, kvg = q.to(dev).requires_grad_(True), kv.to(dev).requires_grad_(True)
+        ops.causal_attention(qg, kvg, heads, e, v, strict).backward(d_o.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_deterministic(was)
+    _util.assert_close(qg.grad, qo.grad, TOL, "attn dq")
+    _util.assert_close(kvg.grad[:, :e], kvo.grad[:, :e], TOL, "attn dk")
+    _util.assert_close(kvg.grad[:, e:], kvo.grad[:, e:], TOL, "attn dv")
+
+
 def test_attention_large_scores_stay_finite(dev):
     """Online-softmax rescale branch: a spike late in the key sequence forces the running max to
     jump; compare with the oracle on the same data."""
