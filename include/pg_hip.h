@@ -176,6 +176,12 @@ int pg_nchw_layernorm_bwd_res(const float* x, const float* gamma, const float* m
  * [h*d,(h+1)*d) (attention.py:134). *_bs = batch stride in floats (k and v are views into
  * the _kv conv output, attention.py:144). lse2: (N, heads, L) log2-domain logsumexp saved for
  * backward. A row with no allowed key (l=0, strict) yields zeros (attention.py:153-157).
+ * Instantiated head dims (PG_ESHAPE otherwise): dk = dv = 4 and every (dk <= 4, dv <= 32) / (dk <= 16, dv <= 16) at
+ * any L; dk in {4, 16, 32, 64} x dv in {16, 32, 64} for L % 16 == 0 with 16-byte aligned planes. The reference's
+ * CausalAttention accepts any embed / head split: the Python host (ops.causal_attention) zero-pads other head dims
+ * and sequence lengths to the next instantiated size — exact, see its docstring.
+ * pg_causal_attn_bwd: dk = 4 with dv in {4, 16, 32} runs ONE fused kernel whose dq is summed with fp32 atomics
+ * (run-to-run last-bit differences); pg_attn_fused_bwd(0) selects the bit-reproducible two-kernel backward.
  * ------------------------------------------------------------------------------------- */
 int pg_causal_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse2,
                        int N, int heads, int L, int dk, int dv, long q_bs, long k_bs, long v_bs,

@@ -1011,9 +1011,10 @@ def merge_qkv_weight(q_conv, kv_conv):
 
 
 def set_deterministic(on=True):
-    """Bit-reproducible gradients (on) or the fastest kernels (off, the default). The only kernel whose
-    result depends on timing is the fused attention backward for d_k = d_v = 4 (dQ is summed over key
-    blocks in arrival order: last-bit differences run to run); `on` selects the two-kernel backward.
+    """Bit-reproducible gradients (on) or the fastest kernels (off, the default). The only kernels whose
+    result depends on timing are the fused attention backwards for d_k = 4 (d_v = 4: ImageGPT; d_v = 16 / 32:
+    PixelSNAIL, round 4) — dQ is summed over key blocks in arrival order: last-bit differences run to run;
+    `on` selects the two-kernel backward.
     Returns the previous setting."""
     prev = _lib.load().pg_attn_fused_bwd(0 if on else 1)
     return prev == 0
