@@ -202,3 +202,47 @@ def test_committed_bench_line_keeps_the_driver_contract():
     assert c["kind"] in ("port", "reference") and c["value"] > 0
     ps = d["pixel_snail"]
     assert ps["images_per_s"] > 0 and "roofline" in ps and "reference_default_batch_128" in ps
+
+
+def test_no_kernel_spills_or_scratch():
+    """Every kernel of the built library: no spilled vector register, no scratch memory (tools/kernel_resources.py reads
+    the code objects' metadata; build.py enforces the same at link time). Skipped when the objects are not there."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir(os.path.join(root, "pytorch-generative_amd", "build")):
+        pytest.skip("no object files (run __graft_entry__.build())")
+    spec = importlib.util.spec_from_file_location("kr", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = kr.table()
+    assert len(rows) > 300
+    bad = [r for r in rows if r["vgpr_spill"] or r["scratch_B"]]
+    assert not bad, kr.render(bad)
+
+
+def test_guard_allocator_library_exports():
+    """tests/guard/libpg_guard.so (the canary allocator of `PG_GUARD=1 pytest -m gpu`) builds and exports the entry
+    points torch's pluggable-allocator hook and the conftest fixture bind."""
+    import ctypes
+
+    import guard
+
+    so = guard.build()
+    lib = ctypes.CDLL(so)
+    for name in ("pg_guard_malloc", "pg_guard_free", "pg_guard_check_all", "pg_guard_violations", "pg_guard_report",
+                 "pg_guard_live", "pg_guard_capture"):
+        assert hasattr(lib, name), name
+
+
+def test_attention_dims_native_matches_the_kernels_table():
+    """ops.attention_dims_native mirrors the instantiation rules of csrc/attention*.hip (include/pg_hip.h)."""
+    from pytorch_generative_amd import ops
+
+    assert ops.attention_dims_native(4, 4, 49) and ops.attention_dims_native(2, 2, 49)          # VALU / m44, any L
+    assert ops.attention_dims_native(4, 32, 1024) and ops.attention_dims_native(16, 16, 50)
+    assert ops.attention_dims_native(32, 32, 784) and ops.attention_dims_native(64, 64, 64)     # matrix-core k4
+    assert not ops.attention_dims_native(64, 64, 49)      # L % 16 != 0 -> padded by ops.causal_attention
+    assert not ops.attention_dims_native(24, 40, 48) and not ops.attention_dims_native(8, 20, 256)
+    assert not ops.attention_dims_native(16, 32, 49)
