@@ -114,26 +114,34 @@ __device__ __forceinline__ u32x4 shift_left1(const u32x4 d, unsigned int next) {
 // MR = MFMA row tiles (16 dy channels) per wave: 2 -> a workgroup owns 64 co (the shape the kernel was built for),
 // 1 -> 32 co (round 3: the 32-channel 3x3 convolutions of PixelCNN / VD-VAE / beta-VAE, which otherwise stay on
 // the fp32 kernel; half the MFMA work per staged x tile)
-template <int T, int MR = 2>
-__global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbArgs a) {
+// WV = waves per workgroup (round 4). 4: a wave owns MR row tiles x one ci tile, two waves per SIMD. 8 (64 dy channels
+// only): a wave owns ONE row tile x one ci tile — half the accumulators, two staging slots per thread instead of three,
+// <= 128 registers: FOUR waves per SIMD (the measurement behind it: conv_b3p_kernel, profiles/README.md round 4 items 5-6 —
+// a wave is serial, so two waves per SIMD leave the matrix pipe idle whenever both stage, wait or store).
+template <int T, int MR = 2, int WV = 4>
+__global__ void __launch_bounds__(64 * WV, WV / 2) conv_wgrad_b3_kernel(const WbArgs a) {
+  static_assert(WV == 4 || (WV == 8 && MR == 2), "8 waves: 64 dy channels per workgroup");
+  constexpr int THREADS = 64 * WV;
+  constexpr int NDS = WV == 4 ? WB_DS : 2, NXS = WV == 4 ? WB_XS : 2;  // staging slots per thread
+  constexpr int MRW = WV == 4 ? MR : 1;                                // row tiles per wave
   constexpr int COT = 2 * MR;  // dy channel tiles per workgroup
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 1, wi = wave >> 1;   // co half (2 row tiles), ci tile of this wave
+  const int wc = WV == 4 ? (wave & 1) : (wave & 3), wi = WV == 4 ? (wave >> 1) : (wave >> 2);  // row-tile group, ci tile of this wave
   const int co0 = blockIdx.y * (16 * COT), ci0 = blockIdx.z * WB_CI;
   const int dplane = COT * a.dpb * 16;       // entries per dy piece plane
   const int xplane = 2 * a.xpb * 16;         // entries per x (copy, piece) plane
 
   // ---- staging slots: the same (channel, tile row, column block) for every tile
-  int d_goff[WB_DS], d_meta[WB_DS], x_goff[WB_XS], x_meta[WB_XS];  // meta: LDS entry | tile row << 20
+  int d_goff[NDS], d_meta[NDS], x_goff[NXS], x_meta[NXS];  // meta: LDS entry | tile row << 20
   int x_edge = 0;  // bit k: slot k is the first column block of its row; bit 8 + k: the last
   int d_half = 0, x_half = 0;  // bit k: slot k is a half pixel block (W % 8 == 4: the last block of a row)
   const bool wpart = (a.W & 7) != 0;
 #pragma unroll
-  for (int k = 0; k < WB_DS; ++k) {
-    int e = tid + k * WB_THREADS;
+  for (int k = 0; k < NDS; ++k) {
+    int e = tid + k * THREADS;
     const bool in = e < a.dslots;
     e = in ? e : 0;
     const int i = e & 15; e >>= 4;
@@ -145,8 +153,8 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     if (wpart && cb == a.PBR - 1) d_half |= 1 << k;
   }
 #pragma unroll
-  for (int k = 0; k < WB_XS; ++k) {
-    int e = tid + k * WB_THREADS;
+  for (int k = 0; k < NXS; ++k) {
+    int e = tid + k * THREADS;
     const bool in = e < a.xslots;
     e = in ? e : 0;
     const int i = e & 15; e >>= 4;
@@ -165,12 +173,12 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     want_p1 |= a.dcs[v] == 1;
   }
 
-  float4 dv[WB_DS][2], xv[WB_XS][2];
-  float xe[WB_XS][2];  // the pixel left / right of the slot's 8
+  float4 dv[NDS][2], xv[NXS][2];
+  float xe[NXS][2];  // the pixel left / right of the slot's 8
 #pragma unroll
-  for (int k = 0; k < WB_DS; ++k) dv[k][0] = dv[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < NDS; ++k) dv[k][0] = dv[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int k = 0; k < WB_XS; ++k) {
+  for (int k = 0; k < NXS; ++k) {
     xv[k][0] = xv[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
     xe[k][0] = xe[k][1] = 0.f;
   }
@@ -183,30 +191,36 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     const float* dyb_ = a.dy + (((long)n_ * a.Cout + co0) * a.H + row0_) * (long)a.W;              \
     const float* xb_ = a.x + (((long)n_ * a.Cin + ci0) * a.H + (row0_ + a.min_dr)) * (long)a.W;    \
     dok = 0; xok = 0;                                                                              \
-    _Pragma("unroll") for (int k = 0; k < WB_DS; ++k) {                                            \
+    _Pragma("unroll") for (int k = 0; k < NDS; ++k) {                                            \
       if (d_goff[k] >= 0 && row0_ + (d_meta[k] >> 20) < a.H) {                                     \
-        const float4* p_ = reinterpret_cast<const float4*>(dyb_ + d_goff[k]);                      \
+        int go_ = d_goff[k];  /* opaque: the 64-bit lane address is formed here, not kept across the tile loop */ \
+        asm volatile("" : "+v"(go_));                                                              \
+        const float4* p_ = reinterpret_cast<const float4*>(dyb_ + go_);                            \
         dv[k][0] = p_[0]; dv[k][1] = p_[((d_half >> k) & 1) ? 0 : 1];  /* a half block stays inside its row */ \
         dok |= 1 << k;                                                                             \
       }                                                                                            \
     }                                                                                              \
-    _Pragma("unroll") for (int k = 0; k < WB_XS; ++k) {                                            \
+    _Pragma("unroll") for (int k = 0; k < NXS; ++k) {                                            \
       const int ir_ = row0_ + a.min_dr + (x_meta[k] >> 20);                                        \
       if (x_goff[k] >= 0 && ir_ >= 0 && ir_ < a.H) {                                               \
-        const float* q_ = xb_ + x_goff[k];                                                         \
+        int go_ = x_goff[k];                                                                       \
+        asm volatile("" : "+v"(go_));                                                              \
+        const float* q_ = xb_ + go_;                                                               \
         const float4* p_ = reinterpret_cast<const float4*>(q_);                                    \
         xv[k][0] = p_[0]; xv[k][1] = p_[((x_half >> k) & 1) ? 0 : 1];                              \
         /* edge slots load an in-image neighbour instead (zeroed at commit): no select on a   */   \
         /* loaded value here, it would put an s_waitcnt vmcnt into the issue phase             */   \
-        if (want_m1) xe[k][0] = q_[((x_edge >> k) & 1) ? 0 : -1];                                  \
-        if (want_p1) xe[k][1] = q_[((x_edge >> (8 + k)) & 1) ? 3 : 8];                             \
+        int eg_ = x_edge;  /* opaque (as go_): the neighbour offsets are formed here */            \
+        asm volatile("" : "+v"(eg_));                                                              \
+        if (want_m1) xe[k][0] = q_[((eg_ >> k) & 1) ? 0 : -1];                                     \
+        if (want_p1) xe[k][1] = q_[((eg_ >> (8 + k)) & 1) ? 3 : 8];                                \
         xok |= 1 << k;                                                                             \
       }                                                                                            \
     }                                                                                              \
   }
 
 #define PG_WB_COMMIT_X(ACT)                                                                        \
-  _Pragma("unroll") for (int k = 0; k < WB_XS; ++k) {                                              \
+  _Pragma("unroll") for (int k = 0; k < NXS; ++k) {                                              \
     if (x_goff[k] >= 0) {                                                                          \
       const bool ld_ = (xok >> k) & 1;                                                             \
       const float r_[8] = {xv[k][0].x, xv[k][0].y, xv[k][0].z, xv[k][0].w,                         \
@@ -236,10 +250,10 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     }                                                                                              \
   }
 
-  f32x4 acc[MR][T];
-  f32x4 accb[MR];
+  f32x4 acc[MRW][T];
+  f32x4 accb[MRW];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) {
+  for (int m = 0; m < MRW; ++m) {
     accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -250,7 +264,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
   for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
 
   const bf16x8* L = reinterpret_cast<const bf16x8*>(lds16) + lane;
-  const int a_base = MR * wc * a.dpb * 16;
+  const int a_base = MRW * wc * a.dpb * 16;
   int b_base[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) b_base[t] = a.x_off16 + a.tap_base[t] + wi * a.xpb * 16;
@@ -264,17 +278,17 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     // compiler's model and it puts a vmcnt(0) in front of every slot of the next issue phase
     // (measured: the load phase did not overlap the MFMA loop at all).
 #pragma unroll
-    for (int k = 0; k < WB_DS; ++k)
+    for (int k = 0; k < NDS; ++k)
       asm volatile("" :: "v"(dv[k][0].x), "v"(dv[k][0].y), "v"(dv[k][0].z), "v"(dv[k][0].w),
                          "v"(dv[k][1].x), "v"(dv[k][1].y), "v"(dv[k][1].z), "v"(dv[k][1].w));
 #pragma unroll
-    for (int k = 0; k < WB_XS; ++k)
+    for (int k = 0; k < NXS; ++k)
       asm volatile("" :: "v"(xv[k][0].x), "v"(xv[k][0].y), "v"(xv[k][0].z), "v"(xv[k][0].w),
                          "v"(xv[k][1].x), "v"(xv[k][1].y), "v"(xv[k][1].z), "v"(xv[k][1].w),
                          "v"(xe[k][0]), "v"(xe[k][1]));
     if (!PG_DBG_BIT(a.dbg, 2)) {
 #pragma unroll
-    for (int k = 0; k < WB_DS; ++k) {
+    for (int k = 0; k < NDS; ++k) {
       if (d_goff[k] >= 0) {
         const bool ld = (dok >> k) & 1;
         const float r[8] = {dv[k][0].x, dv[k][0].y, dv[k][0].z, dv[k][0].w,
@@ -302,14 +316,14 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
     if (!PG_DBG_BIT(a.dbg, 4))
     for (int ks = 0; ks < a.ksteps; ++ks) {
       const bf16x8* Lk = L + ks * 64;
-      bf16x8 af[MR][3];
+      bf16x8 af[MRW][3];
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
+      for (int m = 0; m < MRW; ++m)
 #pragma unroll
         for (int p = 0; p < 3; ++p) af[m][p] = Lk[a_base + (p * COT + m) * a.dpb * 16];
       if (bias_wave) {
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
+        for (int m = 0; m < MRW; ++m)
 #pragma unroll
           for (int p = 0; p < 3; ++p) accb[m] = MFMA16B(af[m][p], ones, accb[m]);
       }
@@ -319,7 +333,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[p] = Lk[b_base[t] + p * xplane];
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
+        for (int m = 0; m < MRW; ++m) {
           f32x4 c = acc[m][t];
           c = MFMA16B(af[m][2], bf[0], c);  // l.h
           c = MFMA16B(af[m][0], bf[2], c);  // h.l
@@ -339,8 +353,8 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3_kernel(const WbAr
   float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
   const int ci = ci0 + wi * 16 + (lane & 15);
 #pragma unroll
-  for (int m = 0; m < MR; ++m) {
-    const int co_b = co0 + (MR * wc + m) * 16 + (lane >> 4) * 4;
+  for (int m = 0; m < MRW; ++m) {
+    const int co_b = co0 + (MRW * wc + m) * 16 + (lane >> 4) * 4;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -638,13 +652,17 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   for (int v = a.ndc; v < 3; ++v) a.dcs[v] = 0;
   const int hr = max_dr - min_dr;
   const int PBR = (OW + 7) / 8;  // W % 8 == 4: the last pixel block of a row is half full
+  // 64 dy channels per workgroup: 8 waves (four per SIMD, 2 staging slots per thread); PG_WGRAD_B3_WAVES=4 for A/B
+  static const int env_waves = []() { const char* e = getenv("PG_WGRAD_B3_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+  const int waves = (MR == 2 && T <= 4) ? env_waves : 4;  // (6 and 9 taps: the accumulators no longer fit 128 registers)
+  const long slot_cap = waves == 8 ? 2L * 512 : (long)WB_DS * WB_THREADS;
   // tile rows: K steps of 4 pixel blocks, staging slots within the per-thread caps, LDS within budget
   int TR = 0;
   for (int tr = 1; tr <= OH + 3; ++tr) {
     if ((tr * PBR) % 4 != 0) continue;
     const long dslots = (long)wb_co * tr * PBR, xslots = (long)WB_CI * (tr + hr) * PBR;
     const long bytes = (3 * dslots + 3L * a.ndc * xslots) * 16;
-    if (dslots > WB_DS * WB_THREADS || xslots > WB_XS * WB_THREADS || bytes > WB_LDS_BUDGET) break;
+    if (dslots > slot_cap || xslots > slot_cap || bytes > WB_LDS_BUDGET) break;
     TR = tr;
     if (tr >= OH) break;
   }
@@ -679,14 +697,20 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
     if (MR == 2) hipLaunchKernelGGL((conv_wgrad_b3_kernel<TT, 2>), grid, dim3(WB_THREADS), shmem, st, a); \
     else hipLaunchKernelGGL((conv_wgrad_b3_kernel<TT, 1>), grid, dim3(WB_THREADS), shmem, st, a);         \
   }
+#define PG_WB8(TT)                                                                                       \
+  {                                                                                                      \
+    if (waves == 8) hipLaunchKernelGGL((conv_wgrad_b3_kernel<TT, 2, 8>), grid, dim3(512), shmem, st, a);  \
+    else PG_WB(TT)                                                                                       \
+  }
   switch (T) {
-    case 1: PG_WB(1); break;
-    case 2: PG_WB(2); break;
-    case 3: PG_WB(3); break;
-    case 4: PG_WB(4); break;
+    case 1: PG_WB8(1); break;
+    case 2: PG_WB8(2); break;
+    case 3: PG_WB8(3); break;
+    case 4: PG_WB8(4); break;
     case 6: PG_WB(6); break;
     default: PG_WB(9); break;
   }
+#undef PG_WB8
 #undef PG_WB
   if (hipGetLastError() != hipSuccess) return -1;
   return (int)G;
