@@ -142,9 +142,13 @@ B3Plan b3_plan(int Kc, int M, int T) {
   return best;
 }
 
-// rows per tile: as many as fit 256 output pixels and the planned tile (with halo)
-int b3_rows(int T, int OH, int OW, int hr, int hc) {
-  const int cap = T == 1 ? 256 : B3_PX_CAP;
+// rows per tile: as many as fit 256 output pixels and a staged tile (with halo) of at most `cap` pixels; cap = 0: the
+// format-level assumption (B3_PX_CAP). pg_b3_conv passes the cap its launch's real LDS budget allows (round 4): the
+// plan is made for 352 pixels whatever the image, but a plan with one channel group leaves room for more — on 64-wide
+// rows a 3x3 then takes 4 output rows per tile (6 staged: 396 pixels) instead of 3 (5 staged), and the tile is a full
+// 256 pixels instead of 192.
+int b3_rows(int T, int OH, int OW, int hr, int hc, int cap = 0) {
+  if (cap <= 0) cap = T == 1 ? 256 : B3_PX_CAP;
   int TR = 256 / OW;
   if (TR > OH) TR = OH;
   while (TR >= 1 && (TR + hr) * (OW + hc) > cap) --TR;
@@ -242,7 +246,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   int hr, hc;
   tap_extent(T, tap_dr, tap_dc, a.min_dr, hr, a.min_dc, hc);
   const B3Plan pl = b3_plan(Cin, Cout, T);
-  const int TR = b3_rows(T, OH, OW, hr, hc);
+  int TR = b3_rows(T, OH, OW, hr, hc);
   PG_REQUIRE(pl.ok && TR >= 1 && OH * OW >= 256 && OW <= 256, PG_ESHAPE,
              "pg_conv2d_mfma(bf16x3): shape not covered");
   a.CIB = pl.CIB; a.cgs = pl.cgs; a.groups = pl.groups; a.ksteps = pl.ksteps;
@@ -287,6 +291,21 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
       else b3_dispatch<false>(a, l, st);
       PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, 1x1)");
       return 0;
+    }
+  }
+  if (T > 1 && !(T == 4 && pl.CIB == 8 && pl.MT == 4 && pl.ksteps == 1 && !pl.w9)) {
+    // conv_b3_kernel: the staged tile may be larger than the format-level 352 pixels if THIS launch's LDS has the room
+    // (one 64-channel chunk per workgroup assumed here; the wide kernel is re-checked below and falls back)
+    static const bool big_on = []() { const char* e = getenv("PG_CONV_B3_BIGTILE"); return !(e && e[0] == '0'); }();
+    const long fixed = (long)pl.w_bytes + 4L * 16 * 68 * 4 + (B3_CO_CHUNK + B3_MAXG + 4) * 4 + 16 * 16 + 512;
+    long cap = (80L * 1024 - fixed) / ((long)pl.cgs * 48);        // 16-byte entries per (group, piece) plane
+    const long slot_cap = (pl.w9 ? 2L : (long)B3_XS) * B3_THREADS / pl.cgs;  // staging slots per thread
+    if (cap > slot_cap) cap = slot_cap;
+    cap = (cap / 16) * 16;
+    const bool wide = !pl.w9 && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0;  // (its LDS holds two weight slabs: keep the plan's tile)
+    if (big_on && !wide && cap > B3_PX_CAP) {
+      const int TR2 = b3_rows(T, OH, OW, hr, hc, (int)cap);
+      if (TR2 > TR) TR = TR2;
     }
   }
   a.TR = TR; a.tile_h = TR + hr; a.tile_w = OW + hc;
