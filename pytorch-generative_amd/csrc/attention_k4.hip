@@ -514,8 +514,8 @@ __global__ void __launch_bounds__(64) attn_dkv_k4_kernel(const PgAttnArgs a) {
 // the score tile S[query 4g + r][key j]: each 16 x 16 dS tile is transposed through a 1.25 KB per-wave LDS scratch
 // (one ds_write_b128 + four ds_read_b32; rows of 20 floats: conflict free both ways), multiplied by K^T float4s on
 // the VALU (d_k = 4: an MFMA tile would be 75 % padding), summed over the block's key groups in registers and over
-// the four lane groups by two shuffles, and deposited with ONE fp32 atomic per lane and query tile into dq (zeroed
-// by the launcher). delta = sum_dv dO * O comes from a small pre-pass (attn_delta_k4_kernel). dQ's summation order
+// the four lane groups by two shuffles, and deposited with ONE fp32 atomic per lane and query tile into dq. delta =
+// sum_dv dO * O comes from a small pre-pass (attn_delta_k4_kernel), which also zeroes dq. dQ's summation order
 // over key blocks depends on the schedule: pg_attn_fused_bwd(0) / ops.set_deterministic(True) keep the two-kernel
 // backward for bit-reproducible gradients, as for d_k = d_v = 4.
 template <int DVT>
@@ -530,6 +530,13 @@ __global__ void __launch_bounds__(256) attn_delta_k4_kernel(const PgAttnArgs a) 
 #pragma unroll
   for (int c = 0; c < DV; ++c) acc = fmaf(dop[(size_t)c * a.L], op[(size_t)c * a.L], acc);
   a.delta[((size_t)n * a.heads + h) * a.L + q] = acc;
+  // dQ is deposited with atomics by the fused kernel, so this pre-pass also zeroes it. (Not a memset node: with
+  // hipMemset2DAsync here, a torch-captured graph of forward + backward returned the right dQ on its first launch and
+  // dQ off by a constant on every later one — ROCm 7.2, tools/exp/attn_graph_check.py; a lone memset node replays
+  // correctly, tools/exp/memset_graph_test.hip, so the node's interplay with its neighbours is what fails.)
+  float* dqp = a.dq + (size_t)n * a.dq_bs + (size_t)h * 4 * a.L + q;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dqp[(size_t)c * a.L] = 0.f;
 }
 
 template <int DVT, int QB>
@@ -713,14 +720,11 @@ int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st) {
   }
   const int units = a.N * a.heads;
   if (which == PG_ATTN_BWD) {
-    // delta pre-pass, dq zeroed (the kernel deposits with atomics), then the fused kernel on 32-key blocks
+    // delta pre-pass (which also zeroes dq: the fused kernel deposits with atomics), then the fused kernel on 32-key blocks
     if ((a.dq_bs % 4) != 0 || (reinterpret_cast<uintptr_t>(a.dq) & 15) != 0) return 0;
     const dim3 dgrid((unsigned)((a.L + 255) / 256), (unsigned)units);
     if (dv == 32) hipLaunchKernelGGL((attn_delta_k4_kernel<2>), dgrid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_delta_k4_kernel<1>), dgrid, dim3(256), 0, st, a);
-    const size_t row_bytes = (size_t)a.heads * 4 * a.L * sizeof(float);
-    if ((size_t)a.dq_bs * sizeof(float) == row_bytes) (void)hipMemsetAsync(a.dq, 0, row_bytes * a.N, st);
-    else (void)hipMemset2DAsync(a.dq, (size_t)a.dq_bs * sizeof(float), 0, row_bytes, (size_t)a.N, st);
     constexpr int FQB = 2;
     const int NBf = (a.L + 16 * FQB - 1) / (16 * FQB);
     const int npf = (NBf + 1) / 2;

@@ -98,6 +98,12 @@ __global__ void __launch_bounds__(VQ_THREADS) vq_assign_kernel(
   }
 }
 
+__global__ void vq_zero_ws_kernel(float* __restrict__ count, float* __restrict__ sum, long nc, long ns) {
+  const long i = blockIdx.x * (long)VQ_THREADS + threadIdx.x;
+  if (i < nc) count[i] = 0.f;
+  else if (i < nc + ns) sum[i - nc] = 0.f;
+}
+
 // batch statistics of the EMA update (nn/utils.py:81-82): count[k] = |{p: idx[p] = k}|,
 // sum[k][d] = sum over those positions of x[p][d]
 __global__ void vq_ema_stats_kernel(const float* __restrict__ x, const int* __restrict__ idx,
@@ -211,11 +217,12 @@ PG_EXPORT int pg_vq_ema_update(const float* x, const int* idx, float* cluster_si
              "pg_vq_ema_update: null pointer");
   PG_REQUIRE(N > 0 && L > 0 && K > 0 && D > 0, PG_EINVAL, "pg_vq_ema_update: non-positive dimension");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(count_ws, 0, (size_t)K * sizeof(float), s) != hipSuccess ||
-      hipMemsetAsync(sum_ws, 0, (size_t)K * D * sizeof(float), s) != hipSuccess) {
-    pg_set_error("pg_vq_ema_update: hipMemsetAsync failed");
-    return PG_EINVAL;
-  }
+  // the two workspaces are zeroed by a kernel, not by memset nodes (attention_k4.hip, attn_delta_k4_kernel: a memset
+  // node inside a replayed step graph went wrong on this ROCm)
+  const long nz = (long)K * (D + 1);
+  hipLaunchKernelGGL(vq_zero_ws_kernel, dim3((unsigned)((nz + VQ_THREADS - 1) / VQ_THREADS)), dim3(VQ_THREADS), 0, s,
+                     count_ws, sum_ws, (long)K, (long)K * D);
+  PG_LAUNCH_CHECK("pg_vq_ema_update(zero)");
   const long P = (long)N * L;
   hipLaunchKernelGGL(vq_ema_stats_kernel, dim3((unsigned)((P + VQ_THREADS - 1) / VQ_THREADS)),
                      dim3(VQ_THREADS), 0, s, x, idx, count_ws, sum_ws, N, D, L);

@@ -67,6 +67,8 @@ struct Block {
 std::mutex g_mu;
 std::unordered_map<void*, Block> g_live;
 bool g_init = false, g_vmm = false, g_poison = true;
+unsigned char g_poison_byte = 0xFF;  // PG_GUARD_POISON_BYTE: 0xFF = NaN (default); 0x5C = 2.5e17, a huge FINITE value that
+                                     // survives the max / select operations (ReLU, masks) which swallow a NaN
 size_t g_gran = 4096, g_align = 512, g_margin = 64 << 10;
 int g_violations = 0;
 unsigned long g_serial = 0;
@@ -97,6 +99,7 @@ void init_once(int device) {
   if (g_align < 16) g_align = 16;
   if (const char* s = getenv("PG_GUARD_MARGIN_KB")) g_margin = (size_t)atol(s) << 10;
   if (const char* s = getenv("PG_GUARD_POISON")) g_poison = atoi(s) != 0;
+  if (const char* s = getenv("PG_GUARD_POISON_BYTE")) g_poison_byte = (unsigned char)strtol(s, nullptr, 0);
   if (g_vmm) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
@@ -228,7 +231,7 @@ __attribute__((visibility("default"))) void* pg_guard_malloc(ssize_t size, int d
   fill((unsigned char*)user - b.lead, kCanary, b.lead);
   fill((unsigned char*)user + b.user_bytes, kCanary, b.trail);
   // poison the tensor itself (0xFF.. = a NaN) so that reads of never-written memory show up (PG_GUARD_POISON=0: off)
-  if (g_poison) fill(user, 0xFF, b.user_bytes);
+  if (g_poison) fill(user, g_poison_byte, b.user_bytes);
   GCHECK(hipStreamSynchronize(nullptr));  // torch's side streams are non-blocking: the fills must have landed
   g_live[user] = b;
   return user;

@@ -355,6 +355,44 @@ def test_attention_k4_backward_paths(dev, case, fused):
     _util.assert_close(kvg.grad[:, e:], kvo.grad[:, e:], TOL, "attn dv")
 
 
+@pytest.mark.parametrize("case", [(1, 1, 4, 32, 28, 28), (3, 2, 4, 16, 16, 16)], ids=["snail28", "two_heads"])
+def test_attention_backward_replayed_graph_equals_eager(dev, case):
+    """A captured forward + fused backward replayed SEVERAL times returns the eager gradients every time. (Round 4,
+    found under the canary allocator: dQ used to be zeroed by a hipMemset2DAsync node, which wrote zeros on the first
+    launch of the executable graph and a stale value afterwards; the delta pre-pass zeroes dQ now. One replay — what
+    the older graph tests looked at — cannot see that.)"""
+    from pytorch_generative_amd import ops
+
+    n, heads, dk, dv, h, w = case
+    e, v = heads * dk, heads * dv
+    qkv0 = _rand(n, 2 * e + v, h, w, seed=4).to(dev)
+    d_o = _rand(n, v, h, w, seed=5).to(dev)
+
+    def run(t):
+        o = ops.causal_attention_qkv(t, heads, e, v, True)
+        (g,) = torch.autograd.grad(o, t, d_o)
+        return o.detach(), g
+
+    o_e, g_e = run(qkv0.clone().requires_grad_(True))
+    static = qkv0.clone().requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run(static)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+        o_g, g_g = run(static)
+    for it in range(4):
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o_g, o_e), f"replay {it}: output"
+        assert torch.equal(g_g[:, e:], g_e[:, e:]), f"replay {it}: dK / dV"
+        # dQ: fp32 atomics, arrival order may differ between launches
+        _util.assert_close(g_g[:, :e], g_e[:, :e], 1e-5, f"replay {it}: dQ")
+
+
 def test_attention_large_scores_stay_finite(dev):
     """Online-softmax rescale branch: a spike late in the key sequence forces the running max to
     jump; compare with the oracle on the same data."""
