@@ -25,6 +25,11 @@ FLAGS = [
     "-fPIC",
     "-fvisibility=hidden",
     "-munsafe-fp-atomics",  # global_atomic_add_f32 instead of a CAS loop
+    # MFMA results in architectural VGPRs, never in AGPRs: every kernel here consumes its accumulators on the VALU (exp, scaling,
+    # epilogues), and with the default (AGPR destinations picked by the allocator) attention_k4 / conv_wgrad / gpt_block carried up
+    # to 64 v_accvgpr_read/write per loop iteration plus the registers to stage them: 103 kernels use fewer registers with this
+    # (29 gain a wave per SIMD, e.g. attn_fwd_k4_kernel<1, 2, 4> 148 -> 128), none spills (profiles/README.md, round 4, item 13)
+    "-mllvm", "-amdgpu-mfma-vgpr-form=1",
     "-Wall",
     "-Wno-unused-function",
 ] + (["-DPG_ABLATE"] if ABLATE else [])

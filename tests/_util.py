@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def golden_names():
     """Autoregressive-model fixtures (the VAE fixtures, `vae_*.pt`, carry noise and KL terms)."""
     names = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.pt")))
-    return [n for n in names if not n.startswith(("vae_", "vq_"))]  # vq_*: SURVEY §8(f) rank 4, oracle only so far
+    return [n for n in names if not n.startswith(("vae_", "vq_", "posenc"))]  # vq_*: SURVEY §8(f) rank 4, oracle only so far
 
 
 def vae_golden_names():

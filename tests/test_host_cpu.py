@@ -246,3 +246,43 @@ def test_attention_dims_native_matches_the_kernels_table():
     assert not ops.attention_dims_native(64, 64, 49)      # L % 16 != 0 -> padded by ops.causal_attention
     assert not ops.attention_dims_native(24, 40, 48) and not ops.attention_dims_native(8, 20, 256)
     assert not ops.attention_dims_native(16, 32, 49)
+
+
+def _arange_like_kernel(n):
+    """`arange_like_torch_cpu` of elementwise.hip restated with exact rational arithmetic: every fma is one correctly
+    rounded double operation (Fraction -> float rounds to nearest even), the float32 store a second rounding."""
+    from fractions import Fraction
+
+    import numpy as np
+
+    step = 1.0 / float(n)  # the double the kernel computes
+    fma = lambda a, b, c: float(Fraction(a) * Fraction(b) + Fraction(c))  # noqa: E731
+    nvec = (n // 16) * 16
+    out = np.empty(n, dtype=np.float32)
+    for i in range(n):
+        if i < nvec:
+            b0 = (i // 8) * 8
+            base = np.float32(fma(float(b0), step, -0.5))
+            out[i] = np.float32(fma(float(i - b0), step, float(base)))
+        else:
+            out[i] = np.float32(fma(float(i), step, -0.5))
+    return out
+
+
+def test_positional_encoding_formula_reproduces_the_reference_fixture():
+    """The rounding recipe `posenc_kernel` implements (ATen's vectorised CPU arange: 8-wide vectors from a float32 base
+    for the first floor(n / 16) * 16 elements, scalar fma for the rest), evaluated WITHOUT a GPU, equals the planes the real
+    reference produced bit for bit (tests/golden/posenc.pt) — so the GPU test's strict `torch.equal` does not depend on
+    which host the GPU box has; plus a sweep of sizes against the oracle on this host when it is an AVX-512 one."""
+    import torch
+
+    gold = _util.load_golden("posenc")
+    for shape, enc in gold["cases"].items():
+        h, w = shape[2], shape[3]
+        rows = torch.from_numpy(_arange_like_kernel(h))
+        cols = torch.from_numpy(_arange_like_kernel(w))
+        assert torch.equal(enc[0, 0], rows[:, None].expand(h, w)), shape
+        assert torch.equal(enc[0, 1], cols[None, :].expand(h, w)), shape
+    if torch.backends.cpu.get_cpu_capability() == gold["cpu_capability"]:
+        for n in list(range(2, 70)) + [96, 100, 127, 128, 200, 255, 256, 511, 600]:
+            assert torch.equal(torch.from_numpy(_arange_like_kernel(n)), torch.arange(-0.5, 0.5, 1 / n)[:n]), n

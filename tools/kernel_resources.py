@@ -16,7 +16,7 @@ import sys
 import yaml
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJ = os.path.join(ROOT, "pytorch-generative_amd", "build")
+OBJ = os.environ.get("PG_OBJ_DIR") or os.path.join(ROOT, "pytorch-generative_amd", "build")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
