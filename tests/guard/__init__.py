@@ -9,6 +9,11 @@ never-written memory shows up as NaN in the test's own comparison.
     PG_GUARD_ALIGN=512|16       rounding of sizes: 512 = what torch's caching allocator guarantees, 16 = strict
     PG_GUARD_MARGIN_KB=64       canary bytes on each side
     PG_GUARD_POISON=0           do not fill fresh tensors with NaN bytes
+    PG_GUARD_POISON_BYTE=0x5C   poison with 2.5e17 (huge but FINITE) instead of NaN: max / select operations (ReLU, masks) swallow
+                                a NaN, a huge finite value survives them and shows up in the comparison
+    PG_GUARD_ARENA_MB=32768     arena that serves allocations made DURING a hipGraph capture (never recycled: a captured graph
+                                keeps its addresses); memory of the arena is virgin, which is how a read of stale graph memory
+                                shows (profiles/README.md, round 4, item 12)
     PG_GUARD_MODE=vmm           experimental guard PAGES (out-of-bounds reads fault); unreliable on ROCm 7.2, see the .hip
 """
 
