@@ -14,9 +14,13 @@ CSRC = os.path.join(HERE, "csrc")
 # PG_ABLATE=1: the timing-only ablation build (-DPG_ABLATE: PG_B3_DBG / PG_WB_DBG are compiled in) as a SEPARATE
 # library, lib/libpg_hip_ablate.so, for tools/exp — the production library never contains those switches
 ABLATE = os.environ.get("PG_ABLATE") == "1"
-OBJ = os.path.join(HERE, "build_ablate" if ABLATE else "build")
+# PG_VARIANT=<name>: an EXPERIMENT build with -DPG_<NAME> (e.g. PG_VARIANT=bufload -> -DPG_BUFLOAD, common.h) as a
+# separate library lib/libpg_hip_<name>.so; tests / bench pick it up with PG_HIP_LIB=<path> (pytorch_generative_amd/_lib.py)
+VARIANT = os.environ.get("PG_VARIANT", "")
+_TAG = "ablate" if ABLATE else VARIANT
+OBJ = os.path.join(HERE, "build_" + _TAG if _TAG else "build")
 LIB_DIR = os.path.join(HERE, "pytorch_generative_amd", "lib")
-LIB = os.path.join(LIB_DIR, "libpg_hip_ablate.so" if ABLATE else "libpg_hip.so")
+LIB = os.path.join(LIB_DIR, f"libpg_hip_{_TAG}.so" if _TAG else "libpg_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950",
@@ -32,7 +36,7 @@ FLAGS = [
     "-mllvm", "-amdgpu-mfma-vgpr-form=1",
     "-Wall",
     "-Wno-unused-function",
-] + (["-DPG_ABLATE"] if ABLATE else [])
+] + (["-DPG_ABLATE"] if ABLATE else []) + ([f"-DPG_{VARIANT.upper()}"] if VARIANT else [])
 
 
 def _sources():

@@ -234,8 +234,30 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
 #pragma unroll
   for (int k = 0; k < WS; ++k) wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+#ifdef PG_BUFLOAD
+#define PG_B3_ISSUE_X_LOADS()                                                              \
+    const __amdgpu_buffer_rsrc_t rs_ = pg_rsrc(a.in + (size_t)(n_first + tl_ * nstep) * a.Cin * plane, \
+                                               (unsigned)a.Cin * (unsigned)plane * 4u);    \
+    const int cb_ = ch_ * a.CIB * plane * 4;                                               \
+    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                       \
+      if (s_goff[k] >= 0) {                                                                \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = pg_bload(rs_, s_goff[k] * 4, cb_ + c * plane * 4); \
+      }                                                                                    \
+    }
+#else
+#define PG_B3_ISSUE_X_LOADS()                                                              \
+    const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
+    if (!(PG_DBG_BIT(a.dbg, 1) && (STEP_) > 0))                                            \
+    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                       \
+      if (s_goff[k] >= 0) {                                                                \
+        const float* p_ = src_ + s_goff[k];                                                \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = p_[(size_t)c * plane];    \
+      }                                                                                    \
+    }
+#endif
 #define PG_B3_ISSUE(STEP)                                                                  \
   {                                                                                        \
+    const int STEP_ = (STEP);                                                              \
     const int tl_ = (STEP) / nchunk;                                                       \
     const int ch_ = (STEP) - tl_ * nchunk;                                                 \
     const float4* ws_ = wsrc_b + (size_t)ch_ * a.wslab4;                                   \
@@ -243,14 +265,7 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       const int i = wt + k * B3_THREADS;                                                   \
       if (MT == 4 ? k < nwk : i < a.wslab4) wv[k] = ws_[i];                                \
     }                                                                                      \
-    const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
-    if (!(PG_DBG_BIT(a.dbg, 1) && (STEP) > 0))                                                      \
-    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                       \
-      if (s_goff[k] >= 0) {                                                                \
-        const float* p_ = src_ + s_goff[k];                                                \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = p_[(size_t)c * plane];    \
-      }                                                                                    \
-    }                                                                                      \
+    PG_B3_ISSUE_X_LOADS()                                                                  \
   }
 #define PG_B3_COMMIT_X(ACT)                                                                \
   _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                         \
@@ -532,6 +547,7 @@ if constexpr (GL) {
   }
   PG_PROF_DUMP(THREADS / 64, wave_all, nsteps)
 #undef PG_B3_ISSUE
+#undef PG_B3_ISSUE_X_LOADS
 #undef PG_B3_COMMIT_X
 #undef PG_B3_COMMIT_ALL
 }
@@ -648,12 +664,26 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
   if (tid < B3_CO_CHUNK) lds[a.b_off + tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
   __syncthreads();  // the zero fill is ordered before the first commit (other threads own the same entries there)
 
+#ifdef PG_BUFLOAD
+  const unsigned img_bytes = (unsigned)a.Cin * (unsigned)plane * 4u;  // one image of the input (< 4 GB)
+#endif
   const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * B3P_W4;  // uniform
   float xv[XS][8];
   float4 wv0, wv1 = make_float4(0.f, 0.f, 0.f, 0.f), wv2 = wv1;  // (named, not an array: indexed inside the unrolled slice loop an array stays in scratch memory)
 
   // (tile, chunk) of the step whose loads are issued next
   int l_tl = 0, l_ch = 0;
+#ifdef PG_BUFLOAD
+#define PG_P_ISSUE_X()                                                                         \
+  {                                                                                            \
+    /* one descriptor per image (scalar), the channel in the scalar offset, the slot's byte offset in a VGPR */ \
+    const __amdgpu_buffer_rsrc_t rs_ = pg_rsrc(a.in + (size_t)(n_first + l_tl * nstep) * a.Cin * plane, img_bytes); \
+    const int cb_ = l_ch * 8 * plane * 4;                                                      \
+    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                           \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = pg_bload(rs_, s_goff[k] * 4, cb_ + c * plane * 4); \
+    }                                                                                          \
+  }
+#else
 #define PG_P_ISSUE_X()                                                                         \
   {                                                                                            \
     const float* src_ = a.in + ((size_t)(n_first + l_tl * nstep) * a.Cin + l_ch * 8) * plane;  \
@@ -662,6 +692,7 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
       _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = (src_ + (size_t)c * plane)[(unsigned)s_goff[k]]; \
     }                                                                                          \
   }
+#endif
 #define PG_P_ISSUE_W()                                                                         \
   {                                                                                            \
     const float4* ws_ = wsrc_b + (size_t)l_ch * B3P_W4;                                        \

@@ -9,7 +9,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpg_hip.so")
+# PG_HIP_LIB=<path>: load an alternative build of the same C-ABI (experiment variants of build.py: PG_VARIANT / PG_ABLATE) — still a
+# HIP library, still loaded or the import fails; the default is the production library
+LIB_PATH = os.environ.get("PG_HIP_LIB") or os.path.join(_HERE, "lib", "libpg_hip.so")
 
 ABI_VERSION = 1
 
