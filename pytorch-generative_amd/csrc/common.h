@@ -235,4 +235,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_rsrc(const void* base, unsi
 __device__ __forceinline__ float pg_bload(__amdgpu_buffer_rsrc_t rs, int voff_bytes, int soff_bytes) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_bytes, soff_bytes, 0));
 }
+__device__ __forceinline__ void pg_bstore(__amdgpu_buffer_rsrc_t rs, float v, int voff_bytes, int soff_bytes) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff_bytes, soff_bytes, 0);
+}
 #endif

@@ -887,6 +887,23 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
         int hrow = 8 * half;
         asm volatile("" : "+v"(ox), "+v"(hrow));
         float q0[4], q1[4], q2[4];
+#ifdef PG_BUFLOAD
+        // one descriptor per operand plane block (64 channels of this image), the lane's pixel + channel-half offset in ONE
+        // VGPR, the channel of the request in the scalar offset
+        // num_records = the chunk's VALID channels: a request beyond them returns 0 / a store there is dropped by the
+        // range check, so no channel predicate is needed on the loads
+        const unsigned blk_bytes = (unsigned)(fullc ? 64 : cvalid) * (unsigned)Lv * 4u;
+        const __amdgpu_buffer_rsrc_t rs0 = pg_rsrc(st0 ? st0 : a.in, blk_bytes), rs1 = pg_rsrc(st1 ? st1 : a.in, blk_bytes),
+                                     rs2 = pg_rsrc(st2 ? st2 : a.in, blk_bytes), rso = pg_rsrc(outp, blk_bytes);
+        const int vo8 = (int)(ox + (unsigned)hrow * (unsigned)Lv) * 4;
+#define PG_P_REQ8(M, H)                                                                    \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                          \
+    const int cu_ = (M) * 16 + (H) * 4 + c;  /* uniform part of the channel */             \
+    if (st0) q0[c] = pg_bload(rs0, vo8, cu_ * Lv * 4);                                     \
+    if (st1) q1[c] = pg_bload(rs1, vo8, cu_ * Lv * 4);                                     \
+    if (st2) q2[c] = pg_bload(rs2, vo8, cu_ * Lv * 4);                                     \
+  }
+#else
 #define PG_P_REQ8(M, H)                                                                    \
   _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                          \
     const int cc = (M) * 16 + hrow + (H) * 4 + c;                                          \
@@ -895,6 +912,7 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
     if (st1) q1[c] = (st1 + off_)[ox];                                                     \
     if (st2) q2[c] = (st2 + off_)[ox];                                                     \
   }
+#endif
         if (any_op) { PG_P_REQ8(0, 0) }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -966,7 +984,11 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 const int cc = m * 16 + hrow + hh * 4 + c;
+#ifdef PG_BUFLOAD
+                if (fullc || cc < cvalid_p) pg_bstore(rso, v[hh * 4 + c], vo8, (m * 16 + hh * 4 + c) * Lv * 4);
+#else
                 if (fullc || cc < cvalid_p) (outp + (size_t)cc * Lv)[ox] = v[hh * 4 + c];
+#endif
               }
             }
           }
