@@ -366,6 +366,23 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       asm volatile("" : "+s"(cvalid_p));
       float* outp = a.out + so;
       const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr, has_res2 = a.res2 != nullptr;
+      // epilogue accesses: channel CC of the chunk at this lane's pixel. PG_EP_LDC: a channel beyond the valid ones reads
+      // channel 0 (value unused). -DPG_BUFLOAD (experiment, common.h): descriptor per operand with num_records = the valid
+      // channels (a read beyond them returns 0, a store there is dropped), lane pixel in one VGPR, channel in the scalar offset
+#ifdef PG_BUFLOAD
+      const unsigned ep_bytes = (unsigned)(fullc ? MT * 16 : cvalid) * (unsigned)Lv * 4u;
+      const int ep_vo = (int)lane_px * 4;
+#define PG_EP_RS(NAME, P) const __amdgpu_buffer_rsrc_t NAME = pg_rsrc((P) ? (const void*)(P) : (const void*)a.in, ep_bytes);
+#define PG_EP_LDC(RS, P, CC) pg_bload(RS, ep_vo, (CC) * Lv * 4)
+#define PG_EP_LDO(RS, P, OFF, CC) pg_bload(RS, ep_vo, (CC) * Lv * 4)
+#define PG_EP_ST(RS, P, CC, V) pg_bstore(RS, V, ep_vo, (CC) * Lv * 4)
+#else
+#define PG_EP_RS(NAME, P)
+#define PG_EP_LDC(RS, P, CC) ((P) + (size_t)((fullc || (CC) < cvalid_p) ? (CC) : 0) * Lv)[lane_px]
+#define PG_EP_LDO(RS, P, OFF, CC) ((P) + (OFF))[lane_px]  /* OFF: the clamped channel offset, shared by the operands */
+#define PG_EP_ST(RS, P, CC, V) ((P) + (size_t)(CC) * Lv)[lane_px] = (V)
+#endif
+      PG_EP_RS(rs_out, outp)
 #define PG_B3_TILE_BODY(M)                                                                       \
   _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
   _Pragma("unroll") for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[M][n][r]; \
@@ -383,11 +400,11 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
   if (sok) {                                                                  \
     if (fullc) {                                                              \
       _Pragma("unroll") for (int c = 0; c < 16; ++c)                          \
-        (outp + (size_t)((M) * 16 + c) * Lv)[lane_px] = v[c];                 \
+        PG_EP_ST(rs_out, outp, (M) * 16 + c, v[c]);                           \
     } else {                                                                  \
       _Pragma("unroll") for (int c = 0; c < 16; ++c) {                        \
         const int cc = (M) * 16 + c;                                          \
-        if (cc < cvalid_p) (outp + (size_t)cc * Lv)[lane_px] = v[c];            \
+        if (cc < cvalid_p) PG_EP_ST(rs_out, outp, cc, v[c]);                  \
       }                                                                       \
     }                                                                         \
   }
@@ -411,13 +428,14 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
         // register limit; with whole-tile buffers this instantiation spilled 33 dwords)
         constexpr int HQ = 4, NH = 16 / HQ;
         float o0[HQ], o1[HQ], o2[HQ];
+        PG_EP_RS(rs_s0, st0) PG_EP_RS(rs_s1, st1) PG_EP_RS(rs_s2, st2)
 #define PG_B3_REQUEST(M, H)                                                                \
   _Pragma("unroll") for (int c = 0; c < HQ; ++c) {                                          \
     const int cc = (M) * 16 + (H) * HQ + c;                                                 \
     const size_t off_ = (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv;                    \
-    if (st0) o0[c] = (st0 + off_)[lane_px];                                                \
-    if (st1) o1[c] = (st1 + off_)[lane_px];                                                \
-    if (st2) o2[c] = (st2 + off_)[lane_px];                                                \
+    if (st0) o0[c] = PG_EP_LDO(rs_s0, st0, off_, cc);                                      \
+    if (st1) o1[c] = PG_EP_LDO(rs_s1, st1, off_, cc);                                      \
+    if (st2) o2[c] = PG_EP_LDO(rs_s2, st2, off_, cc);                                      \
   }
         PG_B3_REQUEST(0, 0)
 #pragma unroll
@@ -461,12 +479,12 @@ if constexpr (GL) {
             if (sok) {
               if (fullc) {
 #pragma unroll
-                for (int c = 0; c < HQ; ++c) (outp + (size_t)(m * 16 + hh * HQ + c) * Lv)[lane_px] = v[hh * HQ + c];
+                for (int c = 0; c < HQ; ++c) PG_EP_ST(rs_out, outp, m * 16 + hh * HQ + c, v[hh * HQ + c]);
               } else {
 #pragma unroll
                 for (int c = 0; c < HQ; ++c) {
                   const int cc = m * 16 + hh * HQ + c;
-                  if (cc < cvalid_p) (outp + (size_t)cc * Lv)[lane_px] = v[hh * HQ + c];
+                  if (cc < cvalid_p) PG_EP_ST(rs_out, outp, cc, v[hh * HQ + c]);
                 }
               }
             }
@@ -479,6 +497,7 @@ if constexpr (GL) {
         const float* op1 = (has_res ? a.res : a.dact_src) + so;
         const float* op2 = (has_res && has_ds) ? a.dact_src + so : nullptr;
         constexpr int MH = GL ? 1 : (MT > 2 ? 2 : MT);  // GELU instantiations: one tile of operands in flight (registers)
+        PG_EP_RS(rs_o1, op1) PG_EP_RS(rs_o2, op2)
         float ov[MH][16];
         const int dsel = has_ds ? a.dact : PG_ACT_NONE;
 #pragma unroll
@@ -489,7 +508,7 @@ if constexpr (GL) {
 #pragma unroll
               for (int c = 0; c < 16; ++c) {
                 const int cc = (m + mm) * 16 + c;
-                ov[mm][c] = (op1 + (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv)[lane_px];
+                ov[mm][c] = PG_EP_LDC(rs_o1, op1, cc);
               }
           }
           PG_B3_TILE_BODY(m)
@@ -501,7 +520,7 @@ if constexpr (GL) {
 #pragma unroll
               for (int c = 0; c < 16; ++c) {
                 const int cc = m * 16 + c;
-                sv[c] = (op2 + (size_t)((fullc || cc < cvalid_p) ? cc : 0) * Lv)[lane_px];
+                sv[c] = PG_EP_LDC(rs_o2, op2, cc);
               }
             }
           } else {
@@ -535,6 +554,10 @@ if constexpr (GL) {
       }
 #undef PG_B3_TILE_BODY
 #undef PG_B3_TILE_STORE
+#undef PG_EP_RS
+#undef PG_EP_LDC
+#undef PG_EP_LDO
+#undef PG_EP_ST
     }
     if (last_chunk) {
 #pragma unroll
