@@ -235,6 +235,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_rsrc(const void* base, unsi
 __device__ __forceinline__ float pg_bload(__amdgpu_buffer_rsrc_t rs, int voff_bytes, int soff_bytes) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_bytes, soff_bytes, 0));
 }
+typedef float pg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pg_f32x2 pg_bload2(__amdgpu_buffer_rsrc_t rs, int voff_bytes, int soff_bytes) {
+  typedef int i32x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(pg_f32x2, (i32x2_)__builtin_amdgcn_raw_buffer_load_b64(rs, voff_bytes, soff_bytes, 0));
+}
+__device__ __forceinline__ float4 pg_bload4(__amdgpu_buffer_rsrc_t rs, int voff_bytes, int soff_bytes) {
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+  const i32x4_ r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, soff_bytes, 0);
+  return make_float4(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]), __builtin_bit_cast(float, r[2]),
+                     __builtin_bit_cast(float, r[3]));
+}
 __device__ __forceinline__ void pg_bstore(__amdgpu_buffer_rsrc_t rs, float v, int voff_bytes, int soff_bytes) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff_bytes, soff_bytes, 0);
 }

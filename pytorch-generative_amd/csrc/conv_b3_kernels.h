@@ -1184,6 +1184,22 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
 #pragma unroll
   for (int c = 0; c < 8; ++c) nxt[c] = f32x2{0.f, 0.f};
 // addresses = uniform base (SGPR pair: image, channel chunk, tile) + 32-bit lane offset: one VGPR per stream
+#ifdef PG_BUFLOAD
+// experiment (common.h): one descriptor per image, (chunk, channel, tile) in the scalar offset, the lane's byte offset in a VGPR
+#define PG_PW_ISSUE(IT, J, DST)                                                                        \
+  {                                                                                                    \
+    const int ni_ = (IT) / tpi;                                                                        \
+    const int t0_ = ((IT) - ni_ * tpi) * 32;                                                           \
+    const bool ok_ = kact && t0_ + 2 * jc < L;                                                         \
+    const __amdgpu_buffer_rsrc_t rs_ = pg_rsrc(a.in + (size_t)ni_ * a.Cin * (size_t)L, (unsigned)a.Cin * (unsigned)L * 4u); \
+    const int vo_ = ok_ ? (int)lane_in * 4 : 0;                                                        \
+    const int cb_ = ((J) * a.CIB * L + t0_) * 4;                                                       \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                    \
+      const f32x2 t_ = pg_bload2(rs_, vo_, cb_ + c * L * 4);                                           \
+      DST[c] = f32x2{ok_ ? t_[0] : 0.f, ok_ ? t_[1] : 0.f};                                            \
+    }                                                                                                  \
+  }
+#else
 #define PG_PW_ISSUE(IT, J, DST)                                                                        \
   {                                                                                                    \
     const int ni_ = (IT) / tpi;                                                                        \
@@ -1197,6 +1213,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
       DST[c] = f32x2{ok_ ? t_[0] : 0.f, ok_ ? t_[1] : 0.f};                                            \
     }                                                                                                  \
   }
+#endif
 #define PG_PW_MFMA(ACT)                                                                   \
   _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                         \
     float e_[8];                                                                          \

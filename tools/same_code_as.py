@@ -29,8 +29,10 @@ def _disasm(hipcc, flags, src, workdir, tag):
     obj = os.path.join(workdir, tag + ".o")
     subprocess.run([hipcc, *flags, "-c", src, "-o", obj], check=True, capture_output=True)
     subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", obj], check=True, capture_output=True, cwd=workdir)
-    co = glob.glob(obj + ".0.hipv4-amdgcn-amd-amdhsa--gfx950")[0]
-    text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True,
+    co = glob.glob(obj + ".0.hipv4-amdgcn-amd-amdhsa--gfx950")
+    if not co:
+        return []  # host-only translation unit (comm.hip)
+    text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co[0]], check=True, capture_output=True,
                           text=True).stdout
     return [ln.split("//")[0].rstrip() for ln in text.splitlines()[3:]]
 
