@@ -37,6 +37,9 @@ FLAGS = [
     "-Wall",
     "-Wno-unused-function",
 ] + (["-DPG_ABLATE"] if ABLATE else []) + ([f"-DPG_{VARIANT.upper()}"] if VARIANT else [])
+# PG_EXTRA_FLAGS="..." (only together with PG_VARIANT): additional compiler flags of an experiment build, e.g. a scheduler strategy
+if VARIANT and os.environ.get("PG_EXTRA_FLAGS"):
+    FLAGS += os.environ["PG_EXTRA_FLAGS"].split()
 
 
 def _sources():
