@@ -240,9 +240,10 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
                                                (unsigned)a.Cin * (unsigned)plane * 4u);    \
     const int cb_ = ch_ * a.CIB * plane * 4;                                               \
     _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                       \
-      if (s_goff[k] >= 0) {                                                                \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = pg_bload(rs_, s_goff[k] * 4, cb_ + c * plane * 4); \
-      }                                                                                    \
+      /* a slot without a pixel asks for an address far beyond num_records: no load, no branch (the sum of the offsets is   */ \
+      /* range-checked without wrapping: tools/exp/buffer_load_test.hip (a)); its registers read 0 and go to the dump entry */ \
+      const int vo_ = s_goff[k] >= 0 ? s_goff[k] * 4 : 0x7ffffff0;                         \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = pg_bload(rs_, vo_, cb_ + c * plane * 4); \
     }
 #else
 #define PG_B3_ISSUE_X_LOADS()                                                              \
