@@ -544,10 +544,25 @@ def _self_spawn(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
+    # all ranks are watched together: a rank that dies leaves the others inside a collective that never completes, so the
+    # survivors get a grace period and are then stopped — the command fails instead of hanging until the caller's timeout
+    import time
+
+    rc, failed_at = 0, None
+    grace = float(os.environ.get("PG_BENCH_RANK_GRACE_S", "15"))
     try:
+        while any(p.poll() is None for p in procs):
+            codes = [p.poll() for p in procs]
+            if failed_at is None and any(c not in (None, 0) for c in codes):
+                failed_at = time.monotonic()
+                bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+                sys.stderr.write(f"[bench] rank(s) exited with an error: {bad}; stopping the others in {grace:g} s\n")
+            if failed_at is not None and time.monotonic() - failed_at > grace:
+                break
+            time.sleep(0.2)
         for p in procs:
-            rc = max(rc, abs(p.wait()))
+            c = p.poll()
+            rc = max(rc, 1 if c is None else abs(c))
     finally:
         for p in procs:
             if p.poll() is None:

@@ -286,3 +286,37 @@ def test_positional_encoding_formula_reproduces_the_reference_fixture():
     if torch.backends.cpu.get_cpu_capability() == gold["cpu_capability"]:
         for n in list(range(2, 70)) + [96, 100, 127, 128, 200, 255, 256, 511, 600]:
             assert torch.equal(torch.from_numpy(_arange_like_kernel(n)), torch.arange(-0.5, 0.5, 1 / n)[:n]), n
+
+
+def test_bench_self_spawn_watches_all_ranks(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` as a bare command (bench._self_spawn): every rank gets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* on 127.0.0.1, rank 0's stdout is forwarded, and a rank that dies does not leave the command hanging on the
+    survivors (they would sit in a collective forever): non-zero exit after a grace period. Ranks here are a stub script —
+    no GPU involved."""
+    import importlib.util
+    import sys
+    import time
+
+    spec = importlib.util.spec_from_file_location("pg_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(
+        "import os, sys, time\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "open(os.path.join(os.path.dirname(__file__), f'seen_{r}_of_{w}'), 'w').write(' '.join(sys.argv[1:]))\n"
+        "mode = sys.argv[1]\n"
+        "if mode == 'ok': sys.exit(0)\n"
+        "if r == 1: sys.exit(3)\n"      # mode 'die': rank 1 fails at once, the others would wait forever
+        "time.sleep(120)\n")
+    monkeypatch.setattr(bench, "__file__", str(stub))
+    monkeypatch.setenv("PG_BENCH_RANK_GRACE_S", "1")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "ok", "--gpus", "3"])
+    assert bench._self_spawn(3) == 0
+    assert sorted(p.name for p in tmp_path.glob("seen_*")) == ["seen_0_of_3", "seen_1_of_3", "seen_2_of_3"]
+    assert (tmp_path / "seen_2_of_3").read_text() == "ok --gpus 3"
+    monkeypatch.setattr(sys, "argv", ["bench.py", "die", "--gpus", "3"])
+    t0 = time.monotonic()
+    assert bench._self_spawn(3) != 0
+    assert time.monotonic() - t0 < 30, "a dead rank must not leave the launcher waiting for the survivors"
