@@ -14,6 +14,8 @@ for v in bufload ilp; do
   PG_HIP_LIB=$so timeout 200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -m gpu -q -x -p no:cacheprovider > $OUT/tests_$v.log 2>&1
   echo "rc=$? $(tail -1 $OUT/tests_$v.log)"
 done
+echo "== graph replay against eager launches, all workloads (production library)"
+timeout 240 python tools/exp/graph_vs_eager_all.py 2>&1 | tail -9
 echo "== throughput, same box: production library, then each variant (images/s)"
 for m in pixel_snail:1024 gated_pixel_cnn:512 pixel_cnn:1024 vd_vae:512; do
   M=${m%%:*}; B=${m##*:}
