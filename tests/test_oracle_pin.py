@@ -203,3 +203,28 @@ def test_vector_quantizer_live(ref, use_ema, training):
     for key in ("_embedding", "_cluster_size", "_embedding_avg"):
         if key in after:
             assert torch.allclose(out[key[1:]], after[key], rtol=1e-6, atol=1e-7), key
+
+
+@pytest.mark.parametrize("heads,embed,out", [(1, 4, 32), (1, 4, 16), (2, 8, 64), (1, 16, 16), (1, 32, 32), (2, 64, 32),
+                                              (1, 64, 64), (2, 16, 40), (1, 8, 20)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("mc", [False, True], ids=["incl_centre", "strict"])
+def test_attention_module_head_dims_forward_and_gradients(ref, heads, embed, out, mc):
+    """The head dimensions the GPU tier exercises (d_k = embed / heads in {4, 8, 16, 32, 64}, d_v = out / heads in
+    {16, 20, 32, 64}; tests/test_gpu_ops.py ATTN_CASES compare the HIP kernels with `oracle.ops.causal_attention_core`):
+    the oracle against the LIVE reference module — output, input gradient and every parameter gradient."""
+    torch.manual_seed(3)
+    cin = 6
+    attn = ref.nn.CausalAttention(cin, n_heads=heads, embed_channels=embed, out_channels=out, mask_center=mc)
+    x = torch.randn(2, cin, 4, 5)
+    d_o = torch.randn(2, out, 4, 5)
+    xr = x.clone().requires_grad_(True)
+    attn(xr).backward(d_o)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in attn.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    got = oops.causal_attention(xo, None, p, "", heads, embed, mc)
+    got.backward(d_o)
+    assert torch.allclose(attn(x), got.detach(), atol=2e-6, rtol=1e-5)
+    assert torch.allclose(xr.grad, xo.grad, atol=2e-6, rtol=1e-5)
+    for k, v in attn.named_parameters():
+        assert torch.allclose(v.grad, p[k].grad, atol=5e-6, rtol=1e-5), k
