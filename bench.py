@@ -60,6 +60,34 @@ def _causal_gflop_per_img(dense_total, dense_attn, heads, L, dk, dv, blocks, str
     return dense_total - dense_attn + attn
 
 
+def _pixelcnnpp_gflop_per_img(f=160, n_resnet=5, n_mix=10, hw=32):
+    """ALGORITHMIC training GFLOP per image of models.PixelCNNpp (Salimans et al. 2017; the reference has no such model, so
+    BASELINE.md section 3 has no row for it): 3 x the forward multiply-adds of every convolution (forward, data gradient,
+    weight gradient), 2 FLOP per multiply-add, as the table's other rows are counted. A stride-2 convolution is counted
+    at its OUTPUT resolution and a stride-2 transposed convolution at its INPUT resolution — the kernels evaluate both at
+    the fine resolution (stride-1 shifted convolution + subsample / zero-insert, 4 x the algorithmic products), which is
+    NOT counted. Elementwise work (concat_elu, gates, the mixture loss) is not counted either."""
+    macs = 0.0
+    px = [hw * hw, (hw // 2) ** 2, (hw // 4) ** 2]
+    ds, drs = 6, 4  # taps of the down-shifted 2x3 and the down-right-shifted 2x2 windows
+    macs += px[0] * 4 * f * (6 + 3 + 2)  # input layers on [x | ones]: 2x3, 1x3, 2x1
+    for s in range(3):  # up pass
+        u = (2 * f * f + 2 * f * 2 * f) * ds                       # conv_in 2f -> f, conv_out 2f -> 2f
+        ul = (2 * f * f + 2 * f * 2 * f) * drs + 2 * f * f          # + nin (aux = u stream, 2f -> f)
+        macs += px[s] * n_resnet * (u + ul)
+        if s < 2:
+            macs += px[s + 1] * f * f * (ds + drs)                  # stride-2 down-sampling, at the output resolution
+    for s, cnt in enumerate([n_resnet, n_resnet + 1, n_resnet + 1]):  # down pass at px[2], px[1], px[0]
+        r = px[2 - s]
+        u = (2 * f * f + 2 * f * 2 * f) * ds + 2 * f * f            # nin 2f -> f
+        ul = (2 * f * f + 2 * f * 2 * f) * drs + 4 * f * f          # nin on [u | ul short-cut]: 4f -> f
+        macs += r * cnt * (u + ul)
+        if s < 2:
+            macs += r * f * f * (ds + drs)                          # stride-2 up-sampling, at the input resolution
+    macs += px[0] * f * 10 * n_mix
+    return 3 * 2 * macs / 1e9
+
+
 # name -> constructor, kwargs, (C, H, W), lr, per-batch lr decay, SURVEY §8(d) GFLOP / MB per image
 WORKLOADS = {
     "image_gpt": dict(ctor="ImageGPT", kw=dict(in_channels=1, out_channels=1, in_size=28, n_transformer_blocks=8,
@@ -85,7 +113,7 @@ WORKLOADS = {
     # model: the paper's configuration (Salimans et al. 2017: 160 filters, 5 gated resnets per
     # level, 10 mixture components), images mapped to [-1, 1], loss = ops.dmol_loss_sum_mean
     "pixel_cnn_pp": dict(ctor="PixelCNNpp", kw=dict(in_channels=3, n_filters=160, n_resnet=5, n_mix=10),
-                         chw=(3, 32, 32), lr=1e-3, decay=0.999995, gflop=0.0, mbytes=0.0),
+                         chw=(3, 32, 32), lr=1e-3, decay=0.999995, gflop=_pixelcnnpp_gflop_per_img(160, 5, 10, 32), mbytes=0.0),
     # BASELINE.json configs[4]: VAE conv stacks + KL on 64x64x3 (ELBO loss, vae.py:149-159)
     "beta_vae": dict(ctor="BetaVAE", kw=dict(in_channels=3, out_channels=3, beta=4.0, latent_channels=16,
                                              strides=[2, 2, 2, 2], hidden_channels=64, residual_channels=32),
@@ -141,9 +169,16 @@ class Env:
         torch.cuda.synchronize()
 
 
-def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=False):
+def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=False, min_seconds=0.0,
+                 same_batch=False, single=False, keep_params=False):
     """Builds the model, captures the step and times EXACTLY `steps` steps between barriers
-    (max over ranks). Returns the record of this workload at this per-GPU batch."""
+    (max over ranks). Returns the record of this workload at this per-GPU batch.
+
+    min_seconds > 0 (secondary records only, never the headline): if the K timed steps took less, a second window
+    of enough steps to fill `min_seconds` is timed and reported instead (`timed_steps` says how many).
+    same_batch: every rank trains on RANK 0's batch (--dp-parity); single: no gradient exchange even when the job has
+    several ranks (the 1-GPU replica --dp-parity compares with); keep_params: rec["_flat_param"] = the parameters after
+    the last step."""
     import pytorch_generative_amd as pg
     from pytorch_generative_amd import graph, ops, optim, parallel
 
@@ -153,13 +188,13 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
     model.train()
     opt = optim.FlatAdam(model.parameters(), lr=w["lr"], lr_decay=w["decay"])
     reducer = None
-    if env.world > 1 or os.environ.get("PG_BENCH_FORCE_RCCL") == "1":
+    if (env.world > 1 and not single) or os.environ.get("PG_BENCH_FORCE_RCCL") == "1":
         # world > 1 under the nccl backend: the direct-RCCL transport (pg_allreduce_sum), captured inside
         # the step's graph; PG_BENCH_FORCE_RCCL=1 runs the same collective with a communicator of ONE
         # rank (what a 1-GPU box can measure of it)
         reducer = parallel.FlatGradAllReduce(opt, transport="rccl" if env.world == 1 else None)
         reducer.broadcast_parameters(src=0)
-    x = synthetic_batch(batch, env.rank, w["chw"]).to(env.device)
+    x = synthetic_batch(batch, 0 if same_batch else env.rank, w["chw"]).to(env.device)
     if name in ("beta_vae", "vd_vae"):
         def loss_fn(xx, preds):  # ELBO: recon.mean() + kl.mean()
             recon, klm = ops.elbo_terms(preds[0], xx, preds[1])
@@ -202,7 +237,7 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
             torch.cuda.synchronize()
             if require_graph:
                 raise SystemExit(f"--require-graph: capture failed on rank {env.rank}: {fallback}")
-    if env.world > 1:  # every rank must take the same path (graphs imply a different collective order)
+    if env.world > 1 and not single:  # every rank must take the same path (graphs imply a different collective order)
         flag = torch.tensor([1 if launch == "eager" else 0], device=env.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) == 1 and launch != "eager":
@@ -218,6 +253,18 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
         loss = step()
     env.barrier()
     elapsed = time.perf_counter() - t0
+    if min_seconds > 0:  # a thin window (secondary records): time a second one long enough; every rank decides alike
+        t = torch.tensor([elapsed], device=env.device, dtype=torch.float64)
+        if env.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t.item()) < min_seconds:
+            steps = int(min_seconds / (float(t.item()) / steps)) + 1
+            env.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            env.barrier()
+            elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=env.device, dtype=torch.float64)
     per_rank = [elapsed]
     if env.world > 1:
@@ -227,11 +274,13 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     loss_val = float(loss.item())
-    value = batch * env.world * steps / elapsed
+    nranks = 1 if single else env.world  # single: every rank ran its own replica; the rate is ONE replica's
+    value = batch * nranks * steps / elapsed
     dims = w["chw"][0] * w["chw"][1] * w["chw"][2]
     rec = {
-        "images_per_s": value, "ms_per_step": elapsed / steps * 1e3, "per_gpu_batch": batch,
-        "global_batch": batch * env.world, "launch": launch, "graph_fallback": fallback,
+        "images_per_s": value, "ms_per_step": elapsed / steps * 1e3, "timed_steps": steps, "timed_seconds": elapsed,
+        "per_gpu_batch": batch,
+        "global_batch": batch * nranks, "launch": launch, "graph_fallback": fallback,
         # each rank's own clock between the two barriers (the job's rate uses the MAX)
         "per_rank_images_per_s": {"min": batch * steps / max(per_rank), "max": batch * steps / min(per_rank)},
         "grad_exchange": None if reducer is None else
@@ -240,10 +289,14 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
            "with compute (the norm needs every gradient, DESIGN.md section 5)"
            if launch == "hipGraph replay" and reducer.capturable else "eager launch between two graphs"),
         "loss_nats_per_image": loss_val, "bits_per_dim": loss_val / (dims * LN2),
-        # whole step against the per-image algorithmic work of SURVEY.md §8(d)
-        "step_hbm_gbps_algorithmic": value * w["mbytes"] * 1e6 / 1e9,
-        "step_tflops_dense_attention_count": value * w["gflop"] / 1e3,
     }
+    if w["gflop"] > 0:  # whole step against the per-image algorithmic work of SURVEY.md §8(d) (omitted where not accounted)
+        rec["step_tflops_dense_attention_count"] = value * w["gflop"] / 1e3
+    if w["mbytes"] > 0:
+        rec["step_hbm_gbps_algorithmic"] = value * w["mbytes"] * 1e6 / 1e9
+    if keep_params:
+        torch.cuda.synchronize()
+        rec["_flat_param"] = opt.flat_param.detach().clone()
     if "gflop_causal" in w:  # attention counted on the allowed pairs only (what the kernels execute)
         rec["step_tflops"] = value * w["gflop_causal"] / 1e3
         rec["step_frac_of_fp32_peak"] = rec["step_tflops"] / env.world / FP32_PEAK_TFLOPS
@@ -335,17 +388,18 @@ def conv_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
     return {"launch_ms": ms, "flop_per_launch": flop, "tflops": flop / ms / 1e9}
 
 
-def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
+def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32, k=(2, 2, 1, 1)):
     """The weight gradient of the same 2x2 64 -> 64 convolution (conv_wgrad_b3_kernel<4> +
-    wgrad_reduce_kernel behind pg_conv2d_wgrad), timed through the C-ABI with HIP events."""
+    wgrad_reduce_kernel behind pg_conv2d_wgrad), timed through the C-ABI with HIP events.
+    k = (kh, kw, pad_h, pad_w) selects another window (profiling helper: tools/exp/pmc_launch.py)."""
     from pytorch_generative_amd import _lib, ops
 
     lib = _lib.load()
-    spec = ops.ConvSpec(2, 2, 1, 1)
+    spec = ops.ConvSpec(*k)
     g = torch.Generator().manual_seed(12)
     x = torch.randn(batch, cin, hw, hw, generator=g).to(device)
     dy = torch.randn(batch, cout, hw, hw, generator=g).to(device)
-    dw = torch.zeros(cout, cin, 2, 2, device=device)
+    dw = torch.zeros(cout, cin, k[0], k[1], device=device)
     db = torch.zeros(cout, device=device)
     T = len(spec.wg_taps)
     ws_n = lib.pg_conv2d_wgrad_workspace_floats(cout, cin, T)
@@ -354,7 +408,7 @@ def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
 
     def run():
         _lib.check(lib.pg_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), batch, cin,
-                                       hw, hw, cout, hw, hw, 2, 2, T, spec.w_dr, spec.w_dc, spec.w_u, spec.w_v,
+                                       hw, hw, cout, hw, hw, k[0], k[1], T, spec.w_dr, spec.w_dc, spec.w_u, spec.w_v,
                                        ops.ACT_ELU, ws.data_ptr(), ws_n, stream.cuda_stream),
                    "pg_conv2d_wgrad")
 
@@ -363,10 +417,11 @@ def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
     return {"launch_ms": ms, "flop_per_launch": flop, "tflops": flop / ms / 1e9}
 
 
-def measured_traffic(batch, kernel, files=("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):
-    """HBM bytes per launch of the headline's dominant kernel from the committed PMC profiles
-    (collected in separate rocprofv3 --pmc passes, see profiles/README.md); None when no committed
-    profile holds this kernel at this batch."""
+def measured_traffic(batch, kernel, files=("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json",
+                                           "r01_traffic.json")):
+    """(HBM bytes per launch, source file) of a kernel from the COMMITTED PMC profiles (collected in separate
+    rocprofv3 --pmc passes, see profiles/README.md; newest round first); (None, None) when no committed profile holds
+    this kernel at this batch. The figure is not measured by this run — the line names the file it comes from."""
     for name in files:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -376,12 +431,12 @@ def measured_traffic(batch, kernel, files=("r04_traffic.json", "r03_traffic.json
             per = t.get("kernels", {})
             for k, v in per.items():
                 if kernel in k and "hbm_read_bytes" in v:
-                    return v["hbm_read_bytes"] + v["hbm_write_bytes"]
+                    return v["hbm_read_bytes"] + v["hbm_write_bytes"], "profiles/" + name
             if kernel.startswith("attn_dkv") and "attn_bwd_dkv_bytes_per_launch" in t:
-                return t["attn_bwd_dkv_bytes_per_launch"]
+                return t["attn_bwd_dkv_bytes_per_launch"], "profiles/" + name
         except (OSError, ValueError, AttributeError):
             pass
-    return None
+    return None, None
 
 
 def _physical_cores():
@@ -498,7 +553,9 @@ def cpu_baseline_pixel_snail(threads, batch=8):
 
 # fp32-compute / HBM ceilings per GPU in images/s (BASELINE.md §3 = SURVEY.md §8(d)) for the compact records:
 # frac_of_fp32_compute_ceiling = images_per_s / ceiling, ceiling = 157.3 TFLOP/s / (GFLOP per image of WORKLOADS[...])
-CEILINGS = {"pixel_cnn": 163e3, "gated_pixel_cnn": 7.4e3, "beta_vae": 100e3, "vd_vae": 14.3e3}
+CEILINGS = {"pixel_cnn": 163e3, "gated_pixel_cnn": 7.4e3, "beta_vae": 100e3, "vd_vae": 14.3e3,
+            # no BASELINE.md row (not in the reference): the same formula on _pixelcnnpp_gflop_per_img's algorithmic count
+            "pixel_cnn_pp": FP32_PEAK_TFLOPS * 1e3 / WORKLOADS["pixel_cnn_pp"]["gflop"]}
 # dominant kernel of each compact record and its share of the step's kernel time, from the tracked rocprofv3 tables
 # (profiles/r04_<model>_kernel_stats.csv, tools/collect_profiles_r04.sh); None = read the table
 DOMINANT = {}
@@ -519,6 +576,12 @@ def _dominant_kernel(model):
                 "avg_us": float(top["AverageNs"]) / 1e3, "source": f"profiles/r04_{model}_kernel_stats.csv"}
     except (OSError, ValueError, KeyError):
         return None
+OTHER_MIN_SECONDS = 0.5  # every secondary record is timed over at least this long (and at least the headline's steps)
+# how parity is gated (tests/) — quoted in the line so that a rate is never read without it
+PARITY_TEXT = ("fp32 outputs / losses / grad norm within 1e-4 and parameter gradients within 5e-4 OF EACH TENSOR'S MAXIMUM "
+               "(max|got - want| / max|want|, tests/_util.py) against the torch-CPU oracle and the reference's golden "
+               "vectors; causal masks, masked weights and positional encodings bit-exact; K graph replays == K eager steps "
+               "for every timed workload (tests/test_gpu_models.py)")
 OTHER_CONFIGS = [  # (record key, workload, per-GPU batch, BASELINE.json config)
     ("pixel_cnn", "pixel_cnn", 1024, "configs[0]"),
     ("gated_pixel_cnn", "gated_pixel_cnn", 512, "configs[2]"),
@@ -570,6 +633,60 @@ def _self_spawn(n):
     return rc
 
 
+def dp_parity(env, args, run):
+    """`bench.py --gpus N --dp-parity`: DDP's defining equality (reference trainer.py:78-82, train.py:27-44; SURVEY.md
+    section 8(e)) checked ON THE TRANSPORT THE JOB USES (RCCL over xGMI on a multi-GPU node; gloo in the 1-GPU tests):
+    with every rank fed rank 0's batch, the all-reduced mean gradient is the 1-GPU gradient, so after the same number
+    of steps every rank must hold (a) exactly rank 0's parameters and (b) the parameters of a 1-rank run of the same
+    steps — bit for bit when the world size is a power of two (sum of N equal values and the 1/N pre-scale are exact)
+    and the bit-reproducible kernels are selected (ops.set_deterministic). Both runs are timed like any other bench
+    run, so the same command yields the N-GPU rate and the 1-rank rate of one rank (scaling_efficiency_vs_n1)."""
+    import hashlib
+
+    from pytorch_generative_amd import ops
+
+    was = ops.set_deterministic(True)
+    name = args.model or "image_gpt"
+    dp = run(name, args.batch, same_batch=True, keep_params=True)
+    one = run(name, args.batch, same_batch=True, single=True, keep_params=True)
+    ops.set_deterministic(was)
+    mine, alone = dp.pop("_flat_param"), one.pop("_flat_param")
+    root = mine.clone()
+    if env.world > 1:
+        dist.broadcast(root, src=0)
+    stats = torch.tensor([float((mine - root).abs().max()), float((mine - alone).abs().max()),
+                          float(alone.abs().max())], device=env.device, dtype=torch.float64)
+    if env.world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    vs_root, vs_one, pmax = (float(v) for v in stats)
+    pow2 = env.world & (env.world - 1) == 0
+    ok = vs_root == 0.0 and (vs_one == 0.0 if pow2 else vs_one <= 1e-6 * pmax)
+    if env.rank == 0:
+        w = WORKLOADS[name]
+        digest = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16]  # noqa: E731
+        print(json.dumps({
+            "metric": f"training images/sec ({w['ctor']}, {w['chw'][1]}x{w['chw'][2]}x{w['chw'][0]}) with the data-parallel "
+                      "equality check", "value": dp["images_per_s"], "unit": "images/s", "n_gpus": env.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dp["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (every rank: rank 0's batch)",
+            "config": {"workload": f"{w['ctor']}({w['kw']}); {STEP_TEXT}", "per_gpu_batch": args.batch,
+                       "global_batch": args.batch * env.world, "parallelism": f"dp{env.world}", "launch": dp["launch"],
+                       "graph_fallback": dp["graph_fallback"]},
+            "grad_exchange": dp["grad_exchange"],
+            "dp_parity": {
+                "ok": ok, "max_abs_diff_vs_rank0": vs_root, "max_abs_diff_vs_one_rank_run": vs_one,
+                "param_abs_max": pmax, "exact_expected": pow2, "kernels": "bit-reproducible (ops.set_deterministic)",
+                "steps_compared": 2 + args.warmup + args.steps if dp["launch"] != "eager" else args.warmup + args.steps,
+                "params_sha256_16": {"rank0_of_the_job": digest(mine), "one_rank_run": digest(alone)},
+                "what": "max over ranks of |params - rank 0's params| and |params - params of a 1-rank run of the same "
+                        "steps on the same batch| (SURVEY.md section 8(e): same batch on all ranks == 1 GPU)"},
+            "one_rank_run": {"images_per_s": one["images_per_s"], "ms_per_step": one["ms_per_step"], "launch": one["launch"]},
+            "scaling_efficiency_vs_n1": dp["images_per_s"] / (env.world * one["images_per_s"]),
+        }), flush=True)
+    if not ok:
+        raise SystemExit(f"--dp-parity FAILED on rank {env.rank}: |p - p_rank0| = {vs_root:.3e}, |p - p_1rank| = {vs_one:.3e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -587,6 +704,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--n1-value", type=float, default=None,
                     help="images/s of the same headline at --gpus 1: adds scaling_efficiency_vs_n1 to the line")
+    ap.add_argument("--dp-parity", action="store_true",
+                    help="SURVEY.md section 8(e) on the job's own transport: every rank trains on rank 0's batch with the "
+                         "bit-reproducible kernels, then its parameters are compared with rank 0's and with a 1-rank replica "
+                         "of the same steps; prints ONE JSON line with dp_parity and the job's rate")
     ap.add_argument("--require-graph", action="store_true",
                     help="exit non-zero if hipGraph capture fails on any rank instead of falling back to eager")
     args = ap.parse_args()
@@ -595,8 +716,14 @@ def main():
     env = Env(args)
     graph_on = not args.no_graph
 
-    def run(name, batch, steps=None):
-        return run_workload(env, name, batch, steps or args.steps, args.warmup, graph_on, args.require_graph)
+    def run(name, batch, steps=None, **kw):
+        return run_workload(env, name, batch, steps or args.steps, args.warmup, graph_on, args.require_graph, **kw)
+
+    if args.dp_parity:
+        dp_parity(env, args, run)
+        if env.world > 1:
+            dist.destroy_process_group()
+        return
 
     if args.model is not None:  # single-workload helper line
         w = WORKLOADS[args.model]
@@ -626,8 +753,9 @@ def main():
         extras["pixel_snail"] = snail
         others = {}
         for key, name, batch, cfg in OTHER_CONFIGS:  # compact driver-run records of the other BASELINE configs
-            r = run(name, batch, steps=max(5, args.steps // 4))
+            r = run(name, batch, min_seconds=OTHER_MIN_SECONDS)
             others[key] = {"baseline_config": cfg, "images_per_s": r["images_per_s"], "ms_per_step": r["ms_per_step"],
+                           "timed_steps": r["timed_steps"], "timed_seconds": r["timed_seconds"],
                            "per_gpu_batch": batch, "launch": r["launch"],
                            "frac_of_fp32_compute_ceiling": (r["images_per_s"] / env.world / CEILINGS[key]
                                                             if key in CEILINGS else None),
@@ -659,6 +787,7 @@ def main():
             },
             "loss_nats_per_image": head["loss_nats_per_image"],
             "bits_per_dim": head["bits_per_dim"],
+            "parity": PARITY_TEXT,
             "grad_exchange": head["grad_exchange"],
             "per_rank_images_per_s": head["per_rank_images_per_s"],
         }
@@ -672,12 +801,15 @@ def main():
             out["pixel_snail"] = {"workload": WORKLOAD_TEXT["pixel_snail"] + "; " + STEP_TEXT,
                                   "unit": "images/s", "dtype": "f32", **extras["pixel_snail"]}
         if "other_configs" in extras:
-            out["other_configs"] = {"what": "the other BASELINE.json configurations, same step definition, 1/4 of "
-                                            "the headline's timed steps each; ceilings: BASELINE.md §3", "unit": "images/s",
+            out["other_configs"] = {"what": "the other BASELINE.json configurations, same step definition, the headline's "
+                                            f"number of timed steps or {OTHER_MIN_SECONDS:g} s, whichever is longer "
+                                            "(timed_steps / timed_seconds per record); ceilings: BASELINE.md §3 (pixel_cnn_pp: the "
+                                            "same formula on bench._pixelcnnpp_gflop_per_img)", "unit": "images/s",
                                     **extras["other_configs"]}
         if env.world == 1:
             r = attention_kernel_roofline(args.batch, env.device, 4, 4, 4, 28, False)
             dom = "bwd" if "bwd" in r else "dkv"
+            traffic, traffic_src = measured_traffic(args.batch, "attn_bwd_m44_kernel" if dom == "bwd" else "attn_dkv_m44_kernel")
             out["roofline"] = {
                 "bound": "mfma",  # fp32: matrix peak == vector peak == 157.3 TF on gfx950; the
                                   # kernel is 4x4x1-MFMA + v_exp issue bound
@@ -687,7 +819,8 @@ def main():
                 "peak": FP32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": r[dom]["tflops"] / FP32_PEAK_TFLOPS,
-                "traffic": measured_traffic(args.batch, "attn_bwd_m44_kernel" if dom == "bwd" else "attn_dkv_m44_kernel"),
+                "traffic": traffic,
+                "traffic_source": traffic_src,  # a committed rocprofv3 --pmc pass of this kernel at this batch, not this run
                 "launch_ms": r[dom]["launch_ms"],
                 "flop_per_launch": r[dom]["flop_per_launch"],
                 "flop_accounting": "algorithmic: 6 d_k + 4 d_v = 40 FLOP per allowed (query, key) pair, every product once",
@@ -705,11 +838,20 @@ def main():
                 a = attention_kernel_roofline(args.snail_batch, env.device, 1, 4, 32, 32, True)
                 w = wgrad_kernel_roofline(args.snail_batch, env.device)
                 b3_ceiling = BF16_PEAK_TFLOPS / 6.0  # six bf16 MFMAs per fp32 product
-                snail_traffic = measured_traffic(args.snail_batch, "conv_b3p_kernel", ("r04_snail_conv_pmc.json",))
+                # which kernel pg_conv2d_mfma routes this launch to depends on the A/B switches of the environment
+                e = os.environ.get
+                if e("PG_CONV_B3", "1")[:1] == "0":
+                    ck, cdesc = "conv_mfma_kernel", "fp32 MFMA"
+                elif e("PG_CONV_B3P", "1")[:1] == "0":
+                    ck, cdesc = "conv_b3_kernel", "fp32 products as 6 bf16 MFMAs, 16-channel chunks"
+                else:
+                    waves = 4 if e("PG_CONV_B3P_WAVES") == "4" else 8
+                    ck, cdesc = f"conv_b3p_kernel<2, {waves}>", f"fp32 products as 6 bf16 MFMAs, {waves} waves per workgroup"
+                snail_traffic, snail_src = measured_traffic(args.snail_batch, ck.split("<")[0],
+                                                            ("r05_snail_conv_pmc.json", "r04_snail_conv_pmc.json"))
                 out["pixel_snail"]["roofline"] = {
                     "bound": "mfma",
-                    "kernel": "conv_b3p_kernel<2, 8> (pg_conv2d_mfma: 2x2 64->64 convolution, ELU prologue; "
-                              "fp32 products as 6 bf16 MFMAs, 8 waves per workgroup)",
+                    "kernel": f"{ck} (pg_conv2d_mfma: 2x2 64->64 convolution, ELU prologue; {cdesc})",
                     # algorithmic fp32 flops against the scheme's OWN ceiling: bf16 dense peak / 6 (the fp32 matrix peak,
                     # 157.3 TF, is not this kernel's ceiling: it does not run fp32 MFMAs)
                     "achieved": c["tflops"], "peak": b3_ceiling, "unit": "TFLOP/s",
@@ -721,6 +863,7 @@ def main():
                     # (profiles/r04_snail_conv_pmc.json: calibrated on an add kernel in the same process); algorithmic =
                     # x read once + out written once
                     "traffic": snail_traffic,
+                    "traffic_source": snail_src,
                     "traffic_algorithmic": 2.0 * args.snail_batch * 64 * 32 * 32 * 4,
                     "other_kernels": {"conv_wgrad_b3_kernel<4> + wgrad_reduce_kernel": w,
                                       "attn_fwd_k4_kernel": a["fwd"],

@@ -78,7 +78,9 @@ def build(force=False, verbose=True):
         results = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in results]
     rebuilt = any(r for _, r in results)
-    if rebuilt or force or not os.path.exists(LIB):
+    linked = rebuilt or force or not os.path.exists(LIB)  # evaluated BEFORE linking: a library removed by a failed check
+    # is re-linked from up-to-date objects on the next call and must be checked again
+    if linked:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
@@ -87,7 +89,7 @@ def build(force=False, verbose=True):
             print(f"[build] linked {LIB} from {len(objs)} objects")
     elif verbose:
         print(f"[build] {LIB} up to date")
-    if (rebuilt or force) and not ABLATE:
+    if linked and not ABLATE:
         _check_resources(verbose)
     return LIB
 
@@ -104,6 +106,7 @@ def _check_resources(verbose):
     spec = importlib.util.spec_from_file_location("pg_kernel_resources", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    mod.OBJ = OBJ  # the objects of THIS build (a PG_VARIANT build is judged on build_<variant>/, not on build/)
     try:
         rows = mod.check(max_spill=0, verbose=verbose)
         scratch = [r for r in rows if r["scratch_B"]]

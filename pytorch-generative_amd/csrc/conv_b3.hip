@@ -91,6 +91,8 @@ struct B3Plan {
   int ok, CIB, cgs, groups, ksteps, MT;
   size_t w_bytes;
   int w9;  // the plan needs the 9-weight-slot instantiation (conv_b3_kernel<.., W9 = true>)
+  int pipelined;  // set ONLY by the PG_CONV_B3P branch of b3_plan: conv_b3p_kernel takes the launch (the generic planner can
+                  // arrive at the same chunk shape — Cin % 16 != 0 with >= 128 output channels — and stays on conv_b3_kernel)
 };
 
 constexpr int B3_PX_CAP = 352;  // tile pixels (with halo) the LDS plan assumes for T > 1 (T == 1: 256)
@@ -111,7 +113,7 @@ B3Plan b3_plan(int Kc, int M, int T) {
   // (one output chunk only: with 128+ output channels the wide conv_b3_kernel, whose two chunks share ONE staged x tile,
   // measured faster — 247 against 282 us on the 2x2 64 -> 128 at N = 512 — while 64 -> 64 runs 119 -> 108 us here)
   if (p_on && on && T == 4 && MT == 4 && M <= B3_CO_CHUNK && Kc % 8 == 0 && Kc >= 16) {
-    B3Plan pp = {1, 8, 1, 4, 1, 4, (size_t)MT * 3 * 1024, 0};
+    B3Plan pp = {1, 8, 1, 4, 1, 4, (size_t)MT * 3 * 1024, 0, 1};
     return pp;
   }
   double best_cost = 1e30;
@@ -127,7 +129,7 @@ B3Plan b3_plan(int Kc, int M, int T) {
     const double cost = (double)ksteps / CIB + 0.002 / CIB;  // MFMA work per channel, then fewer steps
     if (cost < best_cost) {
       best_cost = cost;
-      best = {1, CIB, cgs, groups, ksteps, MT, wb_s, 0};
+      best = {1, CIB, cgs, groups, ksteps, MT, wb_s, 0, 0};
     }
   }
   static const bool w9_on = []() { const char* e = getenv("PG_CONV_B3_W9"); return !(e && e[0] == '0'); }();
@@ -137,7 +139,7 @@ B3Plan b3_plan(int Kc, int M, int T) {
     const size_t xb = (size_t)cgs * 3 * px * 16, wb = (size_t)ksteps * MT * 3 * 1024;
     if (ksteps <= 5 && groups <= B3_MAXG && xb + wb + (size_t)4 * 16 * 68 * 4 + 1024 <= 80 * 1024 &&
         (long)cgs * px <= 2L * B3_THREADS && (long)ksteps * MT * 192 <= 9L * B3_THREADS)
-      best = {1, 8, cgs, groups, ksteps, MT, wb, 1};
+      best = {1, 8, cgs, groups, ksteps, MT, wb, 1, 0};
   }
   return best;
 }
@@ -293,7 +295,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
       return 0;
     }
   }
-  if (T > 1 && !(T == 4 && pl.CIB == 8 && pl.MT == 4 && pl.ksteps == 1 && !pl.w9)) {
+  if (T > 1 && !pl.pipelined) {
     // conv_b3_kernel: the staged tile may be larger than the format-level 352 pixels if THIS launch's LDS has the room
     // (one 64-channel chunk per workgroup assumed here; the wide kernel is re-checked below and falls back)
     static const bool big_on = []() { const char* e = getenv("PG_CONV_B3_BIGTILE"); return !(e && e[0] == '0'); }();
@@ -311,7 +313,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.TR = TR; a.tile_h = TR + hr; a.tile_w = OW + hc;
   a.plane16 = ((a.tile_h * a.tile_w + 15) / 16) * 16;
   a.tiles_per_img = (OH + TR - 1) / TR;
-  if (T == 4 && pl.CIB == 8 && pl.MT == 4 && pl.ksteps == 1 && !pl.w9 && a.tile_h * a.tile_w <= B3P_PX) {
+  if (pl.pipelined && a.tile_h * a.tile_w <= B3P_PX) {
     // ---- the pipelined kernel: LDS = x[2][3 pieces][plane16] | dump entry | w[2][768] | 4 x epilogue scratch | bias, taps
     for (int g = 0; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }
     for (int t = 0; t < 4; ++t) a.g_tapoff[t] = (tap_dr[t] - a.min_dr) * a.tile_w + (tap_dc[t] - a.min_dc);

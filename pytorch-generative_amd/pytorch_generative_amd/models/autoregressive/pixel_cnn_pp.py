@@ -90,6 +90,11 @@ class PixelCNNpp(base.AutoregressiveModel):
         self._out = pg_nn.Conv2d(f, 10 * n_mix, kernel_size=1)
 
     def forward(self, x):
+        return self._net(x)
+
+    def _net(self, x):
+        """The network body on images in [-1, 1]. forward() and sample() both call THIS, so that a subclass whose
+        forward() rescales its input (reproduce()'s wrapper for [0, 1] loaders) does not rescale the sampler's canvas."""
         n, _, h, w = x.shape
         if h % 4 or w % 4:
             raise ValueError("PixelCNNpp: H and W must be multiples of 4 (two stride-2 levels)")
@@ -157,10 +162,28 @@ class PixelCNNpp(base.AutoregressiveModel):
             for col in range(w):
                 if not bool(unknown[:, :, row, col].any()):
                     continue
-                params = self.forward(canvas)[:, :, row, col]
+                params = self._net(canvas)[:, :, row, col]
                 drawn = self.sample_from_mixture(params, self._n_mix)
                 canvas[:, :, row, col] = torch.where(unknown[:, :, row, col], drawn, canvas[:, :, row, col])
         return canvas
+
+
+class PixelCNNppUnitRange(PixelCNNpp):
+    """PixelCNNpp for loaders that deliver images in [0, 1] (the recipe's model): forward() maps its input to the
+    network's [-1, 1]; sample() takes / returns images in [0, 1] (negative entries of `conditioned_on` are the
+    unknown ones, as in the reference's base.AutoregressiveModel.sample, models/base.py:97-120) and runs the
+    sampler's conditioning forwards on the UNSCALED network body."""
+
+    def forward(self, x):
+        return self._net(x * 2.0 - 1.0)
+
+    @torch.no_grad()
+    def sample(self, n_samples=None, conditioned_on=None, *, image_size=None):
+        if conditioned_on is not None:
+            conditioned_on = torch.where(conditioned_on < 0, torch.full_like(conditioned_on, -2.0),
+                                         conditioned_on * 2.0 - 1.0)
+        out = super().sample(n_samples, conditioned_on, image_size=image_size)
+        return (out + 1.0) * 0.5
 
 
 def dmol_loss(x, _, preds, n_mix=10):
@@ -175,12 +198,8 @@ def reproduce(n_epochs=457, batch_size=16, log_dir="/tmp/run", n_gpus=1, device_
     decay 0.999995 of the paper, the discretized logistic mixture loss. Returns the Trainer."""
     from pytorch_generative_amd import recipes
 
-    class _Wrapped(PixelCNNpp):  # the loaders deliver [0, 1]; the network sees [-1, 1]
-        def forward(self, x):
-            return super().forward(x * 2.0 - 1.0)
-
     return recipes.run(
-        lambda: _Wrapped(in_channels=3, n_filters=n_filters, n_resnet=n_resnet, n_mix=n_mix),
+        lambda: PixelCNNppUnitRange(in_channels=3, n_filters=n_filters, n_resnet=n_resnet, n_mix=n_mix),
         loaders=lambda b: recipes.datasets.get_cifar10_loaders(b), loss_fn=lambda x, y, p: dmol_loss(x, y, p, n_mix),
         lr=1e-3, lr_decay=0.999995, n_epochs=n_epochs, batch_size=batch_size, log_dir=log_dir, n_gpus=n_gpus,
         device_id=device_id, debug_loader=debug_loader)

@@ -47,7 +47,7 @@ def install():
     if _lib is not None:
         return _lib
     if not os.path.exists(SO):
-        raise RuntimeError(f"{SO} missing: run __graft_entry__.build() (or tests.guard.build()) first")
+        build()  # lazily: __graft_entry__.build() normally ships it, but the product build does not depend on it
     alloc = torch.cuda.memory.CUDAPluggableAllocator(SO, "pg_guard_malloc", "pg_guard_free")
     torch.cuda.memory.change_current_allocator(alloc)
     _lib = ctypes.CDLL(SO)

@@ -130,6 +130,32 @@ def test_bench_py_spawns_its_own_ranks():
     assert 0 < lo <= hi and rec["value"] <= 2 * hi * 1.001
 
 
+def test_bench_py_dp_parity_mode():
+    """`python bench.py --gpus 2 --dp-parity`: every rank on rank 0's batch; after the run each rank's parameters equal
+    rank 0's AND those of a 1-rank run of the same steps, bit for bit (world of two: the sum of two equal gradients and
+    the 1/2 pre-scale are exact) — SURVEY.md section 8(e)'s equality on whatever transport the job uses (gloo here, RCCL
+    on a multi-GPU node), printed in the one JSON line next to the rate."""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, PG_FORCE_DEVICE="0", PG_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "16", "--dp-parity"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-4000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    d = rec["dp_parity"]
+    assert rec["n_gpus"] == 2 and d["ok"] and d["exact_expected"]
+    assert d["max_abs_diff_vs_rank0"] == 0.0 and d["max_abs_diff_vs_one_rank_run"] == 0.0
+    assert d["params_sha256_16"]["rank0_of_the_job"] == d["params_sha256_16"]["one_rank_run"]
+    assert d["param_abs_max"] > 0 and rec["one_rank_run"]["images_per_s"] > 0
+    assert 0 < rec["scaling_efficiency_vs_n1"] < 1.5
+
+
 def test_train_py_two_workers_through_trainer(tmp_path):
     """`train.py --gpus 2` end to end on one GPU (PG_FORCE_DEVICE=0, gloo): the spawned workers run the
     model module's reproduce() -> recipes.run -> Trainer(n_gpus=2) -> GraphedTrainStep + FlatGradAllReduce.

@@ -183,3 +183,41 @@ def test_pixelcnnpp_sampler(dev):
     c = model.sample(conditioned_on=cond)
     assert torch.equal(c[:, :, :4], a[:, :, :4]) and float(c.min()) >= -1.0
     assert not torch.equal(c[:, :, 4:], a[:, :, 4:])
+
+
+def test_pixelcnnpp_recipe_model_samples_in_unit_range(dev, tmp_path):
+    """The model reproduce() trains rescales its input in forward() ([0, 1] loaders -> the network's [-1, 1]). Its
+    sample() — what Trainer.sample_one_batch calls — must condition on the UNSCALED network body and return images in
+    [0, 1]: with the same weights and seed it equals the plain model's draw mapped to [0, 1], and one full forward of
+    the recipe model on the returned image sees exactly the canvas the sampler conditioned on."""
+    import pytorch_generative_amd as pg
+    from pytorch_generative_amd.models.autoregressive import pixel_cnn_pp
+
+    torch.manual_seed(0)
+    plain = pg.models.PixelCNNpp(in_channels=3, n_filters=16, n_resnet=1, n_mix=5).to(dev)
+    unit = pixel_cnn_pp.PixelCNNppUnitRange(in_channels=3, n_filters=16, n_resnet=1, n_mix=5).to(dev)
+    unit.load_state_dict(plain.state_dict())
+    torch.manual_seed(11)
+    a = plain.sample(n_samples=2, image_size=(8, 8))
+    torch.manual_seed(11)
+    b = unit.sample(n_samples=2, image_size=(8, 8))
+    assert float(b.min()) >= 0.0 and float(b.max()) <= 1.0
+    assert torch.equal(b, (a + 1.0) * 0.5)
+    with torch.no_grad():
+        assert torch.equal(unit(b), plain(b * 2.0 - 1.0))
+    cond = torch.full((2, 3, 8, 8), -1.0, device=dev)
+    cond[:, :, :4] = b[:, :, :4]
+    torch.manual_seed(5)
+    c = unit.sample(conditioned_on=cond)
+    assert float(c.min()) >= 0.0 and float((c[:, :, :4] - b[:, :, :4]).abs().max()) <= 1e-6
+
+    class _Loader:
+        def __iter__(self):
+            g = torch.Generator().manual_seed(0)
+            return iter([(torch.randint(0, 256, (2, 3, 8, 8), generator=g).float() / 255, torch.zeros(2))])
+
+    t = pixel_cnn_pp.reproduce(n_epochs=1, batch_size=2, log_dir=str(tmp_path), debug_loader=_Loader(),
+                               n_filters=8, n_resnet=1, n_mix=2)
+    assert isinstance(t.model, pixel_cnn_pp.PixelCNNppUnitRange)
+    s = t.model.sample(n_samples=2)
+    assert s.shape == (2, 3, 8, 8) and float(s.min()) >= 0.0 and float(s.max()) <= 1.0

@@ -231,6 +231,117 @@ def test_graphed_step_equals_eager_step(dev):
         assert float((p3 - p1).abs().max()) <= 2e-4 * float(p1.abs().max()) + 1e-6, k
 
 
+class _FixedNoise:
+    """Noise source for the VAE families in the replay tests: the i-th draw of EVERY step is the same pre-drawn
+    tensor (a captured step runs its Python once, so a replay can only ever see the tensors of capture time)."""
+
+    def __init__(self, seed):
+        self.bank, self.i, self.gen = [], 0, torch.Generator().manual_seed(seed)
+
+    def reset(self):
+        self.i = 0
+
+    def __call__(self, shape, device):
+        if self.i == len(self.bank):
+            self.bank.append(torch.randn(shape, generator=self.gen).to(device))
+        eps = self.bank[self.i]
+        assert tuple(eps.shape) == tuple(shape)
+        self.i += 1
+        return eps
+
+
+# every workload bench.py times (bench.WORKLOADS: the exact constructors), at a small batch
+REPLAY_WORKLOADS = [("image_gpt", 8), ("pixel_snail", 4), ("pixel_cnn", 8), ("gated_pixel_cnn", 4),
+                    ("pixel_cnn_pp", 2), ("beta_vae", 4), ("vd_vae", 2), ("image_gpt_repro", 4)]
+
+
+@pytest.mark.parametrize("name,batch", REPLAY_WORKLOADS, ids=[w for w, _ in REPLAY_WORKLOADS])
+def test_k_graph_replays_equal_k_eager_steps(dev, name, batch):
+    """bench.py times hipGraph REPLAYS only (reference step: trainer.py:173-193). K = 4 eager steps against K replays of
+    the captured step for every timed workload, on K different batches:
+      * with the bit-reproducible kernels (ops.set_deterministic): parameters AND the last step's gradients bit-identical,
+      * with the default kernels (the ones the bench times — the fused attention backwards deposit dQ with atomics):
+        losses to 1e-5 relative, gradients to 1e-5 of each tensor's max, parameters to 1e-5 of each tensor's max where
+        the gradient is above its noise floor (Adam turns round-off sign flips of ~0 gradients into +-lr steps).
+    Round 4 shipped a captured step that was right on the first replay and wrong on every later one; this is the net."""
+    import bench
+    import pytorch_generative_amd as pg
+    from pytorch_generative_amd import graph, ops, optim
+    from pytorch_generative_amd.models.vae import vaes
+
+    K = 4
+    w = bench.WORKLOADS[name]
+    xs = [bench.synthetic_batch(batch, 100 + i, w["chw"]).to(dev) for i in range(K)]
+    noise = _FixedNoise(3) if name in ("beta_vae", "vd_vae") else None
+    if name in ("beta_vae", "vd_vae"):
+        def loss_fn(xx, preds):
+            recon, klm = ops.elbo_terms(preds[0], xx, preds[1])
+            return recon + klm
+    elif name == "pixel_cnn_pp":
+        xs = [x * 2.0 - 1.0 for x in xs]
+        loss_fn = lambda xx, preds: ops.dmol_loss_sum_mean(preds, xx, w["kw"]["n_mix"])  # noqa: E731
+    else:
+        loss_fn = lambda xx, preds: ops.bce_with_logits_sum_mean(preds, xx)  # noqa: E731
+
+    def run(graphed):
+        torch.manual_seed(0)
+        model = getattr(pg.models, w["ctor"])(**w["kw"]).to(dev)
+        model.train()
+        opt = optim.FlatAdam(model.parameters(), lr=w["lr"], lr_decay=w["decay"])
+
+        def fwd(x, y=None):
+            if noise is not None:
+                noise.reset()
+            return loss_fn(x, model(x))
+
+        losses = []
+        if graphed:
+            step = graph.GraphedTrainStep(model, opt, None, xs[0], warmup_iters=2, forward_fn=fwd, preserve_state=True)
+            for x in xs:
+                losses.append(float(step(x)))
+        else:
+            for x in xs:
+                opt.zero_grad()
+                loss = fwd(x)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        names = [k for k, p in model.named_parameters() if p.requires_grad]
+        params = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+        return losses, names, params, grads
+
+    if noise is not None:
+        vaes.set_noise_fn(noise)
+    was = ops.set_deterministic(True)
+    try:
+        le, names, pe, ge = run(False)
+        lg, _, pgr, gg = run(True)
+        assert all(v == v and abs(v) < 1e30 for v in lg), lg
+        for a, b in zip(le, lg):  # the loss itself is reduced with fp32 atomics (order varies); it feeds nothing
+            assert abs(a - b) <= 2e-6 * abs(a), (le, lg)
+        for k in names:
+            assert torch.equal(gg[k], ge[k]), f"{name}: gradient of {k} differs between replay {K} and eager step {K}"
+            assert torch.equal(pgr[k], pe[k]), f"{name}: {k} differs after {K} replays / {K} eager steps"
+        ops.set_deterministic(False)
+        lf, _, pf, gf = run(True)  # the kernels the bench times
+        for a, b in zip(le, lf):
+            assert abs(a - b) <= 1e-5 * abs(a), (le, lf)
+        lr = w["lr"]
+        for k in names:
+            gmax = float(ge[k].abs().max())
+            assert float((gf[k] - ge[k]).abs().max()) <= 1e-5 * gmax + 1e-12, f"{name}: default-kernel gradient of {k}"
+            solid = ge[k].abs() > 1e-3 * gmax
+            d = (pf[k] - pe[k]).abs()
+            assert float(d.max()) <= 2 * K * lr * 1.001, k
+            if bool(solid.any()):
+                assert float(d[solid].max()) <= 1e-5 * float(pe[k].abs().max()) + 1e-9, f"{name}: default-kernel {k}"
+    finally:
+        ops.set_deterministic(was)
+        vaes.set_noise_fn(None)
+
+
 @pytest.mark.parametrize("name", _util.vae_golden_names())
 def test_vae_golden_step(dev, name):
     """Beta-VAE / VD-VAE (BASELINE.json configs[4]) against the reference's golden step: logits, per-sample

@@ -86,6 +86,12 @@ CONV_CASES = [
     (40, 32, 28, 28, 64, 1, 1, 0, 0, None, None, "relu", False, True),  # PixelCNN's 1x1 32 -> 64
     (3, 32, 12, 12, 64, 2, 2, 1, 1, "hw", None, "elu", False, True),    # 2x2, two blocks per row
     (3, 64, 20, 20, 128, 1, 3, 0, 1, None, None, None, True, True),     # 1x3, W = 20
+    # 4 taps where the GENERIC planner arrives at the pipelined kernel's chunk shape (Cin % 16 != 0, two output chunks):
+    # stays on conv_b3_kernel (B3Plan::pipelined is set by the PG_CONV_B3P branch only); the data gradient (K = 128,
+    # M = 24 -> two co tiles) takes the generic plan as well
+    (3, 24, 32, 32, 128, 2, 2, 1, 1, "hw", None, "elu", True, True),
+    (3, 40, 16, 32, 64, 2, 2, 1, 1, "hw", None, None, False, True),     # pipelined forward with Cin = 40: five 8-channel chunks
+    (3, 64, 32, 32, 56, 2, 2, 1, 1, "hw", None, "elu", False, True),    # pipelined kernel, partial output chunk (56 of 64)
 ]
 
 
