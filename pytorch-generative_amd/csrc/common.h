@@ -219,34 +219,3 @@ __device__ __forceinline__ void pg_stage_rows_vec4(float* __restrict__ lds, int 
 #else
 #define PG_DBG_BIT(flags, bit) false
 #endif
-
-// EXPERIMENT, not in the production library (-DPG_BUFLOAD: `PG_VARIANT=bufload python build.py` writes
-// lib/libpg_hip_bufload.so): the staging loads of the bf16x3 convolution kernels as raw buffer loads — address =
-// descriptor base (scalar registers) + the slot's byte offset (one VGPR, constant over the launch) + the channel's byte
-// offset (a scalar register) — instead of per-lane 64-bit pointers: the default form costs one v_lshl_add_u64 per load
-// (9 per 8-channel slot) in kernels whose side work is VALU bound. The idiom itself (descriptor flags of gfx950, the
-// out-of-bounds clamp) is pinned by tools/exp/buffer_load_test.hip; the kernels with it have NOT run on a GPU yet
-// (profiles/README.md, round 4, item 14).
-#ifdef PG_BUFLOAD
-// stride 0, num_records = bytes, dword 3 = raw buffer with DATA_FORMAT 32 (gfx90a / gfx94x / gfx950)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float pg_bload(__amdgpu_buffer_rsrc_t rs, int voff_bytes, int soff_bytes) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff_bytes, soff_bytes, 0));
-}
-typedef float pg_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pg_f32x2 pg_bload2(__amdgpu_buffer_rsrc_t rs, int voff_bytes, int soff_bytes) {
-  typedef int i32x2_ __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(pg_f32x2, (i32x2_)__builtin_amdgcn_raw_buffer_load_b64(rs, voff_bytes, soff_bytes, 0));
-}
-__device__ __forceinline__ float4 pg_bload4(__amdgpu_buffer_rsrc_t rs, int voff_bytes, int soff_bytes) {
-  typedef int i32x4_ __attribute__((ext_vector_type(4)));
-  const i32x4_ r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, soff_bytes, 0);
-  return make_float4(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]), __builtin_bit_cast(float, r[2]),
-                     __builtin_bit_cast(float, r[3]));
-}
-__device__ __forceinline__ void pg_bstore(__amdgpu_buffer_rsrc_t rs, float v, int voff_bytes, int soff_bytes) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff_bytes, soff_bytes, 0);
-}
-#endif

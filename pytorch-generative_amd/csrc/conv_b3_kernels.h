@@ -234,18 +234,6 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
 #pragma unroll
   for (int k = 0; k < WS; ++k) wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-#ifdef PG_BUFLOAD
-#define PG_B3_ISSUE_X_LOADS()                                                              \
-    const __amdgpu_buffer_rsrc_t rs_ = pg_rsrc(a.in + (size_t)(n_first + tl_ * nstep) * a.Cin * plane, \
-                                               (unsigned)a.Cin * (unsigned)plane * 4u);    \
-    const int cb_ = ch_ * a.CIB * plane * 4;                                               \
-    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                       \
-      /* a slot without a pixel asks for an address far beyond num_records: no load, no branch (the sum of the offsets is   */ \
-      /* range-checked without wrapping: tools/exp/buffer_load_test.hip (a)); its registers read 0 and go to the dump entry */ \
-      const int vo_ = s_goff[k] >= 0 ? s_goff[k] * 4 : 0x7ffffff0;                         \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = pg_bload(rs_, vo_, cb_ + c * plane * 4); \
-    }
-#else
 #define PG_B3_ISSUE_X_LOADS()                                                              \
     const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
     if (!(PG_DBG_BIT(a.dbg, 1) && (STEP_) > 0))                                            \
@@ -255,7 +243,6 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
         _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = p_[(size_t)c * plane];    \
       }                                                                                    \
     }
-#endif
 #define PG_B3_ISSUE(STEP)                                                                  \
   {                                                                                        \
     const int STEP_ = (STEP);                                                              \
@@ -368,21 +355,12 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       float* outp = a.out + so;
       const bool has_res = a.res != nullptr, has_ds = a.dact_src != nullptr, has_res2 = a.res2 != nullptr;
       // epilogue accesses: channel CC of the chunk at this lane's pixel. PG_EP_LDC: a channel beyond the valid ones reads
-      // channel 0 (value unused). -DPG_BUFLOAD (experiment, common.h): descriptor per operand with num_records = the valid
-      // channels (a read beyond them returns 0, a store there is dropped), lane pixel in one VGPR, channel in the scalar offset
-#ifdef PG_BUFLOAD
-      const unsigned ep_bytes = (unsigned)(fullc ? MT * 16 : cvalid) * (unsigned)Lv * 4u;
-      const int ep_vo = (int)lane_px * 4;
-#define PG_EP_RS(NAME, P) const __amdgpu_buffer_rsrc_t NAME = pg_rsrc((P) ? (const void*)(P) : (const void*)a.in, ep_bytes);
-#define PG_EP_LDC(RS, P, CC) pg_bload(RS, ep_vo, (CC) * Lv * 4)
-#define PG_EP_LDO(RS, P, OFF, CC) pg_bload(RS, ep_vo, (CC) * Lv * 4)
-#define PG_EP_ST(RS, P, CC, V) pg_bstore(RS, V, ep_vo, (CC) * Lv * 4)
-#else
+      // channel 0 (value unused). (A raw-buffer-load form of these accesses and of the staging loads was measured in round 5 and
+      // removed: profiles/README.md, round 5, item 2.)
 #define PG_EP_RS(NAME, P)
 #define PG_EP_LDC(RS, P, CC) ((P) + (size_t)((fullc || (CC) < cvalid_p) ? (CC) : 0) * Lv)[lane_px]
 #define PG_EP_LDO(RS, P, OFF, CC) ((P) + (OFF))[lane_px]  /* OFF: the clamped channel offset, shared by the operands */
 #define PG_EP_ST(RS, P, CC, V) ((P) + (size_t)(CC) * Lv)[lane_px] = (V)
-#endif
       PG_EP_RS(rs_out, outp)
 #define PG_B3_TILE_BODY(M)                                                                       \
   _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
@@ -688,26 +666,12 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
   if (tid < B3_CO_CHUNK) lds[a.b_off + tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
   __syncthreads();  // the zero fill is ordered before the first commit (other threads own the same entries there)
 
-#ifdef PG_BUFLOAD
-  const unsigned img_bytes = (unsigned)a.Cin * (unsigned)plane * 4u;  // one image of the input (< 4 GB)
-#endif
   const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * nchunk * B3P_W4;  // uniform
   float xv[XS][8];
   float4 wv0, wv1 = make_float4(0.f, 0.f, 0.f, 0.f), wv2 = wv1;  // (named, not an array: indexed inside the unrolled slice loop an array stays in scratch memory)
 
   // (tile, chunk) of the step whose loads are issued next
   int l_tl = 0, l_ch = 0;
-#ifdef PG_BUFLOAD
-#define PG_P_ISSUE_X()                                                                         \
-  {                                                                                            \
-    /* one descriptor per image (scalar), the channel in the scalar offset, the slot's byte offset in a VGPR */ \
-    const __amdgpu_buffer_rsrc_t rs_ = pg_rsrc(a.in + (size_t)(n_first + l_tl * nstep) * a.Cin * plane, img_bytes); \
-    const int cb_ = l_ch * 8 * plane * 4;                                                      \
-    _Pragma("unroll") for (int k = 0; k < XS; ++k) {                                           \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = pg_bload(rs_, s_goff[k] * 4, cb_ + c * plane * 4); \
-    }                                                                                          \
-  }
-#else
 #define PG_P_ISSUE_X()                                                                         \
   {                                                                                            \
     const float* src_ = a.in + ((size_t)(n_first + l_tl * nstep) * a.Cin + l_ch * 8) * plane;  \
@@ -716,7 +680,6 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
       _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = (src_ + (size_t)c * plane)[(unsigned)s_goff[k]]; \
     }                                                                                          \
   }
-#endif
 #define PG_P_ISSUE_W()                                                                         \
   {                                                                                            \
     const float4* ws_ = wsrc_b + (size_t)l_ch * B3P_W4;                                        \
@@ -911,23 +874,6 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
         int hrow = 8 * half;
         asm volatile("" : "+v"(ox), "+v"(hrow));
         float q0[4], q1[4], q2[4];
-#ifdef PG_BUFLOAD
-        // one descriptor per operand plane block (64 channels of this image), the lane's pixel + channel-half offset in ONE
-        // VGPR, the channel of the request in the scalar offset
-        // num_records = the chunk's VALID channels: a request beyond them returns 0 / a store there is dropped by the
-        // range check, so no channel predicate is needed on the loads
-        const unsigned blk_bytes = (unsigned)(fullc ? 64 : cvalid) * (unsigned)Lv * 4u;
-        const __amdgpu_buffer_rsrc_t rs0 = pg_rsrc(st0 ? st0 : a.in, blk_bytes), rs1 = pg_rsrc(st1 ? st1 : a.in, blk_bytes),
-                                     rs2 = pg_rsrc(st2 ? st2 : a.in, blk_bytes), rso = pg_rsrc(outp, blk_bytes);
-        const int vo8 = (int)(ox + (unsigned)hrow * (unsigned)Lv) * 4;
-#define PG_P_REQ8(M, H)                                                                    \
-  _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                          \
-    const int cu_ = (M) * 16 + (H) * 4 + c;  /* uniform part of the channel */             \
-    if (st0) q0[c] = pg_bload(rs0, vo8, cu_ * Lv * 4);                                     \
-    if (st1) q1[c] = pg_bload(rs1, vo8, cu_ * Lv * 4);                                     \
-    if (st2) q2[c] = pg_bload(rs2, vo8, cu_ * Lv * 4);                                     \
-  }
-#else
 #define PG_P_REQ8(M, H)                                                                    \
   _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                          \
     const int cc = (M) * 16 + hrow + (H) * 4 + c;                                          \
@@ -936,7 +882,6 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
     if (st1) q1[c] = (st1 + off_)[ox];                                                     \
     if (st2) q2[c] = (st2 + off_)[ox];                                                     \
   }
-#endif
         if (any_op) { PG_P_REQ8(0, 0) }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -1008,11 +953,7 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_b3p_kernel(const B3Args 
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
                 const int cc = m * 16 + hrow + hh * 4 + c;
-#ifdef PG_BUFLOAD
-                if (fullc || cc < cvalid_p) pg_bstore(rso, v[hh * 4 + c], vo8, (m * 16 + hh * 4 + c) * Lv * 4);
-#else
                 if (fullc || cc < cvalid_p) (outp + (size_t)cc * Lv)[ox] = v[hh * 4 + c];
-#endif
               }
             }
           }
@@ -1185,22 +1126,6 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
 #pragma unroll
   for (int c = 0; c < 8; ++c) nxt[c] = f32x2{0.f, 0.f};
 // addresses = uniform base (SGPR pair: image, channel chunk, tile) + 32-bit lane offset: one VGPR per stream
-#ifdef PG_BUFLOAD
-// experiment (common.h): one descriptor per image, (chunk, channel, tile) in the scalar offset, the lane's byte offset in a VGPR
-#define PG_PW_ISSUE(IT, J, DST)                                                                        \
-  {                                                                                                    \
-    const int ni_ = (IT) / tpi;                                                                        \
-    const int t0_ = ((IT) - ni_ * tpi) * 32;                                                           \
-    const bool ok_ = kact && t0_ + 2 * jc < L;                                                         \
-    const __amdgpu_buffer_rsrc_t rs_ = pg_rsrc(a.in + (size_t)ni_ * a.Cin * (size_t)L, (unsigned)a.Cin * (unsigned)L * 4u); \
-    const int vo_ = ok_ ? (int)lane_in * 4 : 0;                                                        \
-    const int cb_ = ((J) * a.CIB * L + t0_) * 4;                                                       \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                    \
-      const f32x2 t_ = pg_bload2(rs_, vo_, cb_ + c * L * 4);                                           \
-      DST[c] = f32x2{ok_ ? t_[0] : 0.f, ok_ ? t_[1] : 0.f};                                            \
-    }                                                                                                  \
-  }
-#else
 #define PG_PW_ISSUE(IT, J, DST)                                                                        \
   {                                                                                                    \
     const int ni_ = (IT) / tpi;                                                                        \
@@ -1214,7 +1139,6 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
       DST[c] = f32x2{ok_ ? t_[0] : 0.f, ok_ ? t_[1] : 0.f};                                            \
     }                                                                                                  \
   }
-#endif
 #define PG_PW_MFMA(ACT)                                                                   \
   _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                         \
     float e_[8];                                                                          \

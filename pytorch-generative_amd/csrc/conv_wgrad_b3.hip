@@ -184,36 +184,6 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_wgrad_b3_kernel(const Wb
   }
   int dok = 0, xok = 0;
 
-#ifdef PG_BUFLOAD
-// experiment (common.h): row loads through two descriptors per tile (dy rows of this channel block, x rows of this channel block),
-// the slot's byte offset in a VGPR that never changes; no 64-bit lane addresses, no opaque copies
-#define PG_WB_ISSUE(TILE)                                                                          \
-  {                                                                                                \
-    const int n_ = (TILE) / a.tiles_per_img;                                                       \
-    const int row0_ = ((TILE) - n_ * a.tiles_per_img) * a.TR;                                      \
-    const float* dyb_ = a.dy + (((long)n_ * a.Cout + co0) * a.H + row0_) * (long)a.W;              \
-    const float* xb_ = a.x + (((long)n_ * a.Cin + ci0) * a.H + (row0_ + a.min_dr)) * (long)a.W;    \
-    const __amdgpu_buffer_rsrc_t rd_ = pg_rsrc(dyb_, 0x7fffffffu), rx_ = pg_rsrc(xb_ - 4, 0x7fffffffu); /* x: 4 floats of slack below for the -1 neighbour */ \
-    dok = 0; xok = 0;                                                                              \
-    _Pragma("unroll") for (int k = 0; k < NDS; ++k) {                                            \
-      if (d_goff[k] >= 0 && row0_ + (d_meta[k] >> 20) < a.H) {                                     \
-        const int vo_ = d_goff[k] * 4;                                                             \
-        dv[k][0] = pg_bload4(rd_, vo_, 0); dv[k][1] = pg_bload4(rd_, vo_ + (((d_half >> k) & 1) ? 0 : 16), 0); \
-        dok |= 1 << k;                                                                             \
-      }                                                                                            \
-    }                                                                                              \
-    _Pragma("unroll") for (int k = 0; k < NXS; ++k) {                                            \
-      const int ir_ = row0_ + a.min_dr + (x_meta[k] >> 20);                                        \
-      if (x_goff[k] >= 0 && ir_ >= 0 && ir_ < a.H) {                                               \
-        const int vo_ = x_goff[k] * 4 + 16;                                                        \
-        xv[k][0] = pg_bload4(rx_, vo_, 0); xv[k][1] = pg_bload4(rx_, vo_ + (((x_half >> k) & 1) ? 0 : 16), 0); \
-        if (want_m1) xe[k][0] = pg_bload(rx_, vo_ + (((x_edge >> k) & 1) ? 0 : -4), 0);            \
-        if (want_p1) xe[k][1] = pg_bload(rx_, vo_ + (((x_edge >> (8 + k)) & 1) ? 12 : 32), 0);     \
-        xok |= 1 << k;                                                                             \
-      }                                                                                            \
-    }                                                                                              \
-  }
-#else
 #define PG_WB_ISSUE(TILE)                                                                          \
   {                                                                                                \
     const int n_ = (TILE) / a.tiles_per_img;                                                       \
@@ -248,7 +218,6 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_wgrad_b3_kernel(const Wb
       }                                                                                            \
     }                                                                                              \
   }
-#endif
 
 #define PG_WB_COMMIT_X(ACT)                                                                        \
   _Pragma("unroll") for (int k = 0; k < NXS; ++k) {                                              \

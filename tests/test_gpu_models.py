@@ -261,8 +261,9 @@ def test_k_graph_replays_equal_k_eager_steps(dev, name, batch):
     the captured step for every timed workload, on K different batches:
       * with the bit-reproducible kernels (ops.set_deterministic): parameters AND the last step's gradients bit-identical,
       * with the default kernels (the ones the bench times — the fused attention backwards deposit dQ with atomics):
-        losses to 1e-5 relative, gradients to 1e-5 of each tensor's max, parameters to 1e-5 of each tensor's max where
-        the gradient is above its noise floor (Adam turns round-off sign flips of ~0 gradients into +-lr steps).
+        losses to 1e-5 relative, gradients to 1e-5 of each tensor's max, parameters to 1e-5 of each tensor's max + 0.5 % of
+        the K * lr a parameter can move, where the gradient is above its noise floor (Adam turns round-off sign flips of ~0
+        gradients into +-lr steps and a 1 % change of a small gradient into ~1 % of lr).
     Round 4 shipped a captured step that was right on the first replay and wrong on every later one; this is the net."""
     import bench
     import pytorch_generative_amd as pg
@@ -336,7 +337,10 @@ def test_k_graph_replays_equal_k_eager_steps(dev, name, batch):
             d = (pf[k] - pe[k]).abs()
             assert float(d.max()) <= 2 * K * lr * 1.001, k
             if bool(solid.any()):
-                assert float(d[solid].max()) <= 1e-5 * float(pe[k].abs().max()) + 1e-9, f"{name}: default-kernel {k}"
+                # a gradient perturbed by <= 1e-5 of its tensor's max is perturbed by <= 1 % where it is "solid" (> 1e-3 of
+                # the max), and Adam's normalised update lr * m / sqrt(v) moves by at most about that fraction of lr per step
+                tol = 1e-5 * float(pe[k].abs().max()) + 5e-3 * K * lr
+                assert float(d[solid].max()) <= tol, f"{name}: default-kernel {k}"
     finally:
         ops.set_deterministic(was)
         vaes.set_noise_fn(None)
