@@ -553,14 +553,16 @@ int pg_wgrad_b3s_launch(const float* x, const float* dy, float* part, long part_
                         int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
                         const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st);
 
-static long wgrad_max_rows(int Cout, int Cin) {
+static long wgrad_max_rows(int Cout, int Cin, int T) {
   const long chunks = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
-  const long g = 512 / chunks;
+  // one tap with Cout % 128 == 0 and Cin % 64 == 0: conv_wgrad_b3's 128 x 64 tiles — half as many (co, ci) chunks, so
+  // twice the partial rows for the same number of workgroups
+  const long g = ((T == 1 && Cout % 128 == 0 && Cin % 64 == 0) ? 1024 : 512) / chunks;
   return g > 64 ? g : 64;
 }
 
 PG_EXPORT size_t pg_conv2d_wgrad_workspace_floats(int Cout, int Cin, int T) {
-  return (size_t)wgrad_max_rows(Cout, Cin) * ((size_t)Cout * Cin * T + Cout);
+  return (size_t)wgrad_max_rows(Cout, Cin, T) * ((size_t)Cout * Cin * T + Cout);
 }
 
 PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int N,
@@ -583,7 +585,7 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
                "pg_conv2d_wgrad: tap %d outside the %dx%d filter", t, KH, KW);
   hipStream_t st = (hipStream_t)stream;
   const long stride = (long)Cout * Cin * T + Cout;
-  const long max_rows = wgrad_max_rows(Cout, Cin);
+  const long max_rows = wgrad_max_rows(Cout, Cin, T);
   // 1x1 convolutions whose shape the bf16x3 kernel takes (Cout % 64 == 0, Cin % 32 == 0, W % 8 == 0) go there
   // first (PG_WGRAD_B3_PW=0: the fp32 direct-fragment kernel below, for A/B)
   static const bool b3_pw = []() { const char* e = getenv("PG_WGRAD_B3_PW"); return !(e && e[0] == '0'); }();

@@ -118,21 +118,32 @@ __device__ __forceinline__ u32x4 shift_left1(const u32x4 d, unsigned int next) {
 // only): a wave owns ONE row tile x one ci tile — half the accumulators, two staging slots per thread instead of three,
 // <= 128 registers: FOUR waves per SIMD (the measurement behind it: conv_b3p_kernel, profiles/README.md round 4 items 5-6 —
 // a wave is serial, so two waves per SIMD leave the matrix pipe idle whenever both stage, wait or store).
-template <int T, int MR = 2, int WV = 4>
+// CIT = x channel tiles (16 channels) per workgroup (round 5). 2: the 32 x channels the kernel was built for. 4 ("big tiles",
+// 8 waves, T <= 2): a wave owns MR / 2 row tiles x TWO ci tiles — 64 x 64 (MR = 2) or 128 x 64 (MR = 4) channels per
+// workgroup. Why: the counters of the 1x1 128 -> 256 launch (profiles/r05_wgrad_pmc.json) show 11.4 VALU instructions per
+// MFMA and the matrix pipe 21 % busy — with one tap every staged value (split into three pieces: ~6 VALU instructions and
+// 3/8 of a 13-cycle ds_write_b128 each) feeds 6 MFMAs per OPPOSITE channel tile only, so a 64 x 32 tile stages
+// 3072 values per 48 MFMAs; 128 x 64 stages 6144 per 192 (half the staging per MFMA, and dy / x are read 2 / 2 instead of
+// 4 / 4 times for 128 -> 256). With several taps the x tile is reused per tap and the small tile is not staging bound.
+template <int T, int MR = 2, int WV = 4, int CIT = 2>
 __global__ void __launch_bounds__(64 * WV, WV / 2) conv_wgrad_b3_kernel(const WbArgs a) {
-  static_assert(WV == 4 || (WV == 8 && MR == 2), "8 waves: 64 dy channels per workgroup");
+  static_assert(WV == 4 || (WV == 8 && (MR == 2 || MR == 4)), "8 waves: 64 or 128 dy channels per workgroup");
+  static_assert(CIT == 2 || (CIT == 4 && WV == 8 && T <= 2), "big tiles: 8 waves, at most 2 taps");
+  static_assert(MR != 4 || CIT == 4, "128 dy channels only with 64 x channels");
   constexpr int THREADS = 64 * WV;
-  constexpr int NDS = WV == 4 ? WB_DS : 2, NXS = WV == 4 ? WB_XS : 2;  // staging slots per thread
-  constexpr int MRW = WV == 4 ? MR : 1;                                // row tiles per wave
+  constexpr int NDS = WV == 4 ? WB_DS : 2, NXS = WV == 4 ? WB_XS : (MR == 4 ? 1 : 2);  // staging slots per thread (128 x 64: the
+                                                                                          // host keeps the x tile within 512 slots)
+  constexpr int MRW = WV == 4 ? MR : MR / 2;                           // row tiles per wave
+  constexpr int NCIW = CIT / 2;                                        // ci tiles per wave
   constexpr int COT = 2 * MR;  // dy channel tiles per workgroup
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = WV == 4 ? (wave & 1) : (wave & 3), wi = WV == 4 ? (wave >> 1) : (wave >> 2);  // row-tile group, ci tile of this wave
-  const int co0 = blockIdx.y * (16 * COT), ci0 = blockIdx.z * WB_CI;
+  const int co0 = blockIdx.y * (16 * COT), ci0 = blockIdx.z * (16 * CIT);
   const int dplane = COT * a.dpb * 16;       // entries per dy piece plane
-  const int xplane = 2 * a.xpb * 16;         // entries per x (copy, piece) plane
+  const int xplane = CIT * a.xpb * 16;       // entries per x (copy, piece) plane
 
   // ---- staging slots: the same (channel, tile row, column block) for every tile
   int d_goff[NDS], d_meta[NDS], x_goff[NXS], x_meta[NXS];  // meta: LDS entry | tile row << 20
@@ -250,13 +261,15 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_wgrad_b3_kernel(const Wb
     }                                                                                              \
   }
 
-  f32x4 acc[MRW][T];
+  f32x4 acc[MRW][NCIW][T];
   f32x4 accb[MRW];
 #pragma unroll
   for (int m = 0; m < MRW; ++m) {
     accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NCIW; ++j)
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[m][j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const bool bias_wave = a.has_bias && wi == 0 && blockIdx.z == 0;  // wave-uniform
   bf16x8 ones;
@@ -267,7 +280,7 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_wgrad_b3_kernel(const Wb
   const int a_base = MRW * wc * a.dpb * 16;
   int b_base[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) b_base[t] = a.x_off16 + a.tap_base[t] + wi * a.xpb * 16;
+  for (int t = 0; t < T; ++t) b_base[t] = a.x_off16 + a.tap_base[t] + wi * NCIW * a.xpb * 16;
 
   int tile = blockIdx.x;
   if (tile < a.total_tiles && !PG_DBG_BIT(a.dbg, 1)) PG_WB_ISSUE(tile)
@@ -329,19 +342,22 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_wgrad_b3_kernel(const Wb
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        bf16x8 bf[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bf[p] = Lk[b_base[t] + p * xplane];
+        for (int j = 0; j < NCIW; ++j) {
+          bf16x8 bf[3];
 #pragma unroll
-        for (int m = 0; m < MRW; ++m) {
-          f32x4 c = acc[m][t];
-          c = MFMA16B(af[m][2], bf[0], c);  // l.h
-          c = MFMA16B(af[m][0], bf[2], c);  // h.l
-          c = MFMA16B(af[m][1], bf[1], c);  // m.m
-          c = MFMA16B(af[m][1], bf[0], c);  // m.h
-          c = MFMA16B(af[m][0], bf[1], c);  // h.m
-          c = MFMA16B(af[m][0], bf[0], c);  // h.h
-          acc[m][t] = c;
+          for (int p = 0; p < 3; ++p) bf[p] = Lk[b_base[t] + j * a.xpb * 16 + p * xplane];
+#pragma unroll
+          for (int m = 0; m < MRW; ++m) {
+            f32x4 c = acc[m][j][t];
+            c = MFMA16B(af[m][2], bf[0], c);  // l.h
+            c = MFMA16B(af[m][0], bf[2], c);  // h.l
+            c = MFMA16B(af[m][1], bf[1], c);  // m.m
+            c = MFMA16B(af[m][1], bf[0], c);  // m.h
+            c = MFMA16B(af[m][0], bf[1], c);  // h.m
+            c = MFMA16B(af[m][0], bf[0], c);  // h.h
+            acc[m][j][t] = c;
+          }
         }
       }
     }
@@ -351,15 +367,18 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_wgrad_b3_kernel(const Wb
 
   // ---- this workgroup's row of partial sums: D[row = (lane >> 4) * 4 + r][col = lane & 15]
   float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
-  const int ci = ci0 + wi * 16 + (lane & 15);
 #pragma unroll
   for (int m = 0; m < MRW; ++m) {
     const int co_b = co0 + (MRW * wc + m) * 16 + (lane >> 4) * 4;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int j = 0; j < NCIW; ++j) {
+      const int ci = ci0 + (wi * NCIW + j) * 16 + (lane & 15);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        prow[((size_t)(co_b + r) * a.Cin + ci) * T + t] = acc[m][t][r];
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          prow[((size_t)(co_b + r) * a.Cin + ci) * T + t] = acc[m][j][t][r];
+    }
     if (bias_wave && (lane & 15) == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) prow[(size_t)a.Cout * a.Cin * T + co_b + r] = accb[m][r];
@@ -630,8 +649,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   static const bool on = []() { const char* e = getenv("PG_WGRAD_B3"); return !(e && e[0] == '0'); }();
   if (!on) return 0;
   if (IH != OH || IW != OW || OW % 4 != 0 || Cout % 32 != 0 || Cin % WB_CI != 0) return 0;
-  const int MR = Cout % WB_CO == 0 ? 2 : 1;  // 64 or 32 dy channels per workgroup
-  const int wb_co = 32 * MR;
+  int MR = Cout % WB_CO == 0 ? 2 : 1;  // 64 or 32 dy channels per workgroup
   if (MR == 1 && T == 1) return 0;  // 1x1 with 32 output channels: too little MFMA work per staged tile (measured on
                                     // PixelCNN's 64 -> 32 layers: 70.9 vs 70.6 k img/s against the fp32 direct-fragment kernel)
   if (!(T == 1 || T == 2 || T == 3 || T == 4 || T == 6 || T == 9)) return 0;
@@ -654,18 +672,32 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   const int PBR = (OW + 7) / 8;  // W % 8 == 4: the last pixel block of a row is half full
   // 64 dy channels per workgroup: 8 waves (four per SIMD, 2 staging slots per thread); PG_WGRAD_B3_WAVES=4 for A/B
   static const int env_waves = []() { const char* e = getenv("PG_WGRAD_B3_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
-  const int waves = (MR == 2 && T <= 4) ? env_waves : 4;  // (6 and 9 taps: the accumulators no longer fit 128 registers)
-  const long slot_cap = waves == 8 ? 2L * 512 : (long)WB_DS * WB_THREADS;
   // tile rows: K steps of 4 pixel blocks, staging slots within the per-thread caps, LDS within budget
+  auto pick_rows = [&](int co_, int ci_, long slot_cap_, long xslot_cap_ = 0) {
+    if (xslot_cap_ == 0) xslot_cap_ = slot_cap_;
+    int best = 0;
+    for (int tr = 1; tr <= OH + 3; ++tr) {
+      if ((tr * PBR) % 4 != 0) continue;
+      const long dslots = (long)co_ * tr * PBR, xslots = (long)ci_ * (tr + hr) * PBR;
+      const long bytes = (3 * dslots + 3L * a.ndc * xslots) * 16;
+      if (dslots > slot_cap_ || xslots > xslot_cap_ || bytes > WB_LDS_BUDGET) break;
+      best = tr;
+      if (tr >= OH) break;
+    }
+    return best;
+  };
+  // big tiles (round 5; at most 2 taps, 8 waves): 64 x channels per workgroup, and 128 dy channels for one tap — the
+  // 1x1 / 2x1 / 1x2 weight gradients are bound by staging (split + LDS writes per MFMA: profiles/r05_wgrad_pmc.json),
+  // not by the matrix pipe. PG_WGRAD_B3_BIG=0 for A/B. A shape whose big tile does not fit LDS keeps the 64 x 32 tile.
+  static const bool big_on = []() { const char* e = getenv("PG_WGRAD_B3_BIG"); return !(e && e[0] == '0'); }();
+  bool big = big_on && MR == 2 && T <= 2 && Cin % 64 == 0;
   int TR = 0;
-  for (int tr = 1; tr <= OH + 3; ++tr) {
-    if ((tr * PBR) % 4 != 0) continue;
-    const long dslots = (long)wb_co * tr * PBR, xslots = (long)WB_CI * (tr + hr) * PBR;
-    const long bytes = (3 * dslots + 3L * a.ndc * xslots) * 16;
-    if (dslots > slot_cap || xslots > slot_cap || bytes > WB_LDS_BUDGET) break;
-    TR = tr;
-    if (tr >= OH) break;
-  }
+  if (big && T == 1 && Cout % 128 == 0 && (TR = pick_rows(128, 64, 2L * 512, 512)) > 0) MR = 4;
+  if (big && TR == 0 && (TR = pick_rows(64, 64, 2L * 512)) == 0) big = false;
+  const int CIT = big ? 4 : 2, wb_ci = 16 * CIT;
+  const int wb_co = 32 * MR;
+  const int waves = big ? 8 : (MR == 2 && T <= 4) ? env_waves : 4;  // (6 and 9 taps: the accumulators no longer fit 128 registers)
+  if (!big) TR = pick_rows(wb_co, wb_ci, waves == 8 ? 2L * 512 : (long)WB_DS * WB_THREADS);
   if (TR == 0) return 0;
   a.x = x; a.dy = dy; a.part = part; a.part_stride = part_stride;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = OH; a.W = OW; a.T = T;
@@ -673,7 +705,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   a.tiles_per_img = (OH + TR - 1) / TR;
   a.total_tiles = N * a.tiles_per_img;
   a.PBR = PBR; a.dpb = TR * PBR; a.xpb = a.xh * PBR; a.ksteps = a.dpb / 4;
-  a.dslots = wb_co * a.dpb; a.xslots = WB_CI * a.xpb;
+  a.dslots = wb_co * a.dpb; a.xslots = wb_ci * a.xpb;
   a.x_off16 = 3 * (2 * MR) * a.dpb * 16;
   a.in_act = in_act; a.has_bias = has_bias;
 #ifdef PG_ABLATE
@@ -682,16 +714,23 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
 #else
   a.dbg = 0;
 #endif
-  const int xplane = 2 * a.xpb * 16;
+  const int xplane = CIT * a.xpb * 16;
   for (int t = 0; t < T; ++t) a.tap_base[t] = copy_of[t] * 3 * xplane + (tap_dr[t] - min_dr) * PBR * 16;
   for (int t = T; t < WB_MAXT; ++t) a.tap_base[t] = 0;
   const size_t shmem = ((size_t)a.x_off16 + (size_t)a.ndc * 3 * xplane) * 16;
-  const int co_chunks = Cout / wb_co, ci_chunks = Cin / WB_CI;
+  const int co_chunks = Cout / wb_co, ci_chunks = Cin / wb_ci;
   long G = 512 / ((long)co_chunks * ci_chunks);
   if (G < 16) G = 16;
   if (G > a.total_tiles) G = a.total_tiles;
   if (G > max_rows) G = max_rows;
   dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
+  if (big) {
+    if (T == 1 && MR == 4) hipLaunchKernelGGL((conv_wgrad_b3_kernel<1, 4, 8, 4>), grid, dim3(512), shmem, st, a);
+    else if (T == 1) hipLaunchKernelGGL((conv_wgrad_b3_kernel<1, 2, 8, 4>), grid, dim3(512), shmem, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_b3_kernel<2, 2, 8, 4>), grid, dim3(512), shmem, st, a);
+    if (hipGetLastError() != hipSuccess) return -1;
+    return (int)G;
+  }
 #define PG_WB(TT)                                                                                        \
   {                                                                                                      \
     if (MR == 2) hipLaunchKernelGGL((conv_wgrad_b3_kernel<TT, 2>), grid, dim3(WB_THREADS), shmem, st, a); \

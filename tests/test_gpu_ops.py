@@ -86,6 +86,14 @@ CONV_CASES = [
     (40, 32, 28, 28, 64, 1, 1, 0, 0, None, None, "relu", False, True),  # PixelCNN's 1x1 32 -> 64
     (3, 32, 12, 12, 64, 2, 2, 1, 1, "hw", None, "elu", False, True),    # 2x2, two blocks per row
     (3, 64, 20, 20, 128, 1, 3, 0, 1, None, None, None, True, True),     # 1x3, W = 20
+    # big tiles of the bf16x3 weight gradient (round 5: at most 2 taps, Cin % 64 == 0 -> 64 x channels per workgroup;
+    # one tap with Cout % 128 == 0 -> 128 x 64 channels)
+    (10, 128, 32, 32, 256, 1, 1, 0, 0, None, None, None, False, True),   # GatedPixelCNN's 1x1 128 -> 256: 160 tiles over 128 walkers
+    (6, 64, 28, 28, 128, 1, 1, 0, 0, None, None, "relu", False, True),   # 128 x 64, half pixel blocks (W = 28)
+    (3, 64, 12, 16, 64, 2, 1, 2, 0, "hw", None, "elu", False, True),     # 64 x 64, two taps (row shift)
+    (5, 128, 32, 32, 256, 2, 1, 2, 0, "hw", None, None, False, True),    # GatedPixelCNN's 2x1 128 -> 256
+    (3, 128, 10, 32, 128, 1, 2, 0, 1, "hw", None, None, True, False),    # 1x2: two column copies, no bias
+    (2, 192, 8, 8, 128, 1, 1, 0, 0, None, None, "gelu", False, True),    # 8-wide rows: TR = 8, three ci chunks
     # 4 taps where the GENERIC planner arrives at the pipelined kernel's chunk shape (Cin % 16 != 0, two output chunks):
     # stays on conv_b3_kernel (B3Plan::pipelined is set by the PG_CONV_B3P branch only); the data gradient (K = 128,
     # M = 24 -> two co tiles) takes the generic plan as well
