@@ -112,7 +112,10 @@ B3Plan b3_plan(int Kc, int M, int T) {
   static const bool p_on = []() { const char* e = getenv("PG_CONV_B3P"); return !(e && e[0] == '0'); }();
   // (one output chunk only: with 128+ output channels the wide conv_b3_kernel, whose two chunks share ONE staged x tile,
   // measured faster — 247 against 282 us on the 2x2 64 -> 128 at N = 512 — while 64 -> 64 runs 119 -> 108 us here)
-  if (p_on && on && T == 4 && MT == 4 && M <= B3_CO_CHUNK && Kc % 8 == 0 && Kc >= 16) {
+  // Round 5: also several output chunks when their number is odd-sized for the wide kernel (M % 128 != 0, e.g. PixelCNN++'s 160 / 320
+  // filters): conv_b3_kernel then runs one chunk per workgroup as well, so both stage x once per chunk. PG_CONV_B3P_MULTI=0 for A/B.
+  static const bool pm_on = []() { const char* e = getenv("PG_CONV_B3P_MULTI"); return !(e && e[0] == '0'); }();
+  if (p_on && on && T == 4 && MT == 4 && (M <= B3_CO_CHUNK || (pm_on && M % (2 * B3_CO_CHUNK) != 0)) && Kc % 8 == 0 && Kc >= 16) {
     B3Plan pp = {1, 8, 1, 4, 1, 4, (size_t)MT * 3 * 1024, 0, 1};
     return pp;
   }

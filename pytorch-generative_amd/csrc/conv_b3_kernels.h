@@ -72,7 +72,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int B3_THREADS = 256;
 constexpr int B3_CO_CHUNK = 64;
 constexpr int B3_XS = 4;       // (pixel, channel-group) staging slots per thread per step: 8 loads each
-constexpr int B3_WS = 6;       // float4 weight-fragment slots per thread per step
+constexpr int B3_WS = 6;       // float4 weight-fragment slots per thread per step of the FORMAT-level plan (conv_b3.hip; the kernel itself
+                               // has moved its weight slabs by LDS-DMA since round 5 and holds no weight registers)
 
 
 
@@ -141,7 +142,6 @@ __device__ __forceinline__ void split8t(const float (&x)[8], u32x4& h, u32x4& m,
 template <bool GL, int MT, int NT, int CG, bool MS = false, bool W9 = false>
 __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kernel(const B3Args a) {
   constexpr int THREADS = B3_THREADS * CG;
-  constexpr int WS = W9 ? 9 : B3_WS;
   constexpr int XS = W9 ? 2 : (CG == 1 ? B3_XS : (B3_XS + 1) / 2);  // the tile's slots over twice the threads
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
@@ -219,20 +219,39 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
   __syncthreads();  // the zero fill is ordered before the first commit (other threads own the same entries there)
 
   // weight slab of this thread's chunk: threads [256 c, 256 c + 256) load and commit chunk c's slab
-  const int wt = CG == 1 ? tid : tid & (B3_THREADS - 1);
   const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) +
                          (size_t)(CG == 1 ? blockIdx.y : blockIdx.y * CG + (tid >> 8)) * nchunk * a.wslab4;
-  // 64 output channels: the slab (ksteps x 4 tiles x 3 pieces x 64 lanes) is a whole number of 256-thread rounds,
-  // so the weight slots are predicated by a uniform count instead of one lane mask per slot
-  const int nwk = a.wslab4 >> 8;
   float xv[XS][8];
-  float4 wv[WS];
 #pragma unroll
   for (int k = 0; k < XS; ++k)
 #pragma unroll
     for (int c = 0; c < 8; ++c) xv[k][c] = 0.f;
-#pragma unroll
-  for (int k = 0; k < WS; ++k) wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Round 5: the weight slab of a step goes from global memory STRAIGHT INTO LDS (global_load_lds_dwordx4: 1 KB per
+  // wave-instruction, destination = wave-uniform base + lane * 16 — exactly the ready-made fragment layout
+  // [k step][co tile][piece][lane]) instead of through 6 float4 registers per thread + 6 ds_write_b128. Measured with the
+  // kernel's clocks (profiles/r05_conv_wide_phase_clocks.txt): the commit phase of the wide kernel is bound by the
+  // VGPR -> LDS store path (12 x 13-cycle ds_write_b128 per wave and step, half of them weights) and the issue phase spends
+  // 1 245 cycles on 22 load instructions. 25-30 registers fewer per instantiation; same-box A/B of the two libraries:
+  // GatedPixelCNN 5.88 -> 6.00 k img/s, PixelCNN++ 621 -> 629, every other workload +0.3 ... +0.6 % (profiles/README.md, round 5).
+  // The DMA is issued by inline asm (the compiler never emits it, and its counter model must not see it: a visible DMA in
+  // flight turns every later wait for an ordinary load into vmcnt(0)).
+  // This wave's 1 KB pieces of its chunk's slab: piece = (wave of the chunk) + 4 j.
+  const int wg_pieces = a.wslab4 >> 6;                       // 1 KB pieces per slab (a slab is k steps x MT x 3 pieces x 1 KB)
+  const float4* wg_src = wsrc_b + (size_t)wave * 64 + lane;  // + chunk * wslab4 + 256 j
+  const unsigned wg_dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds) +  // LDS byte address of this wave's piece 0
+                          (unsigned)(a.w_off16 + (CG == 1 ? 0 : cgp * a.wslab4) + wave * 64) * 16u;
+#define PG_B3_WGLDS(STEP)                                                                  \
+  {                                                                                        \
+    const int tlw_ = (STEP) / nchunk;                                                      \
+    const int chw_ = (STEP) - tlw_ * nchunk;                                               \
+    const float4* g_ = wg_src + (size_t)chw_ * a.wslab4;                                   \
+    for (int j = wave; j < wg_pieces; j += 4) {                                            \
+      unsigned keep_;                                                                      \
+      const unsigned d_ = wg_dst + (unsigned)(j - wave) * 1024u;                           \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep_) : "v"(g_ + (size_t)(j - wave) * 64), "s"(d_) : "memory");  \
+    }                                                                                      \
+  }
 
 #define PG_B3_ISSUE_X_LOADS()                                                              \
     const float* src_ = a.in + ((size_t)(n_first + tl_ * nstep) * a.Cin + ch_ * a.CIB) * plane; \
@@ -243,16 +262,14 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
         _Pragma("unroll") for (int c = 0; c < 8; ++c) xv[k][c] = p_[(size_t)c * plane];    \
       }                                                                                    \
     }
+#define PG_B3_ISSUE_W()
+#define PG_B3_COMMIT_W()
 #define PG_B3_ISSUE(STEP)                                                                  \
   {                                                                                        \
     const int STEP_ = (STEP);                                                              \
     const int tl_ = (STEP) / nchunk;                                                       \
     const int ch_ = (STEP) - tl_ * nchunk;                                                 \
-    const float4* ws_ = wsrc_b + (size_t)ch_ * a.wslab4;                                   \
-    _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                    \
-      const int i = wt + k * B3_THREADS;                                                   \
-      if (MT == 4 ? k < nwk : i < a.wslab4) wv[k] = ws_[i];                                \
-    }                                                                                      \
+    PG_B3_ISSUE_W()                                                                        \
     PG_B3_ISSUE_X_LOADS()                                                                  \
   }
 #define PG_B3_COMMIT_X(ACT)                                                                \
@@ -276,24 +293,21 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       case PG_ACT_GELU: if constexpr (GL) { PG_B3_COMMIT_X(PG_ACT_GELU) } break;                                 \
       default:          PG_B3_COMMIT_X(PG_ACT_NONE) break;                                 \
     }                                                                                      \
-    float4* wdst_ = reinterpret_cast<float4*>(lds16 + a.w_off16) +                         \
-                    (CG == 1 ? 0 : (tid >> 8) * a.wslab4);                                 \
-    _Pragma("unroll") for (int k = 0; k < WS; ++k) {                                    \
-      const int i = wt + k * B3_THREADS;                                                   \
-      if (MT == 4 ? k < nwk : i < a.wslab4) wdst_[i] = wv[k];                              \
-    }                                                                                      \
+    PG_B3_COMMIT_W()                                                                       \
   }
 
   // Pipeline over the (tile, channel chunk) steps of this workgroup, ONE x / weight tile in LDS:
-  //   MFMA(s) | barrier | commit(s+1) (its loads were issued a whole step earlier) |
-  //   issue loads(s+2) | [epilogue of the tile that ended at s, in per-wave scratch] | barrier
+  //   MFMA(s) | barrier | weight slab(s+1) by LDS-DMA, commit x(s+1) (its loads were issued a whole step earlier) under it |
+  //   issue x loads(s+2) | [epilogue of the tile that ended at s, in per-wave scratch] | barrier
   // so loads have a whole step (+ an epilogue) to land and the epilogue's stores fly under MFMA(s+1).
   constexpr int EPS = 68;
   const float* bl = lds + a.b_off + (CG == 1 ? 0 : cgp * B3_CO_CHUNK);
   const bf16x8* xl = reinterpret_cast<const bf16x8*>(lds16);
   const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds16 + a.w_off16) + (CG == 1 ? 0 : cgp * a.wslab4) + lane;
   PG_B3_ISSUE(0)
+  PG_B3_WGLDS(0)
   PG_B3_COMMIT_ALL()
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slab has landed
   __syncthreads();
   if (nsteps > 1) PG_B3_ISSUE(1)
   PG_PROF_DECL
@@ -328,9 +342,14 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       }
     }
     PG_PROF_MARK(0)
+    // step + 1's x loads were issued a whole step ago: retire them HERE (a modelled s_waitcnt vmcnt(0)), so that the commit
+    // below needs no wait of its own while the slab DMA — invisible to the compiler's counter model — is in flight
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();  // every wave is done with the tiles: the next commit may overwrite them
     PG_PROF_MARK(1)
+    if (more) PG_B3_WGLDS(step + 1)
     if (more && !PG_DBG_BIT(a.dbg, 2)) PG_B3_COMMIT_ALL()
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slab has landed (nothing else is in flight)
     PG_PROF_MARK(2)
     if (step + 2 < nsteps) PG_B3_ISSUE(step + 2)
     PG_PROF_MARK(3)
@@ -549,6 +568,9 @@ if constexpr (GL) {
   }
   PG_PROF_DUMP(THREADS / 64, wave_all, nsteps)
 #undef PG_B3_ISSUE
+#undef PG_B3_ISSUE_W
+#undef PG_B3_COMMIT_W
+#undef PG_B3_WGLDS
 #undef PG_B3_ISSUE_X_LOADS
 #undef PG_B3_COMMIT_X
 #undef PG_B3_COMMIT_ALL

@@ -100,6 +100,9 @@ CONV_CASES = [
     (3, 24, 32, 32, 128, 2, 2, 1, 1, "hw", None, "elu", True, True),
     (3, 40, 16, 32, 64, 2, 2, 1, 1, "hw", None, None, False, True),     # pipelined forward with Cin = 40: five 8-channel chunks
     (3, 64, 32, 32, 56, 2, 2, 1, 1, "hw", None, "elu", False, True),    # pipelined kernel, partial output chunk (56 of 64)
+    # round 5: the pipelined kernel with several output chunks when the wide kernel does not apply (Cout % 128 != 0)
+    (3, 64, 32, 32, 160, 2, 2, 1, 1, "hw", None, "elu", True, True),    # PixelCNN++'s widths: chunks of 64 + 64 + 32
+    (70, 320, 16, 16, 320, 2, 2, 1, 1, "hw", None, None, False, True),  # 320 -> 320 on 16 x 16, several tiles per workgroup
 ]
 
 

@@ -23,10 +23,13 @@ NAMES = ["mfma", "bar1", "commit", "issue", "epilogue", "bar2", "total", "steps"
 
 
 def one(batch, cin, cout, hw, k, act):
-    spec = ops.ConvSpec(k, k, k // 2 if k == 3 else 1, k // 2 if k == 3 else 1)
+    """k: an int (k x k window: 3 -> pad 1, else pad 1 cropped) or (kh, kw, pad_h, pad_w); output cropped to hw x hw."""
+    if isinstance(k, int):
+        k = (k, k, k // 2 if k == 3 else (1 if k > 1 else 0), k // 2 if k == 3 else (1 if k > 1 else 0))
+    spec = ops.ConvSpec(*k)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(batch, cin, hw, hw, generator=g).to(dev)
-    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.05).to(dev)
+    wt = (torch.randn(cout, cin, k[0], k[1], generator=g) * 0.05).to(dev)
     bias = torch.zeros(cout, device=dev)
     out = torch.empty(batch, cout, hw, hw, device=dev)
     fmt = ops._use_mfma(lib, cin, cout, spec, (hw, hw), hw)
@@ -57,7 +60,7 @@ def one(batch, cin, cout, hw, k, act):
     p = prof.view(-1, 8).cpu()
     p = p[p[:, 6] > 0].double()
     mean = p.mean(0)
-    print(f"N={batch} {cin}->{cout} {k}x{k} {hw}x{hw} act={act}: {us:.1f} us/launch (no clocks), {p.shape[0]} waves, "
+    print(f"N={batch} {cin}->{cout} {k[0]}x{k[1]} {hw}x{hw} act={act}: {us:.1f} us/launch (no clocks), {p.shape[0]} waves, "
           f"{int(mean[7])} steps/wave, wave lifetime {mean[6]:.0f} cycles (min {p[:, 6].min():.0f} max {p[:, 6].max():.0f})")
     for i in range(6):
         print(f"    {NAMES[i]:9s} {mean[i]:9.0f} cycles = {100 * mean[i] / mean[6]:5.1f} %  per step {mean[i] / mean[7]:7.0f}"
@@ -66,6 +69,15 @@ def one(batch, cin, cout, hw, k, act):
     print(f"    prologue+rest {rest:9.0f} cycles = {100 * rest / mean[6]:5.1f} %")
 
 
+if __name__ == "__main__" and sys.argv[1:2] == ["gated"]:
+    # the shapes of GatedPixelCNN's layers (wide kernel, batch 512) and PixelCNN++'s (160 filters, batch 64)
+    for cin, cout, k in ((256, 256, 1), (128, 256, 1), (128, 128, 1), (128, 256, (1, 2, 0, 1)), (128, 256, (2, 1, 1, 0)),
+                         (128, 128, (1, 3, 0, 1))):
+        one(512, cin, cout, 32, k, ops.ACT_NONE)
+    one(64, 320, 160, 32, (2, 3, 1, 1), ops.ACT_NONE)
+    one(64, 320, 320, 32, (2, 2, 1, 1), ops.ACT_NONE)
+    one(128, 32, 32, 64, 3, ops.ACT_NONE)
+    sys.exit(0)
 if __name__ == "__main__":
     batches = [int(v) for v in sys.argv[1:]] or [512]
     for b in batches:
