@@ -491,6 +491,12 @@ PG_EXPORT int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, i
   if (pg_b3_applicable(Cin, Cout, T, OH, OW, hr, hc)) return PG_CONV_FMT_B3;
   if ((IW % 4) != 0) return 0;  // float4 staging slots
   if (OH * OW < 16) return 0;  // tiny images (VD-VAE's 2x2 / 1x1 levels): launch bound either way
+  // Round 5: the 3- / 4-channel image convolutions with >= 32 output channels run on the fp32-MFMA kernel too (K padded to 4
+  // per tap: the arithmetic is nothing, the kernel's transposed epilogue is what counts — the VALU tap kernel wrote their
+  // 64-channel outputs at ~1.1 TB/s): beta-VAE 45.7 -> 47.9 k img/s, PixelSNAIL / GatedPixelCNN +0.7 % (same box;
+  // PG_CONV_MFMA_MIN_CIN=8 restores the old routing for A/B, =1 adds the one-channel input layers)
+  static const int min_cin = []() { const char* e = getenv("PG_CONV_MFMA_MIN_CIN"); const int v = e ? atoi(e) : 3; return v >= 1 ? v : 3; }();
+  if (Cin < 8 && Cin >= min_cin && Cout >= 32) return PG_CONV_FMT_F32;
   return (Cin >= 8 && Cout >= 8) ? PG_CONV_FMT_F32 : 0;
 }
 
