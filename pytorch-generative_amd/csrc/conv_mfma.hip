@@ -494,8 +494,9 @@ PG_EXPORT int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, i
   // Round 5: the 3- / 4-channel image convolutions with >= 32 output channels run on the fp32-MFMA kernel too (K padded to 4
   // per tap: the arithmetic is nothing, the kernel's transposed epilogue is what counts — the VALU tap kernel wrote their
   // 64-channel outputs at ~1.1 TB/s): beta-VAE 45.7 -> 47.9 k img/s, PixelSNAIL / GatedPixelCNN +0.7 % (same box;
-  // PG_CONV_MFMA_MIN_CIN=8 restores the old routing for A/B, =1 adds the one-channel input layers)
-  static const int min_cin = []() { const char* e = getenv("PG_CONV_MFMA_MIN_CIN"); const int v = e ? atoi(e) : 3; return v >= 1 ? v : 3; }();
+  // PG_CONV_MFMA_MIN_CIN=8 restores the old routing for A/B. The ONE-channel input layers stay on the tap kernel: ImageGPT's
+  // 3x3 1 -> 16 measured no different, PixelCNN's 24-tap 7x7 does not fit this kernel's tap table)
+  static const int min_cin = []() { const char* e = getenv("PG_CONV_MFMA_MIN_CIN"); const int v = e ? atoi(e) : 3; return v >= 3 ? v : 3; }();
   if (Cin < 8 && Cin >= min_cin && Cout >= 32) return PG_CONV_FMT_F32;
   return (Cin >= 8 && Cout >= 8) ? PG_CONV_FMT_F32 : 0;
 }
