@@ -838,8 +838,9 @@ def main():
                 a = attention_kernel_roofline(args.snail_batch, env.device, 1, 4, 32, 32, True)
                 w = wgrad_kernel_roofline(args.snail_batch, env.device)
                 b3_ceiling = BF16_PEAK_TFLOPS / 6.0  # six bf16 MFMAs per fp32 product
-                # which kernel pg_conv2d_mfma routes this launch to depends on the A/B switches of the environment
-                e = os.environ.get
+                # which kernel pg_conv2d_mfma routes this launch to: the production library always takes the default route (its
+                # A/B switches are compiled out, csrc/common.h PG_AB_ENV); only a variant library (PG_HIP_LIB) reads the environment
+                e = os.environ.get if os.environ.get("PG_HIP_LIB") else (lambda k, d=None: d)
                 if e("PG_CONV_B3", "1")[:1] == "0":
                     ck, cdesc = "conv_mfma_kernel", "fp32 MFMA"
                 elif e("PG_CONV_B3P", "1")[:1] == "0":

@@ -553,7 +553,7 @@ int check_dims(const char* who, int N, int heads, int L, int dk, int dv, int str
 // VALU row-owner kernels above (A/B measurements, tests of both paths).
 static bool use_mfma_attention() {
   static const bool on = []() {
-    const char* e = getenv("PG_ATTN_MFMA");
+    const char* e = PG_AB_ENV("PG_ATTN_MFMA");
     return !(e && e[0] == '0');
   }();
   return on;

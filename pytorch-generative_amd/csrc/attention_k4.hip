@@ -738,7 +738,7 @@ int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st) {
   // waves, each half as long (measured at batch 128: 1 wave per SIMD ran 2x over the MFMA bound).
   // Rows per block otherwise follow the register file: the resident operands (q / k / v / dO fragments of every
   // 16-row group of the block) must fit — 32 rows from d_k = 16 on, 16 rows when d_k or d_v is 64.
-  static const int force_qb = []() { const char* e = getenv("PG_ATTN_K4_QB"); return e ? atoi(e) : 0; }();
+  static const int force_qb = []() { const char* e = PG_AB_ENV("PG_ATTN_K4_QB"); return e ? atoi(e) : 0; }();
   int qb;
   if (small_k && dv <= 32) {
     qb = ((long)units * (((a.L + 63) / 64 + 1) / 2) >= 3 * 1024) ? 4 : 2;

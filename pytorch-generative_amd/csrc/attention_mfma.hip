@@ -994,7 +994,7 @@ static void attn_waves(int* w) {
   // the main thread and from the autograd thread)
   static const AttnWaveCfg cfg = []() {
     AttnWaveCfg c = {{4, 8, 4}};
-    if (const char* e = getenv("PG_ATTN_WAVES")) {
+    if (const char* e = PG_AB_ENV("PG_ATTN_WAVES")) {
       int f = 0, q = 0, k = 0;
       if (sscanf(e, "%d,%d,%d", &f, &q, &k) == 3 && f >= 1 && f <= 8 && q >= 1 && q <= 8 && k >= 1 && k <= 8)
         c = {{f, q, k}};
@@ -1010,7 +1010,7 @@ int pg_attn_k4_launch(int which, const PgAttnArgs& a, hipStream_t st);  // atten
 // pg_attn_fused_bwd(0) selects the two-kernel backward, whose results are bit-reproducible
 #include <atomic>
 static std::atomic<int>& fused_bwd_flag() {
-  static std::atomic<int> flag([]() { const char* e = getenv("PG_ATTN_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }());
+  static std::atomic<int> flag([]() { const char* e = PG_AB_ENV("PG_ATTN_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }());
   return flag;
 }
 static bool pg_attn_fused_bwd_enabled() { return fused_bwd_flag().load(std::memory_order_relaxed) != 0; }
@@ -1026,7 +1026,7 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
     if (!pg_attn_fused_bwd_enabled()) return 0;
     if (a0.dk_dim != 4 || a0.dv_dim != 4) {
       // d_k = 4, d_v = 16 / 32 (PixelSNAIL): attn_bwd_k4_kernel (round 4); PG_ATTN_FUSED_BWD_K4=0 for A/B
-      static const bool k4_fused = []() { const char* e = getenv("PG_ATTN_FUSED_BWD_K4"); return !(e && e[0] == '0'); }();
+      static const bool k4_fused = []() { const char* e = PG_AB_ENV("PG_ATTN_FUSED_BWD_K4"); return !(e && e[0] == '0'); }();
       return k4_fused ? pg_attn_k4_launch(which, a0, st) : 0;
     }
   }
@@ -1039,13 +1039,13 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   // dK/dV: 10 planes; plus the ones chunk
   // dK/dV score tile on the bf16x3 MFMA (default; PG_ATTN_DKV_BF16=0 selects the all-fp32 variant:
   // measured 0.534-0.545 ms vs 0.515-0.521 ms per launch at batch 1024)
-  static const bool dkv_bf16 = []() { const char* e = getenv("PG_ATTN_DKV_BF16"); return !(e && e[0] == '0'); }();
+  static const bool dkv_bf16 = []() { const char* e = PG_AB_ENV("PG_ATTN_DKV_BF16"); return !(e && e[0] == '0'); }();
   const size_t planes = which == PG_ATTN_BWD ? 21
                         : which == PG_ATTN_DKV ? (dkv_bf16 ? 18 : 10) : (which == PG_ATTN_DQ ? 20 : 12);
   int wcfg[3];
   attn_waves(wcfg);
   static const int bwd_waves = []() {
-    const char* e = getenv("PG_ATTN_BWD_WAVES");
+    const char* e = PG_AB_ENV("PG_ATTN_BWD_WAVES");
     const int v = e ? atoi(e) : 8;
     return v >= 1 && v <= 8 ? v : 8;
   }();
@@ -1053,11 +1053,11 @@ int pg_attn_mfma_launch(int which, const PgAttnArgs& a0, hipStream_t st) {
   // fused backward: + 1 KB of transposition scratch per wave
   const size_t shmem = planes * (size_t)a.lp * sizeof(float) + (which == PG_ATTN_BWD ? 8 * 1024 : 16);
   if (shmem > 160 * 1024) return 0;
-  if (which == PG_ATTN_DKV && dkv_bf16 && !getenv("PG_ATTN_WAVES")) W = 8;
+  if (which == PG_ATTN_DKV && dkv_bf16 && !PG_AB_ENV("PG_ATTN_WAVES")) W = 8;
   // few (n, head) units (the reference's default batch 64 x 4 heads = one workgroup per CU): the launch
   // lasts as long as its most loaded wave, so the forward kernel also spreads its 13 query blocks over
   // 8 waves (longest list 94 -> 58 cost units; with many units per CU 4-wave workgroups pack better)
-  if (which == PG_ATTN_FWD && (long)a.N * a.heads <= 512 && !getenv("PG_ATTN_WAVES")) W = 8;
+  if (which == PG_ATTN_FWD && (long)a.N * a.heads <= 512 && !PG_AB_ENV("PG_ATTN_WAVES")) W = 8;
   if (W > NB) W = NB;
   if ((NB + W - 1) / W > 16) return 0;  // block lists hold 16 entries per wave
   // LPT: blocks by decreasing cost (later query blocks / earlier key blocks stream more), each to

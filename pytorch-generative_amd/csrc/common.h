@@ -219,3 +219,13 @@ __device__ __forceinline__ void pg_stage_rows_vec4(float* __restrict__ lds, int 
 #else
 #define PG_DBG_BIT(flags, bit) false
 #endif
+
+// A/B switches of the kernels' host code ("A/B switches"): measurement only, every default is the fast
+// path. The PRODUCTION library does not read them — PG_AB_ENV is a compile-time null there, so no environment variable can
+// change which kernel a launch takes; `PG_VARIANT=ab python build.py` (-DPG_AB) builds lib/libpg_hip_ab.so with the
+// switches live, for tools/exp (PG_HIP_LIB=<that file>). PG_CONV_LOG (a diagnostic: one stderr line per launch) stays live.
+#ifdef PG_AB
+#define PG_AB_ENV(name) getenv(name)
+#else
+#define PG_AB_ENV(name) ((const char*)nullptr)
+#endif

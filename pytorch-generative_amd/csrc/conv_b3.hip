@@ -102,19 +102,19 @@ constexpr int B3_PX_CAP = 352;  // tile pixels (with halo) the LDS plan assumes 
 // chunk, K steps of 4 groups. ok = 0: the fp32-MFMA kernel takes the problem.
 B3Plan b3_plan(int Kc, int M, int T) {
   B3Plan best = {};
-  static const bool on = []() { const char* e = getenv("PG_CONV_B3"); return !(e && e[0] == '0'); }();
+  static const bool on = []() { const char* e = PG_AB_ENV("PG_CONV_B3"); return !(e && e[0] == '0'); }();
   if (!on || Kc % 8 != 0 || Kc < 16 || M < 16 || T < 1) return best;
   const int MT = b3_mt(M);
   const int px = T == 1 ? 256 : B3_PX_CAP;
   // 4 taps with >= 64 output channels: one 8-channel group x 4 taps = exactly one K step of 32 per chunk — the format
   // of the pipelined kernel (conv_b3p_kernel: double-buffered 14.6 KB x tile + 12 KB weight slab). PG_CONV_B3P=0 keeps
   // the 16-channel chunks of conv_b3_kernel (A/B).
-  static const bool p_on = []() { const char* e = getenv("PG_CONV_B3P"); return !(e && e[0] == '0'); }();
+  static const bool p_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3P"); return !(e && e[0] == '0'); }();
   // (one output chunk only: with 128+ output channels the wide conv_b3_kernel, whose two chunks share ONE staged x tile,
   // measured faster — 247 against 282 us on the 2x2 64 -> 128 at N = 512 — while 64 -> 64 runs 119 -> 108 us here)
   // Round 5: also several output chunks when their number is odd-sized for the wide kernel (M % 128 != 0, e.g. PixelCNN++'s 160 / 320
   // filters): conv_b3_kernel then runs one chunk per workgroup as well, so both stage x once per chunk. PG_CONV_B3P_MULTI=0 for A/B.
-  static const bool pm_on = []() { const char* e = getenv("PG_CONV_B3P_MULTI"); return !(e && e[0] == '0'); }();
+  static const bool pm_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3P_MULTI"); return !(e && e[0] == '0'); }();
   if (p_on && on && T == 4 && MT == 4 && (M <= B3_CO_CHUNK || (pm_on && M % (2 * B3_CO_CHUNK) != 0)) && Kc % 8 == 0 && Kc >= 16) {
     B3Plan pp = {1, 8, 1, 4, 1, 4, (size_t)MT * 3 * 1024, 0, 1};
     return pp;
@@ -135,7 +135,7 @@ B3Plan b3_plan(int Kc, int M, int T) {
       best = {1, CIB, cgs, groups, ksteps, MT, wb_s, 0, 0};
     }
   }
-  static const bool w9_on = []() { const char* e = getenv("PG_CONV_B3_W9"); return !(e && e[0] == '0'); }();
+  static const bool w9_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3_W9"); return !(e && e[0] == '0'); }();
   if (!best.ok && w9_on && MT == 4 && Kc % 8 == 0) {
     // nothing fits 6 weight slots per thread: one 8-channel group per chunk with 9 slots (3x3, >= 64 output channels)
     const int cgs = 1, groups = T, ksteps = (groups + 3) / 4;
@@ -264,7 +264,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     // Measured forward, old -> new kernel (tools/exp/pw_ab.py): 64 -> 64 at N = 512, 32x32: 76.8 -> 65.4 us (4.1 TB/s of
     // algorithmic traffic), with ELU on both sides 83.0 -> 74.8; 64 -> 32 at N = 1024, 28x28: 84.1 -> 64.7; 32 -> 64:
     // 99.4 -> 88.7. 128 input channels are compute-heavy enough for the staged kernel: 182 -> 197 us, left there.
-    static const bool pw_on = []() { const char* e = getenv("PG_CONV_B3_PW"); return !(e && e[0] == '0'); }();
+    static const bool pw_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3_PW"); return !(e && e[0] == '0'); }();
     const int nchunk = Cin / pl.CIB;
     const size_t wbytes = (size_t)nchunk * pl.MT * 3 * 1024;
     // both residual operands the SAME tensor (PixelCNN's x + (x + net(x)) and the two equal skip gradients of its
@@ -301,7 +301,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   if (T > 1 && !pl.pipelined) {
     // conv_b3_kernel: the staged tile may be larger than the format-level 352 pixels if THIS launch's LDS has the room
     // (one 64-channel chunk per workgroup assumed here; the wide kernel is re-checked below and falls back)
-    static const bool big_on = []() { const char* e = getenv("PG_CONV_B3_BIGTILE"); return !(e && e[0] == '0'); }();
+    static const bool big_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3_BIGTILE"); return !(e && e[0] == '0'); }();
     const long fixed = (long)pl.w_bytes + 4L * 16 * 68 * 4 + (B3_CO_CHUNK + B3_MAXG + 4) * 4 + 16 * 16 + 512;
     long cap = (80L * 1024 - fixed) / ((long)pl.cgs * 48);        // 16-byte entries per (group, piece) plane
     const long slot_cap = (pl.w9 ? 2L : (long)B3_XS) * B3_THREADS / pl.cgs;  // staging slots per thread
@@ -325,7 +325,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     a.dump16 = (int)x16;
     a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
     // waves per workgroup: 8 (a wave owns 32 pixels, 128 registers, four waves per SIMD) unless PG_CONV_B3P_WAVES=4
-    static const int env_waves = []() { const char* e = getenv("PG_CONV_B3P_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    static const int env_waves = []() { const char* e = PG_AB_ENV("PG_CONV_B3P_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
     const int p_waves = env_waves;
     const int px = TR * OW;
     const int nt = p_waves == 8 ? (px + 127) / 128 : (px + 63) / 64;   // 16-pixel groups per wave
@@ -358,7 +358,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.dump16 = (int)x16;              // one spare 16-byte entry (+ padding to a 256-byte boundary)
   a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
   // wide workgroups (two output chunks share one staged x tile): default; PG_CONV_B3_WIDE=0 for A/B
-  static const bool wide_on = []() { const char* e = getenv("PG_CONV_B3_WIDE"); return !(e && e[0] == '0'); }();
+  static const bool wide_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3_WIDE"); return !(e && e[0] == '0'); }();
   const int CG = (wide_on && !pl.w9 && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0) ? 2 : 1;
   size_t shmem = (size_t)a.w_off16 * 16 + pl.w_bytes * CG;
   a.ep_off = (int)(shmem / 4);

@@ -496,7 +496,7 @@ PG_EXPORT int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, i
   // 64-channel outputs at ~1.1 TB/s): beta-VAE 45.7 -> 47.9 k img/s, PixelSNAIL / GatedPixelCNN +0.7 % (same box;
   // PG_CONV_MFMA_MIN_CIN=8 restores the old routing for A/B. The ONE-channel input layers stay on the tap kernel: ImageGPT's
   // 3x3 1 -> 16 measured no different, PixelCNN's 24-tap 7x7 does not fit this kernel's tap table)
-  static const int min_cin = []() { const char* e = getenv("PG_CONV_MFMA_MIN_CIN"); const int v = e ? atoi(e) : 3; return v >= 3 ? v : 3; }();
+  static const int min_cin = []() { const char* e = PG_AB_ENV("PG_CONV_MFMA_MIN_CIN"); const int v = e ? atoi(e) : 3; return v >= 3 ? v : 3; }();
   if (Cin < 8 && Cin >= min_cin && Cout >= 32) return PG_CONV_FMT_F32;
   return (Cin >= 8 && Cout >= 8) ? PG_CONV_FMT_F32 : 0;
 }
@@ -610,7 +610,7 @@ PG_EXPORT int pg_conv2d_mfma_ex(const float* in, const float* wfrag, const float
   a.min_dr = min_dr; a.min_dc = min_dc;
   // pixel tile: whole rows of one image (TR rows), or NI whole images when an image is <= 128 px
   const int L = OH * OW;
-  static const int px_cap = []() { const char* e = getenv("PG_MF_PX"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 192) ? v : 256; }();
+  static const int px_cap = []() { const char* e = PG_AB_ENV("PG_MF_PX"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 192) ? v : 256; }();
   if (L <= 128) {
     a.NI = 256 / L;
     if (a.NI > 15) a.NI = 15;  // the image index of a staging slot is packed into 4 bits

@@ -588,7 +588,7 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   const long max_rows = wgrad_max_rows(Cout, Cin, T);
   // 1x1 convolutions whose shape the bf16x3 kernel takes (Cout % 64 == 0, Cin % 32 == 0, W % 8 == 0) go there
   // first (PG_WGRAD_B3_PW=0: the fp32 direct-fragment kernel below, for A/B)
-  static const bool b3_pw = []() { const char* e = getenv("PG_WGRAD_B3_PW"); return !(e && e[0] == '0'); }();
+  static const bool b3_pw = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_PW"); return !(e && e[0] == '0'); }();
   if (b3_pw && T == 1 && KH == 1 && KW == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW) {
     const int g = pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
                                      Cout, OH, OW, T, tap_dr, tap_dc, in_act, st);
@@ -635,7 +635,7 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     // tuned on), else — or when its x copies do not fit LDS (3x3 on 64-wide rows) — the shifted-dy variant
     // (measured, PG_WGRAD_B3S=2 prefers the shifted-dy kernel everywhere: PixelSNAIL 12.43 -> 12.31 k img/s,
     // GatedPixelCNN 5.26 -> 5.06 k, beta-VAE 38.1 -> 38.5 k: only the 3x3 grids gain, so those go there first)
-    static const bool s_all = []() { const char* e = getenv("PG_WGRAD_B3S"); return e && e[0] == '2'; }();
+    static const bool s_all = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3S"); return e && e[0] == '2'; }();
     const bool s_first = s_all || T == 9;
     int g = (Cout % 64 == 0 && !s_first) ? pg_wgrad_b3_launch(x, dy, workspace, stride, max_rows, db != nullptr, N, Cin, IH, IW,
                                                 Cout, OH, OW, T, tap_dr, tap_dc, in_act, st)
@@ -677,7 +677,7 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
   PG_REQUIRE(TR >= 1, PG_ESHAPE, "pg_conv2d_wgrad: row of %d (+%d halo) too wide for LDS", OW, hc);
   if (TR > OH) TR = OH;
   // register-prefetch staging: rows of both tensors 16-byte aligned in global memory
-  static const bool pf_on = []() { const char* e = getenv("PG_WGRAD_PREFETCH"); return !(e && e[0] == '0'); }();
+  static const bool pf_on = []() { const char* e = PG_AB_ENV("PG_WGRAD_PREFETCH"); return !(e && e[0] == '0'); }();
   a.prefetch = pf_on && (OW % 4 == 0) && (IW % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
   a.Qd = OW / 4;
   a.Qx = IW / 4;

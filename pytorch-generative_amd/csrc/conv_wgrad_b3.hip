@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(WB_THREADS, 2) conv_wgrad_b3s_kernel(const WsA
 int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_stride, long max_rows,
                        int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
                        const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st) {
-  static const bool on = []() { const char* e = getenv("PG_WGRAD_B3"); return !(e && e[0] == '0'); }();
+  static const bool on = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3"); return !(e && e[0] == '0'); }();
   if (!on) return 0;
   if (IH != OH || IW != OW || OW % 4 != 0 || Cout % 32 != 0 || Cin % WB_CI != 0) return 0;
   int MR = Cout % WB_CO == 0 ? 2 : 1;  // 64 or 32 dy channels per workgroup
@@ -671,7 +671,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   const int hr = max_dr - min_dr;
   const int PBR = (OW + 7) / 8;  // W % 8 == 4: the last pixel block of a row is half full
   // 64 dy channels per workgroup: 8 waves (four per SIMD, 2 staging slots per thread); PG_WGRAD_B3_WAVES=4 for A/B
-  static const int env_waves = []() { const char* e = getenv("PG_WGRAD_B3_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+  static const int env_waves = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
   // tile rows: K steps of 4 pixel blocks, staging slots within the per-thread caps, LDS within budget
   auto pick_rows = [&](int co_, int ci_, long slot_cap_, long xslot_cap_ = 0) {
     if (xslot_cap_ == 0) xslot_cap_ = slot_cap_;
@@ -689,7 +689,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   // big tiles (round 5; at most 2 taps, 8 waves): 64 x channels per workgroup, and 128 dy channels for one tap — the
   // 1x1 / 2x1 / 1x2 weight gradients are bound by staging (split + LDS writes per MFMA: profiles/r05_wgrad_pmc.json),
   // not by the matrix pipe. PG_WGRAD_B3_BIG=0 for A/B. A shape whose big tile does not fit LDS keeps the 64 x 32 tile.
-  static const bool big_on = []() { const char* e = getenv("PG_WGRAD_B3_BIG"); return !(e && e[0] == '0'); }();
+  static const bool big_on = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_BIG"); return !(e && e[0] == '0'); }();
   bool big = big_on && MR == 2 && T <= 2 && Cin % 64 == 0;
   int TR = 0;
   if (big && T == 1 && Cout % 128 == 0 && (TR = pick_rows(128, 64, 2L * 512, 512)) > 0) MR = 4;
@@ -760,8 +760,8 @@ int pg_wgrad_b3s_launch(const float* x, const float* dy, float* part, long part_
                         int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
                         const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st) {
   static const bool on = []() {
-    const char* e = getenv("PG_WGRAD_B3");
-    const char* s = getenv("PG_WGRAD_B3S");
+    const char* e = PG_AB_ENV("PG_WGRAD_B3");
+    const char* s = PG_AB_ENV("PG_WGRAD_B3S");
     return !(e && e[0] == '0') && !(s && s[0] == '0');
   }();
   if (!on) return 0;

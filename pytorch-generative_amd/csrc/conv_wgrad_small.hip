@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(SW_THREADS) conv_wgrad_small_kernel(const SwAr
 int pg_wgrad_small_launch(const float* x, const float* dy, float* part, long part_stride, long max_rows,
                           int has_bias, int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T,
                           const int* tap_dr, const int* tap_dc, int in_act, hipStream_t st) {
-  static const bool on = []() { const char* e = getenv("PG_WGRAD_SMALL"); return !(e && e[0] == '0'); }();
+  static const bool on = []() { const char* e = PG_AB_ENV("PG_WGRAD_SMALL"); return !(e && e[0] == '0'); }();
   if (!on) return 0;
   // >= 32 output channels: with 16 (ImageGPT's 3x3 input layer) three of the four waves idle and the general
   // kernel measured faster (ImageGPT 100.0 k vs 99.2 k img/s)

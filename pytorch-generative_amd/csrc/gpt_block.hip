@@ -540,12 +540,12 @@ int grid_blocks(int which, int N, int L) {
     Cfg c = {{2048, 768, 2048, 512},  // measured: head bwd 79.8 us at 512, 68.9 at 768
              {1, 2}};                 // tiles per wave below which the grid shrinks (forward, backward);
                                       // measured at batch 64: (4, 8) 1.82 ms/step, (2, 4) 1.59, (1, 2) 1.53, (1, 1) 1.56
-    if (const char* e = getenv("PG_BLOCK_GRID")) {
+    if (const char* e = PG_AB_ENV("PG_BLOCK_GRID")) {
       int v[4];
       if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
         for (int i = 0; i < 4; ++i) c.cap[i] = v[i];
     }
-    if (const char* e = getenv("PG_BLOCK_MINTILES")) {
+    if (const char* e = PG_AB_ENV("PG_BLOCK_MINTILES")) {
       int f = 0, b = 0;
       if (sscanf(e, "%d,%d", &f, &b) == 2 && f > 0 && b > 0) { c.mt[0] = f; c.mt[1] = b; }
     }
