@@ -557,24 +557,27 @@ CEILINGS = {"pixel_cnn": 163e3, "gated_pixel_cnn": 7.4e3, "beta_vae": 100e3, "vd
             # no BASELINE.md row (not in the reference): the same formula on _pixelcnnpp_gflop_per_img's algorithmic count
             "pixel_cnn_pp": FP32_PEAK_TFLOPS * 1e3 / WORKLOADS["pixel_cnn_pp"]["gflop"]}
 # dominant kernel of each compact record and its share of the step's kernel time, from the tracked rocprofv3 tables
-# (profiles/r04_<model>_kernel_stats.csv, tools/collect_profiles_r04.sh); None = read the table
+# (profiles/r05_<model>_kernel_stats.csv, tools/collect_profiles_r05.sh stats); None = read the table
 DOMINANT = {}
 
 
 def _dominant_kernel(model):
-    """(name, share of kernel time, average microseconds) of the top kernel in profiles/r04_<model>_kernel_stats.csv."""
+    """(name, share of kernel time, average microseconds) of the top kernel in the newest committed rocprofv3 table of this
+    workload, profiles/r05_<model>_kernel_stats.csv (else r04): a committed profile, not a measurement of this run."""
     import csv
 
     try:
-        with open(os.path.join(ROOT, "profiles", f"r04_{model}_kernel_stats.csv")) as f:
+        path = next(p for p in (os.path.join(ROOT, "profiles", f"{r}_{model}_kernel_stats.csv") for r in ("r05", "r04"))
+                    if os.path.exists(p))
+        with open(path) as f:
             rows = list(csv.DictReader(f))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
         top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
         name = top["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
         name = name[:name.find("(")] if "(" in name else name
         return {"kernel": name, "share_of_kernel_time": float(top["TotalDurationNs"]) / tot,
-                "avg_us": float(top["AverageNs"]) / 1e3, "source": f"profiles/r04_{model}_kernel_stats.csv"}
-    except (OSError, ValueError, KeyError):
+                "avg_us": float(top["AverageNs"]) / 1e3, "source": "profiles/" + os.path.basename(path)}
+    except (OSError, ValueError, KeyError, StopIteration):
         return None
 OTHER_MIN_SECONDS = 0.5  # every secondary record is timed over at least this long (and at least the headline's steps)
 # how parity is gated (tests/, DESIGN.md section 2) — quoted in the line so that a rate is never read without it

@@ -16,7 +16,9 @@ for mode in "$@"; do
       align=512
       [ $mode = guard-strict ] && align=16
       mkdir -p "$out/$mode"
-      PG_GUARD=1 PG_GUARD_ALIGN=$align AMD_SERIALIZE_KERNEL=3 PG_TRACE="$out/$mode/trace" \
+      # capture arena: never recycled, and the tier now captures every bench workload at full model size twice
+      # (test_k_graph_replays_equal_k_eager_steps): 32 GB ran out in round 5 -> 128 GB of the 288
+      PG_GUARD=1 PG_GUARD_ALIGN=$align PG_GUARD_ARENA_MB=${PG_GUARD_ARENA_MB:-131072} AMD_SERIALIZE_KERNEL=3 PG_TRACE="$out/$mode/trace" \
         timeout ${PG_GUARD_TIMEOUT:-1500} python -X faulthandler -m pytest tests -m gpu -q -n 1 --timeout 300 -rfE --tb=short -p no:cacheprovider ${PG_GUARD_PYTEST_ARGS} > "$out/$mode.log" 2>&1
       echo "$mode rc=$?" >> "$out/summary.txt"
       for f in "$out/$mode"/trace.*; do tail -n 40 "$f" > "$f.tail"; rm -f "$f"; done ;;
