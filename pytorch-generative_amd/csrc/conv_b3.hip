@@ -181,7 +181,12 @@ PG_EXPORT void pg_b3_set_prof(void* p) { g_b3_prof = (long long*)p; }
 
 // ---- interface used by conv_mfma.hip's exported entry points --------------------------------------
 int pg_b3_applicable(int Kc, int M, int T, int OH, int OW, int hr, int hc) {
-  if (OW > 256 || OH * OW < 256) return 0;
+  // Round 5: images down to 16 pixels (4 x 4) run here as well — a bf16x3 tile lives inside one image, so an 8 x 8 image fills a
+  // quarter of the 256-pixel tile, and the six bf16 MFMAs per product still beat the fp32-MFMA kernel's multi-image tiles:
+  // PixelCNN++ (its 8 x 8 level: 320-channel 2x3 / 2x2 convolutions) 606 -> 659 images/s, VD-VAE +2.7 %, beta-VAE +1.6 %
+  // (same box, ab library; PG_CONV_B3_MIN_PX=256 there restores the round-4 routing)
+  static const int min_px = []() { const char* e = PG_AB_ENV("PG_CONV_B3_MIN_PX"); const int v = e ? atoi(e) : 16; return v >= 16 ? v : 16; }();
+  if (OW > 256 || OH * OW < min_px) return 0;
   return b3_plan(Kc, M, T).ok && b3_rows(T, OH, OW, hr, hc) >= 1;
 }
 
@@ -252,7 +257,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   tap_extent(T, tap_dr, tap_dc, a.min_dr, hr, a.min_dc, hc);
   const B3Plan pl = b3_plan(Cin, Cout, T);
   int TR = b3_rows(T, OH, OW, hr, hc);
-  PG_REQUIRE(pl.ok && TR >= 1 && OH * OW >= 256 && OW <= 256, PG_ESHAPE,
+  PG_REQUIRE(pl.ok && TR >= 1 && OH * OW >= 16 && OW <= 256, PG_ESHAPE,
              "pg_conv2d_mfma(bf16x3): shape not covered");
   a.CIB = pl.CIB; a.cgs = pl.cgs; a.groups = pl.groups; a.ksteps = pl.ksteps;
   a.wslab4 = pl.ksteps * pl.MT * 192;

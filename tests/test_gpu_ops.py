@@ -100,6 +100,12 @@ CONV_CASES = [
     (3, 24, 32, 32, 128, 2, 2, 1, 1, "hw", None, "elu", True, True),
     (3, 40, 16, 32, 64, 2, 2, 1, 1, "hw", None, None, False, True),     # pipelined forward with Cin = 40: five 8-channel chunks
     (3, 64, 32, 32, 56, 2, 2, 1, 1, "hw", None, "elu", False, True),    # pipelined kernel, partial output chunk (56 of 64)
+    # round 5: images below 256 pixels on the bf16x3 kernels (one image = a partial tile)
+    (9, 64, 8, 8, 64, 2, 3, 1, 1, "hw", None, "elu", True, True),       # 8 x 8, six taps
+    (530, 32, 8, 8, 32, 3, 3, 1, 1, None, None, "gelu", False, True),   # VD-VAE's 8 x 8 level: more images than workgroups
+    (33, 32, 4, 4, 64, 3, 3, 1, 1, None, None, "relu", True, True),     # 4 x 4 images: 16 of a tile's 256 pixels
+    (12, 320, 8, 8, 160, 2, 2, 1, 1, "hw", None, None, False, True),    # PixelCNN++'s coarsest level, pipelined 4-tap kernel
+    (5, 128, 8, 8, 256, 1, 1, 0, 0, None, None, "relu", True, True),    # 1x1 on 64-pixel images (wide kernel)
     # round 5: the pipelined kernel with several output chunks when the wide kernel does not apply (Cout % 128 != 0)
     (3, 64, 32, 32, 160, 2, 2, 1, 1, "hw", None, "elu", True, True),    # PixelCNN++'s widths: chunks of 64 + 64 + 32
     (70, 320, 16, 16, 320, 2, 2, 1, 1, "hw", None, None, False, True),  # 320 -> 320 on 16 x 16, several tiles per workgroup
