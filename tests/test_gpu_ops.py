@@ -100,6 +100,10 @@ CONV_CASES = [
     (3, 24, 32, 32, 128, 2, 2, 1, 1, "hw", None, "elu", True, True),
     (3, 40, 16, 32, 64, 2, 2, 1, 1, "hw", None, None, False, True),     # pipelined forward with Cin = 40: five 8-channel chunks
     (3, 64, 32, 32, 56, 2, 2, 1, 1, "hw", None, "elu", False, True),    # pipelined kernel, partial output chunk (56 of 64)
+    # round 5: odd numbers of output chunks (PixelCNN++'s widths; the wide kernel for them was measured and dropped: 684 -> 642 images/s)
+    (3, 64, 16, 16, 160, 2, 3, 1, 1, "hw", None, "elu", True, True),     # forward: 3 chunks (64 + 64 + 32 channels)
+    (2, 320, 16, 16, 64, 1, 3, 0, 1, None, None, "relu", False, True),   # data gradient: M = 320 = 5 chunks
+    (70, 64, 32, 32, 320, 2, 3, 1, 1, "hw", None, None, True, False),    # 5 chunks, several tiles per workgroup, no bias
     # round 5: images below 256 pixels on the bf16x3 kernels (one image = a partial tile)
     (9, 64, 8, 8, 64, 2, 3, 1, 1, "hw", None, "elu", True, True),       # 8 x 8, six taps
     (530, 32, 8, 8, 32, 3, 3, 1, 1, None, None, "gelu", False, True),   # VD-VAE's 8 x 8 level: more images than workgroups
