@@ -25,7 +25,7 @@ SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_
 for pass in FETCH_SIZE WRITE_SIZE "$SQ"; do
   tag=$(echo $pass | cut -d' ' -f1)
   timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$tag -o p -- \
-    python $R/tools/exp/pmc_launch.py 3 > $OUT/pmc_$tag.log 2>&1 || echo "[pmc $tag] rc=$?"
+    python $R/tools/exp/pmc_launch.py 3 --wide > $OUT/pmc_$tag.log 2>&1 || echo "[pmc $tag] rc=$?"
   tail -1 $OUT/pmc_$tag.log
 done
 python - <<PY

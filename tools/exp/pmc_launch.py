@@ -21,7 +21,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from pytorch_generative_amd import ops  # noqa: E402
 
-launches = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+launches = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
 dev = torch.device("cuda:0")
 orig = bench._event_time
 bench._event_time = lambda fn, stream, iters=10: orig(fn, stream, iters=launches)
@@ -38,4 +38,15 @@ out["conv_2x2_64_64_b1024"] = round(bench.conv_kernel_roofline(1024, dev)["launc
 out["wgrad_2x2_64_64_b1024"] = round(bench.wgrad_kernel_roofline(1024, dev)["launch_ms"], 4)
 out["wgrad_1x1_128_256_b512"] = round(bench.wgrad_kernel_roofline(512, dev, 128, 256, 32, (1, 1, 0, 0))["launch_ms"], 4)
 out["wgrad_2x3_128_256_b512"] = round(bench.wgrad_kernel_roofline(512, dev, 128, 256, 32, (2, 3, 1, 1))["launch_ms"], 4)
+# GatedPixelCNN's widest 1x1 (256 -> 256, batch 512) on the wide kernel: a forward launch through the public op
+if "--wide" in sys.argv:
+    import torch.nn.functional as F  # noqa: F401
+    xw = torch.randn(512, 256, 32, 32, device=dev)
+    ww = (torch.randn(256, 256, 1, 1, device=dev) * 0.05)
+    bw = torch.zeros(256, device=dev)
+    spec = ops.ConvSpec(1, 1, 0, 0)
+    with torch.no_grad():
+        for _ in range(launches):
+            ops.conv2d_taps(xw, ww, bw, spec, out_hw=(32, 32))
+    torch.cuda.synchronize()
 print(json.dumps(out))
