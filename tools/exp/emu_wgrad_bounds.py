@@ -18,7 +18,6 @@ def old_kernel(N, Cin, Cout, H, W, taps):
     if W % 4 or Cout % 32 or Cin % WB_CI:
         return None
     MR = 2 if Cout % 64 == 0 else 1
-    wb_co = 32 * MR
     if MR == 1 and T == 1:
         return None
     if T not in (1, 2, 3, 4, 6, 9):
@@ -32,16 +31,37 @@ def old_kernel(N, Cin, Cout, H, W, taps):
     min_dr = min(t[0] for t in taps); max_dr = max(t[0] for t in taps)
     hr = max_dr - min_dr
     PBR = (W + 7) // 8
+
+    def pick_rows(co_, ci_, dcap, xcap=None):
+        xcap = xcap or dcap
+        best = 0
+        for tr in range(1, H + 4):
+            if (tr * PBR) % 4:
+                continue
+            dslots, xslots = co_ * tr * PBR, ci_ * (tr + hr) * PBR
+            if dslots > dcap or xslots > xcap or (3 * dslots + 3 * len(dcs) * xslots) * 16 > BUDGET:
+                break
+            best = tr
+            if tr >= H:
+                break
+        return best
+
+    # round 5: big tiles (pg_wgrad_b3_launch): 64 x channels per workgroup for <= 2 taps, 128 dy channels for one tap
+    big = MR == 2 and T <= 2 and Cin % 64 == 0
     TR = 0
-    for tr in range(1, H + 4):
-        if (tr * PBR) % 4:
-            continue
-        dslots, xslots = wb_co * tr * PBR, WB_CI * (tr + hr) * PBR
-        if dslots > WB_DS * WB_THREADS or xslots > WB_XS * WB_THREADS or (3 * dslots + 3 * len(dcs) * xslots) * 16 > BUDGET:
-            break
-        TR = tr
-        if tr >= H:
-            break
+    if big and T == 1 and Cout % 128 == 0:
+        TR = pick_rows(128, 64, 1024, 512)
+        if TR > 0:
+            MR = 4
+    if big and TR == 0:
+        TR = pick_rows(64, 64, 1024)
+        if TR == 0:
+            big = False
+    wb_ci = 64 if big else WB_CI
+    wb_co = 32 * MR
+    waves = 8 if big else (8 if (MR == 2 and T <= 4) else 4)
+    if not big:
+        TR = pick_rows(wb_co, wb_ci, 1024 if waves == 8 else WB_DS * WB_THREADS)
     if TR == 0:
         return None
     xh = TR + hr
@@ -66,9 +86,9 @@ def old_kernel(N, Cin, Cout, H, W, taps):
                         for f in range(4):
                             check("old", dyb + goff + (0 if half else 4) + f, ndy, "dy p[1]")
                             reads += 8
-            for ci0 in range(0, Cin, WB_CI):
+            for ci0 in range(0, Cin, wb_ci):
                 xb = ((n * Cin + ci0) * H + (row0 + min_dr)) * W
-                for e in range(WB_CI * xh * PBR):
+                for e in range(wb_ci * xh * PBR):
                     i = e & 15; e2 = e >> 4
                     cb = e2 % PBR; e2 //= PBR
                     tr = e2 % xh; cit = e2 // xh
@@ -162,7 +182,7 @@ if __name__ == "__main__":
     shapes = []
     for (kh, kw, ph, pw) in ((1, 1, 0, 0), (3, 3, 1, 1), (2, 2, 1, 1), (1, 3, 0, 1), (2, 1, 2, 0), (2, 3, 1, 1), (1, 2, 0, 1)):
         for (h, w) in ((28, 28), (12, 12), (10, 20), (32, 36), (7, 24), (16, 16), (64, 64), (9, 16), (8, 8), (18, 28)):
-            for (cin, cout) in ((32, 32), (32, 64), (64, 64), (128, 256), (96, 96)):
+            for (cin, cout) in ((32, 32), (32, 64), (64, 64), (128, 256), (96, 96), (64, 128), (128, 128), (256, 256), (192, 128), (320, 64)):
                 shapes.append((1, cin, cout, h, w, taps_of(kh, kw, ph, pw)))
                 shapes.append((2, cin, cout, h, w, taps_of(kh, kw, ph, pw)))
     n_old = n_s = 0
