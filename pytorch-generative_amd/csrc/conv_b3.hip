@@ -239,6 +239,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   B3Args a;
   a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
   PG_REQUIRE(res2 == nullptr || res != nullptr, PG_EINVAL, "pg_conv2d_mfma(bf16x3): res2 without res");
+  // the weight slabs are moved by LDS-DMA in 16-byte units (conv_b3_kernel, round 5)
+  PG_REQUIRE((((uintptr_t)wfrag) & 15) == 0, PG_EINVAL, "pg_conv2d_mfma(bf16x3): the fragment buffer must be 16-byte aligned");
   a.res2 = res2;
   a.res_scale = 1.f;
   a.res_bs = res_bs > 0 ? res_bs : (long)Cout * OH * OW;
