@@ -23,7 +23,8 @@ def test_weight_gradient_kernels_read_in_bounds(kernel):
     took = 0
     for n in (1, 2):
         for (h, w) in ((28, 28), (12, 12), (10, 20), (16, 16), (8, 64)):
-            for (cin, cout) in ((32, 32), (32, 64), (128, 256)):
+            # (64, 64) / (64, 128) / (192, 128): the round-5 big tiles (64 x channels per workgroup; 128 dy channels for one tap)
+            for (cin, cout) in ((32, 32), (32, 64), (128, 256), (64, 64), (64, 128), (192, 128)):
                 took += emu.old_kernel(n, cin, cout, h, w, taps) is not None
                 took += emu.b3s_kernel(n, cin, cout, h, w, taps) is not None
     assert took > 0
