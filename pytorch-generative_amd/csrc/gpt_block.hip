@@ -537,7 +537,8 @@ int grid_blocks(int which, int N, int L) {
   // is entered from the main thread and from the autograd thread)
   struct Cfg { int cap[4]; int mt[2]; };
   static const Cfg cfg = []() {
-    Cfg c = {{2048, 768, 2048, 512},  // measured: head bwd 79.8 us at 512, 68.9 at 768
+    Cfg c = {{2048, 1024, 2048, 512},  // measured: head bwd 79.8 us at 512, 68.9 at 768; round 5 (122 registers = four waves per SIMD since the
+                                      // VGPR-form build): 1024 = one full round, ImageGPT 99.16 -> 99.88 k img/s on one box (sweep in profiles/README.md)
              {1, 2}};                 // tiles per wave below which the grid shrinks (forward, backward);
                                       // measured at batch 64: (4, 8) 1.82 ms/step, (2, 4) 1.59, (1, 2) 1.53, (1, 1) 1.56
     if (const char* e = PG_AB_ENV("PG_BLOCK_GRID")) {
