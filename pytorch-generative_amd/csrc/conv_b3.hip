@@ -91,6 +91,8 @@ struct B3Plan {
   int ok, CIB, cgs, groups, ksteps, MT;
   size_t w_bytes;
   int w9;  // the plan needs the 9-weight-slot instantiation (conv_b3_kernel<.., W9 = true>)
+  int px_cap;     // staged tile pixels (with halo) this plan's LDS budget assumes: 0 = the default for T (B3_PX_CAP), or the smaller
+                  // tile (336) that lets a larger channel chunk fit (round 5)
   int pipelined;  // set ONLY by the PG_CONV_B3P branch of b3_plan: conv_b3p_kernel takes the launch (the generic planner can
                   // arrive at the same chunk shape — Cin % 16 != 0 with >= 128 output channels — and stays on conv_b3_kernel)
 };
@@ -116,23 +118,33 @@ B3Plan b3_plan(int Kc, int M, int T) {
   // filters): conv_b3_kernel then runs one chunk per workgroup as well, so both stage x once per chunk. PG_CONV_B3P_MULTI=0 for A/B.
   static const bool pm_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3P_MULTI"); return !(e && e[0] == '0'); }();
   if (p_on && on && T == 4 && MT == 4 && (M <= B3_CO_CHUNK || (pm_on && M % (2 * B3_CO_CHUNK) != 0)) && Kc % 8 == 0 && Kc >= 16) {
-    B3Plan pp = {1, 8, 1, 4, 1, 4, (size_t)MT * 3 * 1024, 0, 1};
+    B3Plan pp = {1, 8, 1, 4, 1, 4, (size_t)MT * 3 * 1024, 0, 0, 1};
     return pp;
   }
   double best_cost = 1e30;
+  // Round 5: a second pass with a slightly smaller staged tile (336 instead of 352 pixels) — a plan is taken from it only when it
+  // lets a LARGER channel chunk fit LDS: the 9-tap convolutions with 32 output channels (VD-VAE's / beta-VAE's 3x3 32 -> 32 and
+  // 64 -> 32) run 16-channel chunks (18 of 20 K-step slots used, 2 chunk steps per 32 channels) instead of 8-channel ones (9 of 12,
+  // 4 steps): VD-VAE 4.77 -> 4.89 k img/s, beta-VAE +0.6 %, nothing else changes plan (PG_CONV_B3_PX2=0 in the ab library for A/B)
+  static const int px2 = []() { const char* e = PG_AB_ENV("PG_CONV_B3_PX2"); const int v = e ? atoi(e) : 336; return (v >= 128 && v < B3_PX_CAP) ? v : 0; }();
+  for (int pass = 0; pass < (px2 && T > 1 ? 2 : 1); ++pass)
   for (int CIB = 32; CIB >= 8; CIB >>= 1) {
     if (Kc % CIB != 0) continue;
+    const int pxp = pass == 0 ? px : px2;
     const int cgs = CIB / 8, groups = cgs * T, ksteps = (groups + 3) / 4;
     if (ksteps > 5 || groups > B3_MAXG) continue;
-    const size_t xb = (size_t)cgs * 3 * px * 16, wb = (size_t)ksteps * MT * 3 * 1024;
+    const size_t xb = (size_t)cgs * 3 * pxp * 16, wb = (size_t)ksteps * MT * 3 * 1024;
     const size_t wb_s = wb;
     if (xb + wb_s + (size_t)4 * 16 * 68 * 4 + 1024 > 80 * 1024) continue;  // + per-wave epilogue scratch
-    if ((long)cgs * px > (long)B3_XS * B3_THREADS) continue;
-    if ((long)ksteps * MT * 192 > (long)B3_WS * B3_THREADS) continue;
-    const double cost = (double)ksteps / CIB + 0.002 / CIB;  // MFMA work per channel, then fewer steps
+    if ((long)cgs * pxp > (long)B3_XS * B3_THREADS) continue;
+    // (round 4 and before: the slab went through 6 float4 registers per thread, so ksteps * MT * 192 <= 6 * 256 bounded the plan. The
+    // slab is moved by LDS-DMA now — no such bound; PG_CONV_B3_WSLOTS=1 in the ab library restores it for A/B)
+    static const bool wslots = []() { const char* e = PG_AB_ENV("PG_CONV_B3_WSLOTS"); return e && e[0] == '1'; }();
+    if (wslots && (long)ksteps * MT * 192 > (long)B3_WS * B3_THREADS) continue;
+    const double cost = (double)ksteps / CIB + 0.002 / CIB + (pass ? 1e-4 : 0.0);  // MFMA work per channel, then fewer steps, then the full tile
     if (cost < best_cost) {
       best_cost = cost;
-      best = {1, CIB, cgs, groups, ksteps, MT, wb_s, 0, 0};
+      best = {1, CIB, cgs, groups, ksteps, MT, wb_s, 0, pass ? pxp : 0, 0};
     }
   }
   static const bool w9_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3_W9"); return !(e && e[0] == '0'); }();
@@ -142,7 +154,7 @@ B3Plan b3_plan(int Kc, int M, int T) {
     const size_t xb = (size_t)cgs * 3 * px * 16, wb = (size_t)ksteps * MT * 3 * 1024;
     if (ksteps <= 5 && groups <= B3_MAXG && xb + wb + (size_t)4 * 16 * 68 * 4 + 1024 <= 80 * 1024 &&
         (long)cgs * px <= 2L * B3_THREADS && (long)ksteps * MT * 192 <= 9L * B3_THREADS)
-      best = {1, 8, cgs, groups, ksteps, MT, wb, 1, 0};
+      best = {1, 8, cgs, groups, ksteps, MT, wb, 1, 0, 0};
   }
   return best;
 }
@@ -187,7 +199,8 @@ int pg_b3_applicable(int Kc, int M, int T, int OH, int OW, int hr, int hc) {
   // (same box, ab library; PG_CONV_B3_MIN_PX=256 there restores the round-4 routing)
   static const int min_px = []() { const char* e = PG_AB_ENV("PG_CONV_B3_MIN_PX"); const int v = e ? atoi(e) : 16; return v >= 16 ? v : 16; }();
   if (OW > 256 || OH * OW < min_px) return 0;
-  return b3_plan(Kc, M, T).ok && b3_rows(T, OH, OW, hr, hc) >= 1;
+  const B3Plan pl = b3_plan(Kc, M, T);
+  return pl.ok && b3_rows(T, OH, OW, hr, hc, pl.px_cap) >= 1;
 }
 
 size_t pg_b3_frag_floats(int Kc, int M, int T) {
@@ -258,7 +271,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   int hr, hc;
   tap_extent(T, tap_dr, tap_dc, a.min_dr, hr, a.min_dc, hc);
   const B3Plan pl = b3_plan(Cin, Cout, T);
-  int TR = b3_rows(T, OH, OW, hr, hc);
+  int TR = b3_rows(T, OH, OW, hr, hc, pl.px_cap);
   PG_REQUIRE(pl.ok && TR >= 1 && OH * OW >= 16 && OW <= 256, PG_ESHAPE,
              "pg_conv2d_mfma(bf16x3): shape not covered");
   a.CIB = pl.CIB; a.cgs = pl.cgs; a.groups = pl.groups; a.ksteps = pl.ksteps;
@@ -315,7 +328,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     if (cap > slot_cap) cap = slot_cap;
     cap = (cap / 16) * 16;
     const bool wide = !pl.w9 && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0;  // (its LDS holds two weight slabs: keep the plan's tile)
-    if (big_on && !wide && cap > B3_PX_CAP) {
+    if (big_on && !wide && cap > (pl.px_cap ? pl.px_cap : B3_PX_CAP)) {
       const int TR2 = b3_rows(T, OH, OW, hr, hc, (int)cap);
       if (TR2 > TR) TR = TR2;
     }
