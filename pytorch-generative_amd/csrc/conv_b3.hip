@@ -122,20 +122,35 @@ B3Plan b3_plan(int Kc, int M, int T) {
     return pp;
   }
   double best_cost = 1e30;
-  // Round 5: a second pass with a slightly smaller staged tile (336 instead of 352 pixels) — a plan is taken from it only when it
-  // lets a LARGER channel chunk fit LDS: the 9-tap convolutions with 32 output channels (VD-VAE's / beta-VAE's 3x3 32 -> 32 and
-  // 64 -> 32) run 16-channel chunks (18 of 20 K-step slots used, 2 chunk steps per 32 channels) instead of 8-channel ones (9 of 12,
-  // 4 steps): VD-VAE 4.77 -> 4.89 k img/s, beta-VAE +0.6 %, nothing else changes plan (PG_CONV_B3_PX2=0 in the ab library for A/B)
-  static const int px2 = []() { const char* e = PG_AB_ENV("PG_CONV_B3_PX2"); const int v = e ? atoi(e) : 336; return (v >= 128 && v < B3_PX_CAP) ? v : 0; }();
-  for (int pass = 0; pass < (px2 && T > 1 ? 2 : 1); ++pass)
+  // Round 5: further passes with smaller staged tiles (336, then 256 pixels instead of 352) — a plan is taken from them only when it
+  // lets a LARGER channel chunk fit LDS (the cost below prefers fuller K steps, then fewer steps, then the larger tile):
+  //   336: the 9-tap convolutions with 32 output channels (VD-VAE's / beta-VAE's 3x3 32 -> 32 and 64 -> 32) run 16-channel chunks (18
+  //        of 20 K-step slots used, 2 chunk steps per 32 channels) instead of 8-channel ones (9 of 12, 4 steps): VD-VAE 4.77 -> 4.89 k;
+  //   256: the 6-tap convolutions with >= 64 output channels (PixelCNN++'s 2x3, 31 % of its step) run 16-channel chunks (12 of 12
+  //        slots) instead of 8-channel ones (6 of 8) on 192-pixel tiles: PixelCNN++ 669 -> 707 images/s. Nothing else changes plan
+  //        (PG_CONV_B3_CAPS=352 in the ab library restores the round-4 plans). The wide kernel's real budget (x shared by two chunks in
+  //        160 KB), which would give GatedPixelCNN's 1x3 32-channel chunks, measured +0.4 %: within noise, not taken.
+  struct Caps { int n; int v[4]; };
+  static const Caps caps = []() {
+    Caps c = {3, {B3_PX_CAP, 336, 256, 0}};
+    if (const char* e = PG_AB_ENV("PG_CONV_B3_CAPS")) {  // A/B: "352" = round-4 plans
+      int a = 0, b = 0, d = 0, f = 0;
+      const int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &f);
+      if (n >= 1 && a == B3_PX_CAP) { c.n = n; c.v[0] = a; c.v[1] = b; c.v[2] = d; c.v[3] = f; }
+    }
+    return c;
+  }();
+  for (int pass = 0; pass < (T > 1 ? caps.n : 1); ++pass)
   for (int CIB = 32; CIB >= 8; CIB >>= 1) {
     if (Kc % CIB != 0) continue;
-    const int pxp = pass == 0 ? px : px2;
+    const int pxp = pass == 0 ? px : caps.v[pass];
+    if (pxp < 64) continue;
     const int cgs = CIB / 8, groups = cgs * T, ksteps = (groups + 3) / 4;
     if (ksteps > 5 || groups > B3_MAXG) continue;
     const size_t xb = (size_t)cgs * 3 * pxp * 16, wb = (size_t)ksteps * MT * 3 * 1024;
     const size_t wb_s = wb;
-    if (xb + wb_s + (size_t)4 * 16 * 68 * 4 + 1024 > 80 * 1024) continue;  // + per-wave epilogue scratch
+    const size_t scratch = (size_t)4 * 16 * 68 * 4;  // per-wave epilogue scratch of one chunk's four waves
+    if (xb + wb_s + scratch + 1024 > 80 * 1024) continue;
     if ((long)cgs * pxp > (long)B3_XS * B3_THREADS) continue;
     // (round 4 and before: the slab went through 6 float4 registers per thread, so ksteps * MT * 192 <= 6 * 256 bounded the plan. The
     // slab is moved by LDS-DMA now — no such bound; PG_CONV_B3_WSLOTS=1 in the ab library restores it for A/B)
