@@ -194,6 +194,8 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
         # rank (what a 1-GPU box can measure of it)
         reducer = parallel.FlatGradAllReduce(opt, transport="rccl" if env.world == 1 else None)
         reducer.broadcast_parameters(src=0)
+        if os.environ.get("PG_BENCH_FORCE_SPLIT") == "1":  # diagnosis: two graphs around an eager collective even where it is capturable
+            reducer.force_split = True
     x = synthetic_batch(batch, 0 if same_batch else env.rank, w["chw"]).to(env.device)
     if name in ("beta_vae", "vd_vae"):
         def loss_fn(xx, preds):  # ELBO: recon.mean() + kl.mean()

@@ -561,7 +561,10 @@ static bool use_mfma_attention() {
 
 // launch `which` on whichever kernel family covers the shape
 static int launch_any(int which, AttnArgs& a, hipStream_t st) {
-  if (use_mfma_attention() && pg_attn_mfma_launch(which, a, st) == 1) return 0;
+  // ab library: PG_ATTN_MFMA_MASK = bit mask of the kernels allowed on the matrix-core family (1 forward, 2 dQ, 4 dK/dV)
+  static const int mask = []() { const char* e = PG_AB_ENV("PG_ATTN_MFMA_MASK"); return e ? atoi(e) : 7; }();
+  const int bit = which == K_FWD ? 1 : (which == K_DQ ? 2 : 4);
+  if (use_mfma_attention() && (mask & bit) && pg_attn_mfma_launch(which, a, st) == 1) return 0;
   return launch_attn(which, a, st);
 }
 
