@@ -51,13 +51,20 @@ def worker(out, world, rank, port):
         if not nosync:
             torch.cuda.synchronize()
             put(f"s{step}.flat_grad_local", opt.flat_grad)
+        if nosync:  # stream-ordered device clones, no host synchronisation
+            keep.append((f"s{step}.logits", logits.detach().clone()))
+            keep.append((f"s{step}.flat_grad_local", opt.flat_grad.detach().clone()))
         if red is not None:
             red.all_reduce()
+            if nosync:
+                keep.append((f"s{step}.flat_grad_mean", opt.flat_grad.detach() * (1.0 / world)))
             if not nosync:
                 torch.cuda.synchronize()
                 put(f"s{step}.flat_grad_mean", opt.flat_grad * (1.0 / world))
         elif not nosync:
             put(f"s{step}.flat_grad_mean", opt.flat_grad)
+        else:
+            keep.append((f"s{step}.flat_grad_mean", opt.flat_grad.detach().clone()))
         opt.step()
         if nosync:
             keep.append((f"s{step}.flat_param", opt.flat_param.detach().clone()))
