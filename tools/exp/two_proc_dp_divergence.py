@@ -30,6 +30,9 @@ def worker(out, world, rank, port):
     model.train()
     opt = optim.FlatAdam(model.parameters(), lr=w["lr"], lr_decay=w["decay"])
     red = parallel.FlatGradAllReduce(opt) if world > 1 else None
+    fake_host = None
+    if world == 1 and os.environ.get("FAKE_STAGING") == "1":  # one process, no process group: only the pinned-host round trip of the gradient
+        fake_host = torch.empty(opt.flat_grad.shape, dtype=opt.flat_grad.dtype, pin_memory=True)
     if red is not None:
         red.broadcast_parameters(src=0)
     x = bench.synthetic_batch(32, 0, w["chw"]).to(dev)
@@ -54,6 +57,9 @@ def worker(out, world, rank, port):
         if nosync:  # stream-ordered device clones, no host synchronisation
             keep.append((f"s{step}.logits", logits.detach().clone()))
             keep.append((f"s{step}.flat_grad_local", opt.flat_grad.detach().clone()))
+        if fake_host is not None:
+            fake_host.copy_(opt.flat_grad)
+            opt.flat_grad.copy_(fake_host, non_blocking=False)
         if red is not None:
             red.all_reduce()
             if nosync:
