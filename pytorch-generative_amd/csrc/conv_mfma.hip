@@ -216,6 +216,12 @@ __global__ void __launch_bounds__(MF_THREADS, 2) conv_mfma_kernel(const MfArgs a
   // Two LDS buffers: while the waves run the MFMA loop of step s out of one, each wave that finishes
   // commits step s+1 (its loads were issued before the loop) into the other — one barrier per step.
   PG_MF_ISSUE(0)
+  // The zero fill above is ordered before the first commit: other threads own the same entries there. (Round 5: without
+  // this barrier a wave that started late zeroed entries another wave had already committed. Never seen with the GPU to
+  // itself - the fill comes hundreds of cycles before the first loads land - but two PROCESSES sharing the GPU skew the
+  // waves of a workgroup enough: PixelSNAIL's input and q/k/v convolutions came out wrong in 2-4 of 15 forwards,
+  // tools/exp/conc_forward_selfcheck.py, profiles/README.md round 5 item 16. The loads of step 0 fly under the barrier.)
+  __syncthreads();
   PG_MF_COMMIT_ALL(0, 0)
   __syncthreads();
   const int kb = lane >> 4;

@@ -102,15 +102,9 @@ class FlatGradAllReduce:
         if self._host is None:
             fn(tensor)
             return
-        # Round 5: an explicit device synchronisation in front of the staging copy. The copy is stream-ordered by contract, yet
-        # without this the two-rank run of PixelSNAIL (and only PixelSNAIL) read an incomplete gradient buffer from its third step
-        # on (profiles/README.md round 5 item 16: `tools/exp/two_proc_dp_divergence.py`, NOSYNC=1 reproduces it, every other
-        # workload and every synchronised variant is bit-exact). Development transport only: the RCCL path never passes here.
-        torch.cuda.synchronize()
         self._host.copy_(tensor)  # synchronous D2H on the current stream
         fn(self._host)
         tensor.copy_(self._host, non_blocking=False)
-        torch.cuda.synchronize()
 
     def broadcast_parameters(self, src=0):
         """DDP's constructor broadcast: every rank starts from rank `src`'s parameters."""

@@ -30,6 +30,9 @@ def worker(out, world, rank, port):
     model.train()
     opt = optim.FlatAdam(model.parameters(), lr=w["lr"], lr_decay=w["decay"])
     red = parallel.FlatGradAllReduce(opt) if world > 1 else None
+    if red is not None and os.environ.get("DP_IDLE") == "1":  # a process group exists, but the loop below never uses it
+        opt.set_grad_prescale(1.0)
+        world, red = 1, None
     fake_host = None
     if world == 1 and os.environ.get("FAKE_STAGING") == "1":  # one process, no process group: only the pinned-host round trip of the gradient
         fake_host = torch.empty(opt.flat_grad.shape, dtype=opt.flat_grad.dtype, pin_memory=True)
