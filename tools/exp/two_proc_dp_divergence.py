@@ -24,7 +24,7 @@ def worker(out, world, rank, port):
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    w = bench.WORKLOADS["pixel_snail"]
+    w = bench.WORKLOADS[os.environ.get("WORKLOAD", "pixel_snail")]  # BCE workloads: image_gpt, pixel_cnn, gated_pixel_cnn, pixel_snail
     torch.manual_seed(0)
     model = getattr(pg.models, w["ctor"])(**w["kw"]).to(dev)
     model.train()
@@ -38,7 +38,7 @@ def worker(out, world, rank, port):
         fake_host = torch.empty(opt.flat_grad.shape, dtype=opt.flat_grad.dtype, pin_memory=True)
     if red is not None:
         red.broadcast_parameters(src=0)
-    x = bench.synthetic_batch(32, 0, w["chw"]).to(dev)
+    x = bench.synthetic_batch(int(os.environ.get("BATCH", "32")), 0, w["chw"]).to(dev)
     rec, order = {}, []
 
     def put(k, t):
