@@ -320,3 +320,36 @@ def test_bench_self_spawn_watches_all_ranks(tmp_path, monkeypatch):
     t0 = time.monotonic()
     assert bench._self_spawn(3) != 0
     assert time.monotonic() - t0 < 30, "a dead rank must not leave the launcher waiting for the survivors"
+
+
+# Which kernel family a convolution shape is sent to (csrc/conv_mfma.hip pg_conv_mfma_supported: a host function, no GPU needed).
+# 0 = the VALU tap kernel, 1 = fp32 MFMA fragments (conv_mfma_kernel), 2 = bf16x3 fragments (conv_b3*). The shapes are the layers the
+# eight bench workloads launch (DESIGN.md section 3's kernel table); a change here moves a model onto another kernel, so it should be a
+# decision (profiles/README.md records each one: e.g. round 5 item 7 for the 3-channel input layers), not a side effect.
+CONV_ROUTING = [
+    ("PixelSNAIL input 3 -> 64, 4 causal taps, 32x32", (3, 64, 4, 32, 32, 32, 1, 2), 1),
+    ("PixelSNAIL merged q/k/v projection 69 -> 40, 1x1", (69, 40, 1, 32, 32, 32, 0, 0), 1),
+    ("PixelSNAIL 2x2 64 -> 64", (64, 64, 4, 32, 32, 32, 1, 1), 2),
+    ("PixelSNAIL 1x1 64 -> 128", (64, 128, 1, 32, 32, 32, 0, 0), 2),
+    ("PixelCNN 7x7 input 1 -> 32 (24 taps: more than the fragment kernels' tap table)", (1, 32, 24, 28, 28, 28, 3, 6), 0),
+    ("ImageGPT 3x3 input 1 -> 16", (1, 16, 4, 28, 28, 28, 1, 2), 0),
+    ("GatedPixelCNN vertical 2x3 128 -> 256", (128, 256, 6, 32, 32, 32, 1, 2), 2),
+    ("beta-VAE 4x4 / stride 2 input layer as a 2x2 phase convolution 3 -> 64", (3, 64, 4, 32, 32, 32, 1, 1), 1),
+    ("VD-VAE 3x3 32 -> 32 on 64x64", (32, 32, 9, 64, 64, 64, 2, 2), 2),
+    ("PixelCNN++ 2x3 160 -> 160", (160, 160, 6, 32, 32, 32, 1, 2), 2),
+    ("Cin 24 (a multiple of 8, not of 16)", (24, 128, 1, 32, 32, 32, 0, 0), 2),
+    ("Cout 56 (a partial last 16-channel tile)", (64, 56, 1, 28, 28, 28, 0, 0), 2),
+    ("rows wider than a 256-pixel tile", (64, 64, 1, 4, 320, 320, 0, 0), 0),
+    ("a 2x2 image (VD-VAE's lowest levels)", (64, 64, 9, 2, 2, 2, 2, 2), 0),
+    ("2 input channels", (2, 64, 4, 32, 32, 32, 1, 1), 0),
+    ("4 input channels but only 16 outputs", (4, 16, 4, 32, 32, 32, 1, 1), 0),
+]
+
+
+@pytest.mark.parametrize("what,shape,fmt", CONV_ROUTING, ids=[c[0] for c in CONV_ROUTING])
+def test_convolution_routing_table(lib, what, shape, fmt):
+    assert lib.pg_conv_mfma_supported(*shape) == fmt, what
+    if fmt:  # the fragment buffer the caller must allocate for that format is non-empty and 16-byte granular
+        cin, cout, taps = shape[0], shape[1], shape[2]
+        n = lib.pg_conv_frag_floats(cin, cout, taps, fmt)
+        assert n > 0 and n % 4 == 0
