@@ -353,3 +353,24 @@ def test_convolution_routing_table(lib, what, shape, fmt):
         cin, cout, taps = shape[0], shape[1], shape[2]
         n = lib.pg_conv_frag_floats(cin, cout, taps, fmt)
         assert n > 0 and n % 4 == 0
+
+
+def test_lds_zero_fills_are_ordered_before_the_first_commit():
+    """Source-level guard for the race of round 5 (profiles/README.md item 16): every kernel that zero-fills an LDS tile once and relies on the
+    halo staying zero must pass a workgroup barrier before another thread may commit into that tile. The GPU tier has the behavioural check
+    (tests/test_gpu_shared_device.py); this one fails on the CPU as soon as somebody removes a barrier."""
+    csrc = os.path.join(ROOT, "pytorch-generative_amd", "csrc")
+
+    def between(path, start, end):
+        text = open(os.path.join(csrc, path)).read()
+        i = text.index(start)
+        return text[i:text.index(end, i)]
+
+    # fp32-MFMA kernel: zero fill ... issue(0) ... barrier ... commit(0)
+    assert "__syncthreads();" in between("conv_mfma.hip", "lds[a.buf_stride + i] = 0.f;", "PG_MF_COMMIT_ALL(0, 0)")
+    # bf16x3 kernels: zero fill ... barrier ... (first issue / commit)
+    assert "__syncthreads();" in between("conv_b3_kernels.h", "i < a.cgs * 3 * a.plane16; i += THREADS) lds16[i]", "PG_B3_COMMIT_ALL()")
+    assert "__syncthreads();" in between("conv_b3_kernels.h", "i < 2 * xbuf16; i += THREADS) lds16[i]", "PG_P_COMMIT_X(0, 0)")
+    # VALU tap kernel and fp32 weight-gradient kernel: the chunk / tile loop opens with a barrier
+    assert "__syncthreads();" in between("conv_direct.hip", "i < a.CIB * a.ch_stride; i += blockDim.x) lds[i] = 0.f;", "pg_stage_rows_vec4<ACT>")
+    assert "__syncthreads();" in between("conv_wgrad.hip", "i < lds_floats; i += WG_THREADS) lds[i] = 0.f;", "PG_WG_COMMIT_X(PG_ACT_RELU) break;")
