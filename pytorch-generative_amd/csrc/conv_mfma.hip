@@ -487,6 +487,76 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
                const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
                const float* res2, long res_bs, long res2_bs, hipStream_t st);
 
+// Geometry of one fp32-MFMA launch: pixel tile, channel chunk, LDS layout. Needs a.N / Cin / IW / Cout / OH / OW / T; hr / hc = row /
+// column extent of the tap list. Shared by the launch (pg_conv2d_mfma_ex) and by the routing query (pg_conv_mfma_supported), so that
+// "supported" can never promise a shape the launch then refuses (round 5: 5x5 / 7x7 kernels with 13+ active taps were routed here
+// and rejected with "exceeds the staging slots" — found by the CPU sweep tests/test_host_cpu.py::test_routing_never_promises_...).
+enum { MF_FIT_OK = 0, MF_FIT_SLOTS = 1, MF_FIT_LDS = 2 };
+static int mf_geometry(MfArgs& a, int hr, int hc, size_t* shmem_out) {
+  const int N = a.N, Cin = a.Cin, IW = a.IW, Cout = a.Cout, OH = a.OH, OW = a.OW, T = a.T;
+  // pixel tile: whole rows of one image (TR rows), or NI whole images when an image is <= 128 px
+  const int L = OH * OW;
+  static const int px_cap = []() { const char* e = PG_AB_ENV("PG_MF_PX"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 192) ? v : 256; }();
+  if (L <= 128) {
+    a.NI = 256 / L;
+    if (a.NI > 15) a.NI = 15;  // the image index of a staging slot is packed into 4 bits
+    if (a.NI > N) a.NI = N;
+    a.TR = OH;
+  } else {
+    a.NI = 1;
+    a.TR = px_cap / OW;
+    if (a.TR < 1) a.TR = 1;
+    if (a.TR > OH) a.TR = OH;
+    // even out the row tiles (e.g. 28 rows: 4 tiles of 7 instead of 9,9,9,1)
+    const int nt_rows = (OH + a.TR - 1) / a.TR;
+    a.TR = (OH + nt_rows - 1) / nt_rows;
+  }
+  a.tiles_per_grp = (OH + a.TR - 1) / a.TR;
+  a.tile_h = a.TR + hr;
+  a.tile_w = OW + hc;
+  a.img_stride = a.tile_h * a.tile_w;
+  {
+    int cs = a.NI * a.img_stride;
+    const int r = cs % 32;
+    cs += (r <= 16) ? (16 - r) : (48 - r);  // channel stride == 16 (mod 32): conflict-free B reads
+    a.ch_stride = cs;
+  }
+  const int MT = mf_mt(Cout);
+  a.KQ = ((Cin + 3) / 4) * T;
+  // channel chunk: x tile + weight fragments of ONE buffer within ~36 KB (two buffers per workgroup,
+  // two workgroups per CU)
+  const long budget = 36 * 1024 / 4;
+  const long per_ci = a.ch_stride + (long)T * MT * 16;
+  long CIB = (budget - 16) / per_ci;
+  CIB = (CIB / 4) * 4;
+  if (CIB < 4) CIB = 4;
+  if (CIB > Cin) CIB = ((Cin + 3) / 4) * 4;
+  a.Q = IW / 4;
+  // x slots: NI * CIB * tile_h * Q float4 per chunk over XS * 256 thread slots
+  while (CIB > 4 && (long)a.NI * CIB * a.tile_h * a.Q > (long)XS * MF_THREADS) CIB -= 4;
+  while (CIB > 4 && (CIB / 4) * (long)T * MT * 16 > (long)WS * MF_THREADS) CIB -= 4;  // weight slots
+  if (!((CIB / 4) * (long)T * MT * 16 <= (long)WS * MF_THREADS && (long)a.NI * CIB * a.tile_h * a.Q <= (long)XS * MF_THREADS))
+    return MF_FIT_SLOTS;
+  size_t shmem = 0;
+  for (;;) {  // the scratch floor of the weight area can push a buffer over its budget: shrink the chunk
+    a.CIB = (int)CIB;
+    a.xslots = a.NI * a.CIB * a.tile_h * a.Q;
+    const long x_floats = CIB * a.ch_stride;
+    a.dump = (int)x_floats;
+    a.w_off = (int)(((x_floats + 4 + 3) / 4) * 4);
+    size_t w_area = (size_t)(CIB / 4) * T * MT * 64;
+    if (w_area < (size_t)4 * 16 * 68) w_area = (size_t)4 * 16 * 68;  // doubles as the epilogue's transposition scratch
+    a.buf_stride = (int)(((size_t)a.w_off + w_area + 3) / 4 * 4);
+    shmem = (size_t)2 * a.buf_stride * sizeof(float);
+    a.b_off = (int)(shmem / sizeof(float));
+    shmem += MF_CO_CHUNK * sizeof(float);
+    if (shmem <= 80 * 1024 || CIB <= 4) break;
+    CIB -= 4;
+  }
+  *shmem_out = shmem;
+  return shmem <= 80 * 1024 ? MF_FIT_OK : MF_FIT_LDS;
+}
+
 // The matrix-core path pays off once both channel extents fill MFMA tiles; tiny contractions
 // (the 1- / 3-channel image convolutions, 4-channel query projections) stay on conv_direct.hip.
 // Returns the weight-fragment FORMAT the matrix-core path uses for this problem: 0 = none (use
@@ -503,8 +573,12 @@ PG_EXPORT int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, i
   // PG_CONV_MFMA_MIN_CIN=8 restores the old routing for A/B. The ONE-channel input layers stay on the tap kernel: ImageGPT's
   // 3x3 1 -> 16 measured no different, PixelCNN's 24-tap 7x7 does not fit this kernel's tap table)
   static const int min_cin = []() { const char* e = PG_AB_ENV("PG_CONV_MFMA_MIN_CIN"); const int v = e ? atoi(e) : 3; return v >= 3 ? v : 3; }();
-  if (Cin < 8 && Cin >= min_cin && Cout >= 32) return PG_CONV_FMT_F32;
-  return (Cin >= 8 && Cout >= 8) ? PG_CONV_FMT_F32 : 0;
+  if (!((Cin < 8 && Cin >= min_cin && Cout >= 32) || (Cin >= 8 && Cout >= 8))) return 0;
+  // ... and only if the launch geometry fits (the batch is not known here: the largest image group, i.e. the most slots and LDS)
+  MfArgs g;
+  g.N = 1 << 20; g.Cin = Cin; g.IW = IW; g.Cout = Cout; g.OH = OH; g.OW = OW; g.T = T;
+  size_t shmem = 0;
+  return mf_geometry(g, hr, hc, &shmem) == MF_FIT_OK ? PG_CONV_FMT_F32 : 0;
 }
 
 PG_EXPORT size_t pg_conv_frag_floats(int K_channels, int M_channels, int T, int fmt) {
@@ -614,72 +688,15 @@ PG_EXPORT int pg_conv2d_mfma_ex(const float* in, const float* wfrag, const float
     max_dc = tap_dc[t] > max_dc ? tap_dc[t] : max_dc;
   }
   a.min_dr = min_dr; a.min_dc = min_dc;
-  // pixel tile: whole rows of one image (TR rows), or NI whole images when an image is <= 128 px
-  const int L = OH * OW;
-  static const int px_cap = []() { const char* e = PG_AB_ENV("PG_MF_PX"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 192) ? v : 256; }();
-  if (L <= 128) {
-    a.NI = 256 / L;
-    if (a.NI > 15) a.NI = 15;  // the image index of a staging slot is packed into 4 bits
-    if (a.NI > N) a.NI = N;
-    a.TR = OH;
-  } else {
-    a.NI = 1;
-    a.TR = px_cap / OW;
-    if (a.TR < 1) a.TR = 1;
-    if (a.TR > OH) a.TR = OH;
-    // even out the row tiles (e.g. 28 rows: 4 tiles of 7 instead of 9,9,9,1)
-    const int nt_rows = (OH + a.TR - 1) / a.TR;
-    a.TR = (OH + nt_rows - 1) / nt_rows;
-  }
-  a.tiles_per_grp = (OH + a.TR - 1) / a.TR;
-  const int groups = (N + a.NI - 1) / a.NI;
-  a.tile_h = a.TR + (max_dr - min_dr);
-  a.tile_w = OW + (max_dc - min_dc);
-  a.img_stride = a.tile_h * a.tile_w;
-  {
-    int cs = a.NI * a.img_stride;
-    const int r = cs % 32;
-    cs += (r <= 16) ? (16 - r) : (48 - r);  // channel stride == 16 (mod 32): conflict-free B reads
-    a.ch_stride = cs;
-  }
   PG_REQUIRE((IW % 4) == 0 && (((uintptr_t)in & 15) == 0), PG_ESHAPE,
              "pg_conv2d_mfma: input rows must be 16-byte aligned (IW %% 4 == 0)");
-  const int MT = mf_mt(Cout);
-  a.KQ = ((Cin + 3) / 4) * T;
-  // channel chunk: x tile + weight fragments of ONE buffer within ~36 KB (two buffers per workgroup,
-  // two workgroups per CU)
-  const long budget = 36 * 1024 / 4;
-  const long per_ci = a.ch_stride + (long)T * MT * 16;
-  long CIB = (budget - 16) / per_ci;
-  CIB = (CIB / 4) * 4;
-  if (CIB < 4) CIB = 4;
-  if (CIB > Cin) CIB = ((Cin + 3) / 4) * 4;
-  a.Q = IW / 4;
-  // x slots: NI * CIB * tile_h * Q float4 per chunk over XS * 256 thread slots
-  while (CIB > 4 && (long)a.NI * CIB * a.tile_h * a.Q > (long)XS * MF_THREADS) CIB -= 4;
-  while (CIB > 4 && (CIB / 4) * (long)T * MT * 16 > (long)WS * MF_THREADS) CIB -= 4;  // weight slots
-  PG_REQUIRE((CIB / 4) * (long)T * MT * 16 <= (long)WS * MF_THREADS &&
-                 (long)a.NI * CIB * a.tile_h * a.Q <= (long)XS * MF_THREADS,
-             PG_ESHAPE, "pg_conv2d_mfma: %d taps x %d-row tile exceeds the staging slots", T, a.tile_h);
   size_t shmem = 0;
-  for (;;) {  // the scratch floor of the weight area can push a buffer over its budget: shrink the chunk
-    a.CIB = (int)CIB;
-    a.xslots = a.NI * a.CIB * a.tile_h * a.Q;
-    const long x_floats = CIB * a.ch_stride;
-    a.dump = (int)x_floats;
-    a.w_off = (int)(((x_floats + 4 + 3) / 4) * 4);
-    size_t w_area = (size_t)(CIB / 4) * T * MT * 64;
-    if (w_area < (size_t)4 * 16 * 68) w_area = (size_t)4 * 16 * 68;  // doubles as the epilogue's transposition scratch
-    a.buf_stride = (int)(((size_t)a.w_off + w_area + 3) / 4 * 4);
-    shmem = (size_t)2 * a.buf_stride * sizeof(float);
-    a.b_off = (int)(shmem / sizeof(float));
-    shmem += MF_CO_CHUNK * sizeof(float);
-    if (shmem <= 80 * 1024 || CIB <= 4) break;
-    CIB -= 4;
-  }
-  PG_REQUIRE(shmem <= 80 * 1024, PG_ESHAPE,
-             "pg_conv2d_mfma: tile %dx%d x %d taps needs %zu B of LDS (> 80 KB)", a.tile_h, a.tile_w,
-             T, shmem);
+  const int fit = mf_geometry(a, max_dr - min_dr, max_dc - min_dc, &shmem);
+  PG_REQUIRE(fit != MF_FIT_SLOTS, PG_ESHAPE, "pg_conv2d_mfma: %d taps x %d-row tile exceeds the staging slots", T, a.tile_h);
+  PG_REQUIRE(fit != MF_FIT_LDS, PG_ESHAPE, "pg_conv2d_mfma: tile %dx%d x %d taps needs %zu B of LDS (> 80 KB)", a.tile_h,
+             a.tile_w, T, shmem);
+  const int MT = mf_mt(Cout);
+  const int groups = (N + a.NI - 1) / a.NI;
   for (int t = 0; t < T; ++t) a.tapoff[t] = (tap_dr[t] - min_dr) * a.tile_w + (tap_dc[t] - min_dc);
   const int npx_max = a.NI * a.TR * OW;
   const int nt = (npx_max + 63) / 64;  // 16-pixel groups per wave

@@ -374,3 +374,119 @@ def test_lds_zero_fills_are_ordered_before_the_first_commit():
     # VALU tap kernel and fp32 weight-gradient kernel: the chunk / tile loop opens with a barrier
     assert "__syncthreads();" in between("conv_direct.hip", "i < a.CIB * a.ch_stride; i += blockDim.x) lds[i] = 0.f;", "pg_stage_rows_vec4<ACT>")
     assert "__syncthreads();" in between("conv_wgrad.hip", "i < lds_floats; i += WG_THREADS) lds[i] = 0.f;", "PG_WG_COMMIT_X(PG_ACT_RELU) break;")
+
+
+# ---- planners without a GPU ------------------------------------------------------------------------------------------
+# Without a device every launch fails with hipErrorNoDevice (100) AFTER the host-side planning (tile geometry, channel
+# chunks, LDS budget, staging slots) has accepted the problem; a problem the planner refuses comes back as a negative
+# PG_E* code before any launch. So on the CPU box the planners can be swept over thousands of shapes: whatever the routing
+# query promises, the launch must accept. (Pointers are fake and never dereferenced: these tests must not run where a
+# launch would succeed.)
+_NO_DEVICE = 100
+_no_gpu = pytest.mark.skipif(torch.cuda.is_available(), reason="sweeps the planners with fake pointers: CPU box only")
+
+
+def _fake_ptr():
+    import ctypes
+
+    import numpy as np
+    buf = np.zeros(1 << 12, dtype=np.float32)
+    return buf, ctypes.c_void_p((buf.ctypes.data + 255) // 256 * 256)
+
+
+def _reached_launch(lib, rc):
+    return rc == _NO_DEVICE or b"launch failed" in lib.pg_last_error()
+
+
+@_no_gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_routing_never_promises_a_shape_the_launch_refuses(lib, seed):
+    """Round 5: pg_conv_mfma_supported sent 5x5 / 7x7 kernels with 13+ active taps to the fp32-MFMA kernel, whose planner then
+    refused them ("exceeds the staging slots") - a ValueError where the VALU tap kernel would have worked. The query now runs the
+    launch's own geometry function; this sweep holds the two together for forward and data gradient, and checks that the tap
+    kernel takes everything the query does not route to the matrix cores."""
+    import random
+
+    from pytorch_generative_amd import _lib
+    ia = _lib.int_array
+    keep, p = _fake_ptr()
+    r = random.Random(seed)
+    kernels = [(1, 1), (2, 2), (3, 3), (2, 3), (1, 3), (3, 1), (2, 1), (1, 2), (5, 5), (4, 4), (7, 7), (3, 5)]
+    checked = 0
+    for _ in range(1500):
+        kh, kw = r.choice(kernels)
+        ph, pw = r.choice([(0, 0), (kh // 2, kw // 2), (kh - 1, kw - 1), (kh - 1, kw // 2)])
+        taps = [(u, v) for u in range(kh) for v in range(kw)]
+        mode = r.choice(["all", "A", "B", "random"])
+        if mode == "A":
+            taps = [(u, v) for u, v in taps if u < kh // 2 or (u == kh // 2 and v < kw // 2)] or taps
+        elif mode == "B":
+            taps = [(u, v) for u, v in taps if u < kh // 2 or (u == kh // 2 and v <= kw // 2)]
+        elif mode == "random":
+            taps = [t for t in taps if r.random() < 0.6] or taps
+        cin = r.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 24, 32, 33, 40, 48, 64, 66, 69, 96, 100, 128, 160, 192, 256, 320, 512])
+        cout = r.choice([1, 2, 3, 8, 10, 16, 24, 32, 36, 40, 56, 64, 72, 96, 100, 128, 160, 192, 256, 320, 512])
+        ih = r.choice([1, 2, 3, 4, 5, 7, 8, 12, 14, 16, 20, 28, 32, 33, 48, 64, 100, 128])
+        iw = r.choice([1, 2, 3, 4, 6, 8, 12, 14, 16, 20, 28, 32, 36, 48, 64, 100, 128, 256, 300])
+        n = r.choice([1, 2, 3, 7, 16, 33])
+        oh, ow = ih + 2 * ph - kh + 1, iw + 2 * pw - kw + 1
+        if oh < 1 or ow < 1:
+            continue
+        t = len(taps)
+        hr = max(u for u, _ in taps) - min(u for u, _ in taps)
+        hc = max(v for _, v in taps) - min(v for _, v in taps)
+        problems = (  # (K channels, IH, IW, M channels, OH, OW, tap rows, tap columns)
+            (cin, ih, iw, cout, oh, ow, [u - ph for u, _ in taps], [v - pw for _, v in taps]),  # forward
+            (cout, oh, ow, cin, ih, iw, [ph - u for u, _ in taps], [pw - v for _, v in taps]),  # data gradient
+        )
+        for kc, h_in, w_in, m, h_out, w_out, dr, dc in problems:
+            fmt = lib.pg_conv_mfma_supported(kc, m, t, h_out, w_out, w_in, hr, hc)
+            if fmt:
+                rc = lib.pg_conv2d_mfma_ex(p, p, None, None, p, n, kc, h_in, w_in, m, h_out, w_out, t, ia(dr), ia(dc), 0, None, 0, 0,
+                                           fmt, None, 0, 0, None)
+            else:
+                rc = lib.pg_conv2d_taps(p, p, None, None, p, n, kc, h_in, w_in, m, h_out, w_out, t, ia(dr), ia(dc), 0, None, 0, None)
+            assert _reached_launch(lib, rc), (fmt, rc, lib.pg_last_error(), (kh, kw, ph, pw, t, cin, cout, ih, iw, n))
+            checked += 1
+    assert checked > 2000
+    del keep
+
+
+@_no_gpu
+def test_weight_gradient_planner_takes_every_layer_of_the_bench_workloads(lib):
+    """pg_conv2d_wgrad picks among five kernels; each has LDS / slot limits (the widest row it takes shrinks with the kernel size:
+    DESIGN.md section 6, "limits"). Every convolution of the eight bench workloads, at every resolution its model runs it, must
+    pass the planner - at batch 1 and at batch 64."""
+    import bench
+    import pytorch_generative_amd as pg
+    from pytorch_generative_amd import _lib
+    ia = _lib.int_array
+    keep, p = _fake_ptr()
+    checked = 0
+    for name, w in bench.WORKLOADS.items():
+        model = getattr(pg.models, w["ctor"])(**w["kw"])
+        side = w["chw"][1]
+        sides = [side] if name in ("image_gpt", "image_gpt_repro", "pixel_snail", "gated_pixel_cnn", "pixel_cnn") else \
+            [s for s in (64, 32, 16, 8, 4, 2, 1) if s <= side]
+        seen = set()
+        for label, mod in model.named_modules():
+            if not hasattr(mod, "_conv_spec") or getattr(mod, "weight", None) is None or mod.weight.dim() != 4:
+                continue
+            sp = mod._conv_spec()
+            cout, cin = mod.weight.shape[:2]
+            taps = sp.wg_taps
+            for s in sides:
+                oh, ow = sp.full_out(s, s)
+                oh, ow = min(oh, s), min(ow, s)  # the causal layers crop their output back to the input size
+                key = (cin, cout, sp.kh, sp.kw, sp.pad_h, sp.pad_w, len(taps), s, oh, ow)
+                if key in seen or oh < 1 or ow < 1:
+                    continue
+                seen.add(key)
+                ws = lib.pg_conv2d_wgrad_workspace_floats(cout, cin, len(taps))
+                for n in (1, 64):
+                    rc = lib.pg_conv2d_wgrad(p, p, p, p, n, cin, s, s, cout, oh, ow, sp.kh, sp.kw, len(taps), sp.w_dr, sp.w_dc,
+                                             sp.w_u, sp.w_v, 0, p, ws, None)
+                    assert _reached_launch(lib, rc), (name, label, key, n, rc, lib.pg_last_error())
+                    checked += 1
+    assert checked > 100
+    del keep
