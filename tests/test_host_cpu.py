@@ -490,3 +490,61 @@ def test_weight_gradient_planner_takes_every_layer_of_the_bench_workloads(lib):
                     checked += 1
     assert checked > 100
     del keep
+
+
+@_no_gpu
+def test_attention_entry_points_accept_exactly_the_native_dims(lib):
+    """ops.attention_dims_native (what the Python host sends to the kernels unpadded) against the planners of pg_causal_attn_fwd / _bwd:
+    accepted if and only if native, for every head-dim / length / head-count / batch combination of the grid."""
+    from pytorch_generative_amd import ops
+    keep, p = _fake_ptr()
+    checked = 0
+    for dk in (1, 2, 3, 4, 5, 8, 12, 16, 32, 64, 128):
+        for dv in (1, 2, 4, 8, 16, 32, 64, 128):
+            for seq in (1, 2, 5, 16, 17, 49, 64, 100, 784, 1024, 1040):
+                for heads, n in ((1, 1), (2, 3), (4, 1024)):
+                    for strict in (0, 1):
+                        native = ops.attention_dims_native(dk, dv, seq)
+                        qb, vb = heads * dk * seq, heads * dv * seq
+                        rc = lib.pg_causal_attn_fwd(p, p, p, p, p, n, heads, seq, dk, dv, qb, qb, vb, vb, strict, None)
+                        assert _reached_launch(lib, rc) == native, ("fwd", dk, dv, seq, heads, n, rc, lib.pg_last_error())
+                        rc = lib.pg_causal_attn_bwd(p, p, p, p, p, p, p, p, p, p, n, heads, seq, dk, dv, qb, qb, vb, vb, vb, qb, qb, vb,
+                                                    strict, None)
+                        assert _reached_launch(lib, rc) == native, ("bwd", dk, dv, seq, heads, n, rc, lib.pg_last_error())
+                        checked += 1
+    assert checked > 5000
+    del keep
+
+
+@_no_gpu
+def test_shape_agnostic_entry_points_take_any_size(lib):
+    """LayerNorm, gates, pooling / upsampling / phase split, Gaussian heads, the losses: no shape of the grid is refused."""
+    import ctypes
+    import random
+    keep, p = _fake_ptr()
+    r = random.Random(0)
+    for _ in range(600):
+        n = r.choice([1, 2, 3, 17, 64, 1024])
+        c = r.choice([1, 2, 3, 4, 8, 16, 17, 32, 48, 64, 100, 128, 256, 512])
+        seq = r.choice([1, 2, 3, 4, 16, 49, 64, 196, 784, 1024, 4096])
+        h, w = r.choice([1, 2, 3, 4, 7, 8, 16, 32]), r.choice([1, 2, 3, 4, 7, 8, 16, 32])
+        ws = lib.pg_nchw_layernorm_bwd_workspace_floats(n, c, seq)
+        calls = [
+            ("layernorm_fwd", lib.pg_nchw_layernorm_fwd(p, p, p, p, p, p, n, c, seq, ctypes.c_float(1e-5), None)),
+            ("layernorm_bwd", lib.pg_nchw_layernorm_bwd(p, p, p, p, p, p, p, p, n, c, seq, p, ws, None)),
+            ("layernorm_bwd_res", lib.pg_nchw_layernorm_bwd_res(p, p, p, p, p, p, p, p, p, n, c, seq, p, ws, None)),
+            ("gated_fwd", lib.pg_gated_fwd(p, p, n, c, seq, 0, None)),
+            ("gated_bwd", lib.pg_gated_bwd(p, p, p, n, c, seq, 1, None)),
+            ("avgpool2_fwd", lib.pg_avgpool2_fwd(p, p, n * c, h, w, None)),
+            ("avgpool2_bwd", lib.pg_avgpool2_bwd(p, p, n * c, h, w, None)),
+            ("upsample2_fwd", lib.pg_upsample2_fwd(p, p, n * c, h, w, None)),
+            ("upsample2_bwd", lib.pg_upsample2_bwd(p, p, n * c, h, w, None)),
+            ("phase_split2", lib.pg_phase_split2(p, p, n * c, h, w, 0, None)),
+            ("gauss_head_fwd", lib.pg_gauss_head_fwd(p, p, p, p, p, n, c, seq, 2 * c * seq, 2 * c * seq, 1, None)),
+            ("gauss_head_bwd", lib.pg_gauss_head_bwd(p, p, p, p, p, p, p, n, c, seq, 2 * c * seq, 2 * c * seq, 1, None)),
+            ("dmol_fwd", lib.pg_dmol_fwd(p, p, p, n, r.choice([1, 5, 10]), seq, None)),
+            ("bce_logits_fwd", lib.pg_bce_logits_fwd(p, p, p, n, c * seq, None)),
+        ]
+        for name, rc in calls:
+            assert rc == _NO_DEVICE, (name, n, c, seq, h, w, rc)
+    del keep
