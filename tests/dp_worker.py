@@ -33,6 +33,17 @@ def build(dev, seed, kind="igpt"):
     if kind == "gated":
         model = pg.models.GatedPixelCNN(in_channels=1, out_channels=1, n_gated=2, gated_channels=16,
                                         head_channels=8).to(dev)
+    elif kind == "snail":
+        # BASELINE.json configs[3] (north_star's DDP workload) at its own channel counts — 64 channels, key 4 / value 32 —
+        # on 16x16x3, two blocks: the bf16x3 convolutions, the 66 / 69-channel fp32-MFMA projections and the k4 attention
+        model = pg.models.PixelSNAIL(in_channels=3, out_channels=3, n_channels=64, n_pixel_snail_blocks=2,
+                                     n_residual_blocks=2, attention_key_channels=4,
+                                     attention_value_channels=32).to(dev)
+    elif kind == "vd_vae":
+        # BASELINE.json configs[4]: the bench's channel counts (64 hidden / 32 bottleneck / 16 latent) on 32x32x3
+        model = pg.models.VeryDeepVAE(in_channels=3, out_channels=3, input_resolution=32,
+                                      stack_configs=[(1, 2), (1, 2), (1, 1), (1, 1)], latent_channels=16,
+                                      hidden_channels=64, bottleneck_channels=32).to(dev)
     else:
         model = pg.models.ImageGPT(1, 1, in_size=8, n_transformer_blocks=2, n_attention_heads=4,
                                    n_embedding_channels=16).to(dev)
@@ -42,9 +53,52 @@ def build(dev, seed, kind="igpt"):
     return model, optim.FlatAdam(model.parameters(), lr=5e-3, lr_decay=0.999)
 
 
-def batches(n_steps=3, b=8):
+def batches(n_steps=3, b=8, kind="igpt"):
     g = torch.Generator().manual_seed(77)
+    if kind == "snail":
+        return [torch.randint(0, 256, (b, 3, 16, 16), generator=g).float() / 255 for _ in range(n_steps)]
+    if kind == "vd_vae":
+        return [torch.randint(0, 256, (b, 3, 32, 32), generator=g).float() / 255 for _ in range(n_steps)]
     return [torch.bernoulli(torch.full((b, 1, 8, 8), 0.3), generator=g) for _ in range(n_steps)]
+
+
+class FixedNoise:
+    """Noise source of the VAE family for captured steps (a replay only ever sees the tensors of capture time): the i-th
+    draw of EVERY step is the same pre-drawn tensor, identical in every process that uses the same seed."""
+
+    def __init__(self, seed=3):
+        self.bank, self.i, self.gen = [], 0, torch.Generator().manual_seed(seed)
+
+    def reset(self):
+        self.i = 0
+
+    def __call__(self, shape, device):
+        if self.i == len(self.bank):
+            self.bank.append(torch.randn(shape, generator=self.gen).to(device))
+        eps = self.bank[self.i]
+        assert tuple(eps.shape) == tuple(shape)
+        self.i += 1
+        return eps
+
+
+def step_functions(kind, model):
+    """(loss_fn, forward_fn) for graph.GraphedTrainStep: the VAE's ELBO with its noise replayed, BCE otherwise."""
+    from pytorch_generative_amd import ops
+
+    if kind != "vd_vae":
+        return (lambda x, preds: ops.bce_with_logits_sum_mean(preds, x)), None
+    from pytorch_generative_amd.models.vae import vaes
+
+    noise = FixedNoise()
+    vaes.set_noise_fn(noise)
+
+    def fwd(x, y=None):
+        noise.reset()
+        preds = model(x)
+        recon, klm = ops.elbo_terms(preds[0], x, preds[1])
+        return recon + klm
+
+    return None, fwd
 
 
 def rccl_world1(out):
@@ -144,12 +198,12 @@ def main():
     model, opt = build(dev, seed=rank, kind=kind)  # different seeds: the broadcast must make them equal
     red = parallel.FlatGradAllReduce(opt)
     red.broadcast_parameters(src=0)
-    loss_fn = lambda x, preds: ops.bce_with_logits_sum_mean(preds, x)  # noqa: E731
-    data = batches()
+    loss_fn, fwd = step_functions(kind, model)
+    data = batches(kind=kind)
     if mode == "shard":
         per = data[0].shape[0] // world
         data = [b[rank * per:(rank + 1) * per] for b in data]
-    step = graph.GraphedTrainStep(model, opt, loss_fn, data[0].to(dev), reducer=red, preserve_state=True)
+    step = graph.GraphedTrainStep(model, opt, loss_fn, data[0].to(dev), reducer=red, preserve_state=True, forward_fn=fwd)
     assert step.split and step.graph_b is not None
     losses = [float(step(b.to(dev))) for b in data]
     torch.cuda.synchronize()

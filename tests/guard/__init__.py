@@ -31,7 +31,15 @@ def build(force=False):
     if not force and os.path.exists(SO) and os.path.getmtime(SO) > os.path.getmtime(SRC):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17", SRC, "-o", SO], check=True)
+    # several processes may get here at once (pytest-xdist workers, two PG_GUARD runs): each links into its own temporary
+    # file and renames it into place atomically, so that nobody ever dlopens a half-written library
+    tmp = f"{SO}.{os.getpid()}.tmp"
+    try:
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17", SRC, "-o", tmp], check=True)
+        os.replace(tmp, SO)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return SO
 
 

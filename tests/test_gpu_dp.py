@@ -22,18 +22,23 @@ def _single_gpu_reference(kind="igpt"):
     import dp_worker
     from pytorch_generative_amd import graph, ops
 
+    from pytorch_generative_amd.models.vae import vaes
+
     dev = torch.device("cuda", 0)
     model, opt = dp_worker.build(dev, seed=0, kind=kind)
-    loss_fn = lambda x, preds: ops.bce_with_logits_sum_mean(preds, x)  # noqa: E731
-    data = dp_worker.batches()
-    step = graph.GraphedTrainStep(model, opt, loss_fn, data[0].to(dev), preserve_state=True)
-    losses = [float(step(b.to(dev))) for b in data]
-    torch.cuda.synchronize()
+    loss_fn, fwd = dp_worker.step_functions(kind, model)
+    try:
+        data = dp_worker.batches(kind=kind)
+        step = graph.GraphedTrainStep(model, opt, loss_fn, data[0].to(dev), preserve_state=True, forward_fn=fwd)
+        losses = [float(step(b.to(dev))) for b in data]
+        torch.cuda.synchronize()
+    finally:
+        vaes.set_noise_fn(None)
     return {k: v.detach().cpu() for k, v in model.named_parameters()}, losses, opt.current_lr()
 
 
 def _run_world2(mode, out, kind="igpt"):
-    port = 29600 + os.getpid() % 300 + (0 if mode == "same" else 1) + (2 if kind == "gated" else 0)
+    port = 29600 + os.getpid() % 300 + (0 if mode == "same" else 1) + 2 * ["igpt", "gated", "snail", "vd_vae"].index(kind)
     env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), mode, out, kind],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -43,7 +48,10 @@ def _run_world2(mode, out, kind="igpt"):
     return torch.load(out, map_location="cpu", weights_only=False)
 
 
-@pytest.mark.parametrize("mode,kind", [("same", "igpt"), ("shard", "igpt"), ("shard", "gated")])
+# snail = BASELINE.json configs[3], north_star's data-parallel workload (pixel_snail.py:122-187) and the one whose two-rank run
+# exposed round 5's LDS race; vd_vae = configs[4] (vd_vae.py:141-189) with its noise replayed identically on every rank
+@pytest.mark.parametrize("mode,kind", [("same", "igpt"), ("shard", "igpt"), ("shard", "gated"), ("same", "snail"),
+                                       ("shard", "snail"), ("same", "vd_vae")])
 def test_two_ranks_equal_one_gpu(tmp_path, mode, kind):
     want, want_losses, want_lr = _single_gpu_reference(kind)
     got = _run_world2(mode, str(tmp_path / f"dp_{mode}.pt"), kind)

@@ -305,6 +305,62 @@ ATTN_CASES = [
 ]
 
 
+ALLOWED_SET_CASES = [
+    # (heads, dk, dv, H, W, strict)
+    (4, 4, 4, 28, 28, False),   # ImageGPT (BASELINE configs[1]): attention_mfma.hip, L = 784
+    (4, 4, 4, 28, 28, True),
+    (1, 4, 32, 32, 32, True),   # PixelSNAIL (configs[3]): attention_k4.hip, L = 1024, strict
+    (1, 4, 32, 32, 32, False),
+    (2, 32, 32, 28, 28, False),  # ImageGPT reproduce() head dims, ragged last 32-row block
+    (1, 4, 4, 36, 36, True),    # L = 1296: two workgroups per (n, head)
+    (2, 2, 2, 7, 7, False),     # VALU row-owner kernels, L = 49
+]
+
+
+@pytest.mark.parametrize("deterministic", [False, True], ids=["fused-bwd", "two-kernel-bwd"])
+@pytest.mark.parametrize("case", ALLOWED_SET_CASES, ids=lambda c: "-".join(str(int(v)) for v in c))
+def test_attention_allowed_set_is_bit_exact(dev, case, deterministic):
+    """north_star: "bit-exact for the causal mask indices". No L x L mask exists on the HIP path, so the set of (query, key)
+    pairs the kernels admit is read back FROM the kernels and compared with `_get_causal_mask`
+    (reference nn/attention.py:60-63 = oracle.ops.attention_mask) by torch.equal:
+      * q = k = 0 makes every admitted score 0, so P[l, m] = 1 / count(l) on admitted pairs and 0 elsewhere;
+      * V one-hot over key positions (image n, channel j marks key n * d_v + j) turns the forward output into
+        O[n, j, l] = P[l, n * d_v + j]: non-zero exactly on the forward kernels' admitted set;
+      * dO one-hot over QUERY positions turns dV into dV[n, j, m] = P[n * d_v + j, m]: the backward kernels' admitted set
+        (fused backward, and the two-kernel backward under ops.set_deterministic).
+    The recovered values are also checked: P * count == 1 to fp32 rounding, the strict mask's empty row is exactly zero."""
+    from pytorch_generative_amd import ops
+
+    heads, dk, dv, h, w, strict = case
+    L, e, v = h * w, heads * dk, heads * dv
+    n = -(-L // dv)
+    pos = torch.arange(n * dv).reshape(n, 1, dv, 1)                                     # position marked by (image, channel)
+    onehot = (pos == torch.arange(L).reshape(1, 1, 1, L)).float().expand(n, heads, dv, L)  # every head sees the same marks
+    onehot = onehot.reshape(n, v, h, w).contiguous()
+    q = torch.zeros(n, e, h, w, device=dev)
+    kv = torch.cat([torch.zeros(n, e, h, w), onehot], dim=1).to(dev).requires_grad_(True)
+    want = oops.attention_mask(L, strict)                                               # [query l, key m]
+    was = ops.set_deterministic(deterministic)
+    try:
+        o = ops.causal_attention(q, kv, heads, e, v, strict)
+        o.backward(onehot.to(dev))
+    finally:
+        ops.set_deterministic(was)
+    count = want.sum(1)
+    for hd in range(heads):
+        # forward: P[l, m] = O[n(m), hd * dv + j(m), l]
+        p_fwd = o.detach().cpu().reshape(n, heads, dv, L)[:, hd].reshape(n * dv, L)[:L].t().contiguous()
+        assert torch.equal((p_fwd != 0).float(), want), f"forward allowed set, head {hd}"
+        assert float((p_fwd * count[:, None] - want).abs().max()) <= 5e-6, "forward P * count != 1"
+        # backward: P[l, m] = dV[n(l), hd * dv + j(l), m]
+        p_bwd = kv.grad[:, e:].cpu().reshape(n, heads, dv, L)[:, hd].reshape(n * dv, L)[:L].contiguous()
+        assert torch.equal((p_bwd != 0).float(), want), f"backward allowed set, head {hd}"
+        assert float((p_bwd * count[:, None] - want).abs().max()) <= 5e-6, "backward P * count != 1"
+    if strict:
+        assert float(o[:, :, 0, 0].abs().max()) == 0.0
+    assert float(kv.grad[:, :e].abs().max()) == 0.0  # dK = dS^T q with q = 0
+
+
 @pytest.mark.parametrize("case", ATTN_CASES, ids=lambda c: "-".join(str(int(v)) for v in c))
 def test_causal_attention_core(dev, case):
     from pytorch_generative_amd import ops
