@@ -382,6 +382,56 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, pipelined)");
     return 0;
   }
+  {
+    // ---- the overlapped 16-wave kernel (conv_b3q_kernel.h, round 6): >= 64 output channels, any tap count. Its LDS (one
+    // workgroup per CU, up to 160 KB) = x tiles [NXT][2 buffers][cgs][3 pieces][plane16] | dump entry | slab ring [2][NCH][768] |
+    // bias, K-group table; two output chunks share one x tile when Cout % 128 == 0, otherwise two tiles share one slab.
+    static const bool q_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3Q"); return !(e && e[0] == '0'); }();
+    const bool stm = Cout % (2 * B3_CO_CHUNK) != 0;
+    const int NCH = stm ? 1 : 2, NXT = stm ? 2 : 1, GT = stm ? 512 : 1024;
+    const long tail = (long)(NCH * B3_CO_CHUNK + B3_MAXG + 4) * 4 + 16 * 16 + 256;
+    long cap = (160L * 1024 - 2L * NCH * B3Q_SLAB16 * 16 - tail) / ((long)NXT * 2 * pl.cgs * 48);
+    cap = (cap / 16) * 16;
+    const int TRq = (q_on && pl.MT == 4 && !pl.pipelined && cap >= 64) ? b3_rows(T, OH, OW, hr, hc, (int)cap) : 0;
+    if (TRq >= 1) {
+      const int th = TRq + hr, tw = OW + hc;
+      const int xs = (pl.cgs * th * tw + GT - 1) / GT;
+      // at least 6 of the 8 pixel slices of 32 must be busy (small images stay on the 4-wave kernels), and in ST mode the
+      // batch must provide pairs of images
+      if (xs <= 2 && TRq * OW >= 192 && (!stm || N >= 2)) {
+        a.TR = TRq; a.tile_h = th; a.tile_w = tw;
+        a.plane16 = ((th * tw + 15) / 16) * 16;
+        a.tiles_per_img = (OH + TRq - 1) / TRq;
+        for (int g = 0; g < pl.groups; ++g) {
+          const int t = g / pl.cgs, cg = g - t * pl.cgs;
+          a.g_tapoff[g] = (tap_dr[t] - a.min_dr) * tw + (tap_dc[t] - a.min_dc);
+          a.g_cg[g] = cg;
+        }
+        for (int g = pl.groups; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }
+        a.xslots = pl.cgs * th * tw;
+        const size_t x16 = (size_t)NXT * 2 * pl.cgs * 3 * a.plane16;
+        a.dump16 = (int)x16;
+        a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
+        size_t shmem = ((size_t)a.w_off16 + 2 * NCH * B3Q_SLAB16) * 16;
+        a.ep_off = 0;
+        a.b_off = (int)(shmem / 4);
+        shmem += (size_t)(NCH * B3_CO_CHUNK + B3_MAXG + 4) * sizeof(float);
+        PG_REQUIRE(shmem <= (size_t)160 * 1024, PG_ESHAPE, "pg_conv2d_mfma(bf16x3, overlapped): %zu B of LDS", shmem);
+        const int chunks_y = stm ? b3_chunks(Cout) : Cout / (2 * B3_CO_CHUNK);
+        long want = 256 / chunks_y;  // resident workgroups: 1 per CU
+        if (want < a.tiles_per_img) want = a.tiles_per_img;
+        long gx = (want / a.tiles_per_img) * a.tiles_per_img;
+        const long units = (stm ? (long)(N + 1) / 2 : (long)N) * a.tiles_per_img;  // ST: a workgroup takes images in pairs
+        if (gx > units) gx = units;
+        const dim3 grid((unsigned)gx, (unsigned)chunks_y);
+        const B3Launch l = {3, 4, xs, stm ? 1 : 0, 0, 0, grid, shmem};
+        if (gelu) pg_b3_dispatch_gelu(a, l, st);
+        else b3_dispatch<false>(a, l, st);
+        PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, overlapped)");
+        return 0;
+      }
+    }
+  }
   for (int g = 0; g < pl.groups; ++g) {
     const int t = g / pl.cgs, cg = g - t * pl.cgs;
     a.g_tapoff[g] = (tap_dr[t] - a.min_dr) * a.tile_w + (tap_dc[t] - a.min_dc);

@@ -55,7 +55,7 @@ struct B3Args {
 // Which instantiation takes a launch: decided by the host code of conv_b3.hip, executed in the translation unit
 // that holds the instantiations for GL (conv_b3.hip: GL = false; conv_b3_gelu.hip: GL = true).
 struct B3Launch {
-  int pw;            // 2: conv_b3p_kernel (pipelined, 4 taps), 1: conv_b3_pw_kernel, 0: conv_b3_kernel
+  int pw;            // 3: conv_b3q_kernel (overlapped, 16 waves), 2: conv_b3p_kernel (pipelined, 4 taps), 1: conv_b3_pw_kernel, 0: conv_b3_kernel
   int MT, nt, CG, ms, w9;
   dim3 grid;
   size_t shmem;
@@ -1329,6 +1329,8 @@ if constexpr (GL) {
 #undef PG_PW_MFMA
 }
 
+#include "conv_b3q_kernel.h"
+
 template <bool GL, int MT, int CG = 1, bool MS = false, bool W9 = false>
 void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
   // the LDS opt-in is set once per instantiation by a function-local static initialiser: thread-safe
@@ -1383,6 +1385,10 @@ void b3_pw_launch(const B3Args& a, dim3 grid, size_t shmem, hipStream_t st) {
 
 template <bool GL>
 void b3_dispatch(const B3Args& a, const B3Launch& l, hipStream_t st) {
+  if (l.pw == 3) {  // the overlapped 16-wave kernel (conv_b3q_kernel.h): nt = staging slots per thread, CG = 1 for two tiles per workgroup
+    b3q_launch<GL>(a, l.nt, l.CG != 0, l.grid, l.shmem, st);
+    return;
+  }
   if (l.pw == 2) {  // the pipelined 4-tap kernel
     b3p_launch<GL>(a, l.nt, l.CG, l.grid, l.shmem, st);  // (CG carries the waves per workgroup: 4 / 8)
     return;

@@ -231,6 +231,10 @@ PG_EXPORT int pg_gauss_head_fwd(const float* q, const float* p, const float* eps
   const size_t CL = (size_t)C * L;
   int bx = (int)((CL + VT - 1) / VT);
   if (bx > 64) bx = 64;
+  // bit-reproducible mode (pg_attn_fused_bwd(0) = ops.set_deterministic): ONE block per sample, so that kl[n] is a fixed-order
+  // sum instead of an arrival-order sum of up to 64 block partials (last-bit differences run to run, found by the twin-process
+  // self-check of round 6; the value feeds no gradient — d loss / d kl is a constant — but it is a module output)
+  if (pg_attn_fused_bwd(-1) == 0) bx = 1;
   hipLaunchKernelGGL(gauss_fwd_kernel, dim3(bx, N), dim3(VT), 0, VST, a);
   PG_LAUNCH_CHECK("pg_gauss_head_fwd");
   return 0;

@@ -1014,7 +1014,10 @@ def set_deterministic(on=True):
     """Bit-reproducible gradients (on) or the fastest kernels (off, the default). The only kernels whose
     result depends on timing are the fused attention backwards for d_k = 4 (d_v = 4: ImageGPT; d_v = 16 / 32:
     PixelSNAIL, round 4) — dQ is summed over key blocks in arrival order: last-bit differences run to run;
-    `on` selects the two-kernel backward.
+    `on` selects the two-kernel backward, and the per-sample KL sums of the Gaussian heads are then reduced by one
+    workgroup per sample (fixed order). Still summed with fp32 atomics in arrival order, because they feed no gradient
+    and no parameter: the scalar loss values (BCE / DMOL / VQ) and the squared gradient norm that `FlatAdam` reports
+    (it only scales the step above max_norm = 1e50).
     Returns the previous setting."""
     prev = _lib.load().pg_attn_fused_bwd(0 if on else 1)
     return prev == 0

@@ -195,6 +195,12 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pytorch_generative_amd import graph, ops, parallel
 
+    if mode == "same":
+        # identical batches on every rank: with the bit-reproducible kernels the averaged gradient IS the 1-GPU gradient
+        # (x + x and the 1/2 pre-scale are exact), so the comparison needs no allowance for Adam amplifying the last-bit
+        # run-to-run differences of the fused attention backwards' atomic dQ deposits
+        ops_mod = __import__("pytorch_generative_amd.ops", fromlist=["ops"])
+        ops_mod.set_deterministic(True)
     model, opt = build(dev, seed=rank, kind=kind)  # different seeds: the broadcast must make them equal
     red = parallel.FlatGradAllReduce(opt)
     red.broadcast_parameters(src=0)

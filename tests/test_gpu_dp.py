@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 
-def _single_gpu_reference(kind="igpt"):
+def _single_gpu_reference(kind="igpt", deterministic=False):
     import dp_worker
     from pytorch_generative_amd import graph, ops
 
@@ -27,6 +27,7 @@ def _single_gpu_reference(kind="igpt"):
     dev = torch.device("cuda", 0)
     model, opt = dp_worker.build(dev, seed=0, kind=kind)
     loss_fn, fwd = dp_worker.step_functions(kind, model)
+    was = ops.set_deterministic(deterministic)
     try:
         data = dp_worker.batches(kind=kind)
         step = graph.GraphedTrainStep(model, opt, loss_fn, data[0].to(dev), preserve_state=True, forward_fn=fwd)
@@ -34,6 +35,7 @@ def _single_gpu_reference(kind="igpt"):
         torch.cuda.synchronize()
     finally:
         vaes.set_noise_fn(None)
+        ops.set_deterministic(was)
     return {k: v.detach().cpu() for k, v in model.named_parameters()}, losses, opt.current_lr()
 
 
@@ -53,7 +55,7 @@ def _run_world2(mode, out, kind="igpt"):
 @pytest.mark.parametrize("mode,kind", [("same", "igpt"), ("shard", "igpt"), ("shard", "gated"), ("same", "snail"),
                                        ("shard", "snail"), ("same", "vd_vae")])
 def test_two_ranks_equal_one_gpu(tmp_path, mode, kind):
-    want, want_losses, want_lr = _single_gpu_reference(kind)
+    want, want_losses, want_lr = _single_gpu_reference(kind, deterministic=mode == "same")
     got = _run_world2(mode, str(tmp_path / f"dp_{mode}.pt"), kind)
     if kind == "gated":  # parameters that never receive a gradient stay exactly where the broadcast put them
         import dp_worker
@@ -74,8 +76,13 @@ def test_two_ranks_equal_one_gpu(tmp_path, mode, kind):
             # reference too (see test_golden_step_flat_adam); only bounded by lr per step here
             assert float((g - w).abs().max()) <= 3 * 2 * 5e-3, k
             continue
-        err = float((g - w).abs().max() / w.abs().max().clamp_min(1e-12))
-        assert err <= (2e-6 if mode == "same" else 5e-5), f"{k} after 3 data-parallel steps: {err:.2e}"
+        d, pmax = float((g - w).abs().max()), float(w.abs().max().clamp_min(1e-12))
+        # "same" (bit-reproducible kernels on both sides): equal up to the rounding of the flat all-reduce; "shard": the two
+        # half-batch gradients are summed in another order than the 1-GPU kernels sum the whole batch (~1e-6 of a tensor's
+        # max), and Adam's normalised update turns a RELATIVE change e of a gradient entry into e * lr per step — small
+        # entries (1e-3 of the max) therefore move by a few 1e-3 * lr per step, independent of the parameter's own scale
+        tol = 2e-6 * pmax if mode == "same" else 5e-5 * pmax + 3e-3 * 3 * 5e-3
+        assert d <= tol, f"{k} after 3 data-parallel steps: |diff| {d:.2e} > {tol:.2e} (max |param| {pmax:.2e})"
     for i, w in enumerate(want_losses):
         per_rank = [l[i] for l in got["losses"]]
         mean = sum(per_rank) / len(per_rank)  # global loss = mean of the per-rank means

@@ -67,8 +67,24 @@ def one(batch, cin, cout, hw, k, act):
               f"   (min {p[:, i].min():.0f} max {p[:, i].max():.0f})")
     rest = mean[6] - mean[:6].sum()
     print(f"    prologue+rest {rest:9.0f} cycles = {100 * rest / mean[6]:5.1f} %")
+    if os.environ.get("PG_PROF_BY_WAVE"):  # conv_b3q_kernel (16 waves per workgroup): the mean per wave index of a workgroup
+        W = int(os.environ["PG_PROF_BY_WAVE"])
+        pw = prof.view(-1, 8).cpu().double()
+        pw = pw[: (pw.shape[0] // W) * W].view(-1, W, 8)
+        live = pw[:, 0, 6] > 0
+        pw = pw[live].mean(0)
+        for w in range(W):
+            print(f"      wave {w:2d}: " + "  ".join(f"{NAMES[i]} {pw[w, i] / max(pw[w, 7], 1):6.0f}" for i in range(6)))
 
 
+if __name__ == "__main__" and sys.argv[1:2] == ["q"]:
+    # conv_b3q_kernel (round 6; its phases: mfma = MFMA block, bar1 = barrier, commit = side work, issue = load retire + DMA issue,
+    # epilogue, bar2 = wait for the slab)
+    for cin, cout, k in ((256, 256, 1), (128, 256, (1, 2, 0, 1)), (256, 256, (2, 1, 1, 0)), (128, 256, (1, 3, 0, 1))):
+        one(512, cin, cout, 32, k, ops.ACT_NONE)
+    one(1024, 64, 128, 32, (2, 2, 1, 1), ops.ACT_ELU)
+    one(64, 160, 320, 32, (2, 3, 1, 1), ops.ACT_NONE)
+    sys.exit(0)
 if __name__ == "__main__" and sys.argv[1:2] == ["gated"]:
     # the shapes of GatedPixelCNN's layers (wide kernel, batch 512) and PixelCNN++'s (160 filters, batch 64)
     for cin, cout, k in ((256, 256, 1), (128, 256, 1), (128, 128, 1), (128, 256, (1, 2, 0, 1)), (128, 256, (2, 1, 1, 0)),
