@@ -387,18 +387,29 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     // workgroup per CU, up to 160 KB) = x tiles [NXT][2 buffers][cgs][3 pieces][plane16] | dump entry | slab ring [2][NCH][768] |
     // bias, K-group table; two output chunks share one x tile when Cout % 128 == 0, otherwise two tiles share one slab.
     static const bool q_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3Q"); return !(e && e[0] == '0'); }();
+    // Measured on MI355X (round 6, tools/exp/q_ab.py, same box, median of 5 x 20 launches, forward; profiles/r06_conv_q_ab.txt):
+    //   two tiles per workgroup (ST): PixelCNN++'s 2x3 160 -> 320 265 -> 243 us, 320 -> 160 301 -> 283 us at batch 64 — taken;
+    //     2x3 160 -> 160 152 -> 160 us and the 16 x 16 level (one 256-pixel tile per image: 96-160 workgroups for 256 CUs) 97 -> 147 us — not;
+    //   two output chunks per workgroup (CG, GatedPixelCNN / PixelSNAIL 64 -> 128): 3-6 % SLOWER than the 8-wave wide kernel on every
+    //     shape (1x1 256 -> 256 446 -> 463 us, 2x1 755 -> 792, 1x2 426 -> 439, 1x3 641 -> 675, 2x2 64 -> 128 392 -> 416): sixteen waves that
+    //     meet at one barrier per K step run their phases in lockstep, and the kernel's ablation (profiles/r06_conv_q_ablation.txt) shows the
+    //     phases ADD UP (MFMA 200 + loads / commit 130 + epilogue 95 + slab DMA 28 + empty K-step loop 100 of 564 us) instead of overlapping:
+    //     the epilogue alone streams at 5.6 TB/s, i.e. at the HBM write rate, while no wave computes. Not taken (PG_CONV_B3Q_CG=1 in the ab
+    //     library runs it for A/B).
+    static const bool q_cg = []() { const char* e = PG_AB_ENV("PG_CONV_B3Q_CG"); return e && e[0] == '1'; }();
     const bool stm = Cout % (2 * B3_CO_CHUNK) != 0;
     const int NCH = stm ? 1 : 2, NXT = stm ? 2 : 1, GT = stm ? 512 : 1024;
     const long tail = (long)(NCH * B3_CO_CHUNK + B3_MAXG + 4) * 4 + 16 * 16 + 256;
     long cap = (160L * 1024 - 2L * NCH * B3Q_SLAB16 * 16 - tail) / ((long)NXT * 2 * pl.cgs * 48);
     cap = (cap / 16) * 16;
-    const int TRq = (q_on && pl.MT == 4 && !pl.pipelined && cap >= 64) ? b3_rows(T, OH, OW, hr, hc, (int)cap) : 0;
+    const bool q_shape = stm ? (T >= 6 && (Cin >= 256 || Cout >= 256)) : q_cg;
+    const int TRq = (q_on && q_shape && pl.MT == 4 && !pl.pipelined && cap >= 64) ? b3_rows(T, OH, OW, hr, hc, (int)cap) : 0;
     if (TRq >= 1) {
       const int th = TRq + hr, tw = OW + hc;
       const int xs = (pl.cgs * th * tw + GT - 1) / GT;
       // at least 6 of the 8 pixel slices of 32 must be busy (small images stay on the 4-wave kernels), and in ST mode the
       // batch must provide pairs of images
-      if (xs <= 2 && TRq * OW >= 192 && (!stm || N >= 2)) {
+      if (xs <= 2 && TRq * OW >= 192 && (!stm || N >= 2) && (OH + TRq - 1) / TRq >= 2) {
         a.TR = TRq; a.tile_h = th; a.tile_w = tw;
         a.plane16 = ((th * tw + 15) / 16) * 16;
         a.tiles_per_img = (OH + TRq - 1) / TRq;

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(B3Q_THREADS, 4) conv_b3q_kernel(const B3Args a
   // wave roles: a slice beyond the tile's pixels has nothing to compute; the order of side work and MFMA block alternates
   // between the two wave pairs of a SIMD (waves w, w + 4, w + 8, w + 12 share one)
   const bool has_px = slice * (NT * 16) < npx;
-    const bool mfma_first = ((wave >> 2) & 1) != 0;
+    const bool mfma_first = ((wave >> 2) & 1) != 0 && !PG_DBG_BIT(a.dbg, 32);
 
   int pixoff[NT];
 #pragma unroll
@@ -163,15 +163,12 @@ __global__ void __launch_bounds__(B3Q_THREADS, 4) conv_b3q_kernel(const B3Args a
   // for its own pieces with an explicit s_waitcnt before the barrier that publishes the stage.
   const float4* wsrc_b = reinterpret_cast<const float4*>(a.wfrag) + (size_t)blockIdx.y * NCH * nchunk * a.wslab4 + lane;
   const unsigned lds_b = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
-#define PG_Q_DMA(Q)                                                                             \
+#define PG_Q_DMA(J, KS, STAGE)  /* (channel chunk, K step) of the slab, ring stage */          \
   {                                                                                             \
-    const int cs_ = (Q) / a.ksteps;                                                             \
-    const int ks_ = (Q) - cs_ * a.ksteps;                                                       \
-    const int j_ = cs_ % nchunk;                                                                \
     for (int p_ = wave; p_ < NCH * 12; p_ += 16) {                                              \
       const int c_ = p_ / 12, r_ = p_ - c_ * 12;                                                \
-      const float4* g_ = wsrc_b + ((size_t)c_ * nchunk + j_) * a.wslab4 + ks_ * B3Q_SLAB16 + r_ * 64; \
-      const unsigned d_ = lds_b + (unsigned)(a.w_off16 + (((Q) & 1) * NCH + c_) * B3Q_SLAB16 + r_ * 64) * 16u; \
+      const float4* g_ = wsrc_b + ((size_t)c_ * nchunk + (J)) * a.wslab4 + (KS) * B3Q_SLAB16 + r_ * 64; \
+      const unsigned d_ = lds_b + (unsigned)(a.w_off16 + ((STAGE) * NCH + c_) * B3Q_SLAB16 + r_ * 64) * 16u; \
       unsigned keep_;                                                                           \
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
                    : "=&s"(keep_) : "v"(g_), "s"(d_) : "memory");                               \
@@ -184,7 +181,7 @@ __global__ void __launch_bounds__(B3Q_THREADS, 4) conv_b3q_kernel(const B3Args a
   // the MFMA block of one K step: B fragments of the wave's two pixel groups resident, A fragments in two halves of two
   // output tiles (24 + 24 fragment registers)
 #define PG_Q_MFMA(KS, XBUF, STAGE)                                                              \
-  if (has_px && tile_ok) {                                                                      \
+  if (has_px && tile_ok && !PG_DBG_BIT(a.dbg, 4)) {                                             \
     const bf16x8* xb_ = xl + (XBUF) * xbuf16 + gtab[4 * (KS) + kq];                             \
     const bf16x8* wb_ = wl + (STAGE) * (NCH * B3Q_SLAB16);                                      \
     bf16x8 bf_[NT][3];                                                                          \
@@ -197,17 +194,14 @@ __global__ void __launch_bounds__(B3Q_THREADS, 4) conv_b3q_kernel(const B3Args a
       bf16x8 ah_[QMH][3];                                                                       \
       _Pragma("unroll") for (int m = 0; m < QMH; ++m)                                           \
         _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) ah_[m][pc] = wb_[((QMH * mh + m) * 3 + pc) * 64]; \
-      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                            \
-        _Pragma("unroll") for (int m = 0; m < QMH; ++m) {                                       \
-          f32x4 c = acc[QMH * mh + m][n];                                                       \
-          c = MFMA16B(ah_[m][2], bf_[n][0], c);  /* small terms first */                        \
-          c = MFMA16B(ah_[m][0], bf_[n][2], c);                                                 \
-          c = MFMA16B(ah_[m][1], bf_[n][1], c);                                                 \
-          c = MFMA16B(ah_[m][1], bf_[n][0], c);                                                 \
-          c = MFMA16B(ah_[m][0], bf_[n][1], c);                                                 \
-          c = MFMA16B(ah_[m][0], bf_[n][0], c);                                                 \
-          acc[QMH * mh + m][n] = c;                                                             \
-        }                                                                                       \
+      /* the six piece products of one accumulator form a dependent chain ("small terms first"): the chains of the QMH x NT \
+         tiles are interleaved term by term, so that consecutive MFMAs never wait for each other's result */ \
+      _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                           \
+        constexpr int pa_[6] = {2, 0, 1, 1, 0, 0}, pb_[6] = {0, 2, 1, 0, 1, 0};                 \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                          \
+          _Pragma("unroll") for (int m = 0; m < QMH; ++m)                                       \
+            acc[QMH * mh + m][n] = MFMA16B(ah_[m][pa_[t]], bf_[n][pb_[t]], acc[QMH * mh + m][n]); \
+      }                                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                        \
     }                                                                                           \
   }
@@ -215,14 +209,14 @@ __global__ void __launch_bounds__(B3Q_THREADS, 4) conv_b3q_kernel(const B3Args a
   // buffer, then request the chunk after it
 #define PG_Q_SIDE(XBUF)                                                                         \
   {                                                                                             \
-    if (more) { PG_Q_COMMIT_X((XBUF) ^ 1) }                                                     \
-    if (more2) { PG_Q_ISSUE_X() }                                                               \
+    if (more && !PG_DBG_BIT(a.dbg, 2)) { PG_Q_COMMIT_X((XBUF) ^ 1) }                            \
+    if (more2 && !PG_DBG_BIT(a.dbg, 1)) { PG_Q_ISSUE_X() }                                      \
     __builtin_amdgcn_sched_barrier(0);                                                          \
   }
 
   // prologue: chunk step 0 committed, its first slab landed, chunk step 1 in the registers
   PG_Q_ISSUE_X()
-  PG_Q_DMA(0)
+  PG_Q_DMA(0, 0, 0)
   PG_Q_COMMIT_X(0)
   if (nsteps > 1) { PG_Q_ISSUE_X() }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -231,6 +225,11 @@ __global__ void __launch_bounds__(B3Q_THREADS, 4) conv_b3q_kernel(const B3Args a
   // phase clocks (ablation builds only, tools/exp/b3_phase_prof.py): 0 MFMA block, 1 barrier, 2 side work, 3 load retire + DMA issue,
   // 4 epilogue, 5 wait for the slab
   PG_PROF_DECL
+#ifdef PG_ABLATE
+#define PG_Q_MARK(I) if (a.prof) PG_PROF_MARK(I)   /* no clock reads (s_memtime + lgkmcnt wait) in the plain ablation timings */
+#else
+#define PG_Q_MARK(I)
+#endif
   int q = 0, chunk = 0, tl = 0;
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
@@ -248,26 +247,33 @@ __global__ void __launch_bounds__(B3Q_THREADS, 4) conv_b3q_kernel(const B3Args a
         // model — is in flight
         __builtin_amdgcn_s_waitcnt(0x0F70);
       }
-      if (more_q) PG_Q_DMA(q + 1)
-      PG_PROF_MARK(3)
+      if (more_q && !PG_DBG_BIT(a.dbg, 16)) {
+        // the next K step's slab: the same chunk's next K step, or the first K step of the next chunk (no divisions: a
+        // wave-uniform integer division is ~25 VALU instructions, and the youngest waves of a SIMD get the leftover issue
+        // slots — the first version spent 1 200-2 500 cycles per K step here, profiles/r06_conv_q_phase_clocks.txt)
+        const bool same_ = ks + 1 < a.ksteps;
+        const int nj_ = same_ ? chunk : (chunk + 1 == nchunk ? 0 : chunk + 1);
+        PG_Q_DMA(nj_, same_ ? ks + 1 : 0, stage ^ 1)
+      }
+      PG_Q_MARK(3)
       if (side_before) PG_Q_SIDE(cur)
-      PG_PROF_MARK(2)
+      PG_Q_MARK(2)
       PG_Q_MFMA(ks, cur, stage)
-      PG_PROF_MARK(0)
+      PG_Q_MARK(0)
       // (side-after waves: the commit waits for this wave's x loads — issued one chunk step ago, at the end of that step — with
       // a vmcnt(0) of the compiler's; by then the slab DMA issued above has had the whole MFMA block to land)
       if (side_after) PG_Q_SIDE(cur)
-      PG_PROF_MARK(2)
+      PG_Q_MARK(2)
       // this K step's DMA is older than the x loads a side block issued behind it (8 per slot): wait for everything but those
       if (ks == 0 && more2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * XS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PG_PROF_MARK(5)
+      PG_Q_MARK(5)
       if (ks + 1 == a.ksteps && ++chunk == nchunk) {
         chunk = 0;
         // ---- epilogue of the tile: v = out_act(acc + bias) * act'(dact_src) + res + res2
         const int n_img = PG_Q_IMG(tl);
         ++tl;
-        if (has_px && tile_ok) {
+        if (has_px && tile_ok && !PG_DBG_BIT(a.dbg, 8)) {
           int Lv = L;
           asm volatile("" : "+s"(Lv));
           const size_t so = ((size_t)n_img * a.Cout + co0) * Lv;
@@ -385,12 +391,13 @@ __global__ void __launch_bounds__(B3Q_THREADS, 4) conv_b3q_kernel(const B3Args a
           for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         // (the epilogue's loads / stores are younger than this K step's DMA, which the wait above has retired)
       }
-      PG_PROF_MARK(4)
+      PG_Q_MARK(4)
       if (more_q) __syncthreads();  // the other x buffer / slab stage are committed; every wave is done with the current ones
-      PG_PROF_MARK(1)
+      PG_Q_MARK(1)
     }
   }
   PG_PROF_DUMP(16, wave, nq)
+#undef PG_Q_MARK
 #undef PG_Q_IMG
 #undef PG_Q_ISSUE_X
 #undef PG_Q_COMMIT_SLOT

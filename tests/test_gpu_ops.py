@@ -54,6 +54,11 @@ CONV_CASES = [
     (2, 32, 10, 16, 128, 1, 3, 0, 1, None, None, "gelu", True, True),   # 3 taps, two co chunks
     (2, 96, 7, 24, 64, 2, 1, 2, 0, "hw", None, "elu", False, True),     # 2 taps, ragged last row tile
     (1, 32, 64, 64, 64, 2, 2, 1, 1, "hw", None, None, False, True),     # 64 wide: one row per tile
+    # round 6: the overlapped 16-wave kernel (conv_b3q_kernel.h), two tiles per workgroup sharing one weight slab: 6 taps with >= 256
+    # channels on one side (PixelCNN++'s 2x3 convolutions); odd batch = an idle half in the last round, Cout % 64 != 0 = a partial chunk
+    (3, 320, 32, 32, 160, 2, 3, 1, 1, "hw", None, None, False, True),    # forward on Q (Cin 320), data gradient 160 -> 320 on Q too
+    (5, 160, 32, 32, 320, 2, 3, 1, 1, "hw", None, "elu", True, True),    # + residual + fused input activation
+    (2, 256, 24, 32, 96, 2, 3, 1, 1, "hw", None, None, False, False),    # 24 rows: ragged last row tile, 96 output channels
     # bench regime: N * tiles_per_img above the persistent grid -> several tiles per workgroup, ragged last round
     (300, 64, 32, 32, 64, 2, 2, 1, 1, "hw", None, "elu", True, True),   # PixelSNAIL 2x2 64->64: 1200 tiles / 512
     (150, 64, 32, 32, 128, 2, 2, 1, 1, "hw", None, "elu", False, True),  # 64->128: 600 tiles / 256 per chunk row

@@ -18,15 +18,21 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
 
-def timeit(fn, iters=10):
-    fn()
-    fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
+def timeit(fn, iters=20, reps=5):
+    """median over `reps` event-timed windows of `iters` calls (single windows show 10x outliers on a fresh box)"""
+    for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters * 1e6
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters * 1e3)
+    return sorted(ts)[len(ts) // 2]
 
 
 # name, (cin, cout, kernel, padding), crop to the input size?, forward kwargs, image size, bench batch
