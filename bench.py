@@ -189,8 +189,39 @@ class Env:
         torch.cuda.synchronize()
 
 
+class _Watchdog:
+    """A rank that BLOCKS (instead of raising) while it captures or warms up next to a live communicator would hang the whole job:
+    every other rank then waits inside a collective that never completes. While armed, a daemon thread ends THIS process with
+    exit code 3 after `seconds`; the launcher (bench.py's own _self_spawn, or torch.distributed.run) then stops the other ranks,
+    so the command fails instead of hanging until the caller's timeout. PG_BENCH_CAPTURE_TIMEOUT_S (default 300; 0 disables)."""
+
+    def __init__(self, what, rank):
+        self.seconds = float(os.environ.get("PG_BENCH_CAPTURE_TIMEOUT_S", "300"))
+        self.what, self.rank, self.timer = what, rank, None
+
+    def _fire(self):
+        sys.stderr.write(f"[bench] FATAL rank {self.rank}: {self.what} did not finish within {self.seconds:g} s "
+                         "(PG_BENCH_CAPTURE_TIMEOUT_S); aborting this rank so that the job fails instead of hanging\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import threading
+
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
 def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=False, min_seconds=0.0,
-                 same_batch=False, single=False, keep_params=False):
+                 same_batch=False, single=False, keep_params=False, x_override=None):
     """Builds the model, captures the step and times EXACTLY `steps` steps between barriers
     (max over ranks). Returns the record of this workload at this per-GPU batch.
 
@@ -216,7 +247,10 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
         reducer.broadcast_parameters(src=0)
         if os.environ.get("PG_BENCH_FORCE_SPLIT") == "1":  # diagnosis: two graphs around an eager collective even where it is capturable
             reducer.force_split = True
-    x = workload_input(name, synthetic_batch(batch, 0 if same_batch else env.rank, w["chw"])).to(env.device)
+    if x_override is not None:  # --dp-parity's shard equality: this rank's shard of a global batch / the whole global batch
+        x, batch = x_override.to(env.device), int(x_override.shape[0])
+    else:
+        x = workload_input(name, synthetic_batch(batch, 0 if same_batch else env.rank, w["chw"])).to(env.device)
     loss_fn = make_loss_fn(name)
 
     def eager_step():
@@ -232,7 +266,9 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
     if use_graph:
         try:
             try:
-                gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
+                with _Watchdog(f"hipGraph capture of {name} (warm-up steps + capture"
+                               + (", RCCL all-reduce inside)" if reducer is not None and reducer.capturable else ")"), env.rank):
+                    gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
             except Exception as e1:  # capture with the collective inside failed: retry with it between two graphs
                 if reducer is None or not reducer.capturable:
                     raise
@@ -241,7 +277,8 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
                       file=sys.stderr, flush=True)
                 torch.cuda.synchronize()
                 reducer.force_split = True
-                gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
+                with _Watchdog(f"hipGraph capture of {name} (two graphs around an eager all-reduce)", env.rank):
+                    gstep = graph.GraphedTrainStep(model, opt, loss_fn, x, reducer=reducer, warmup_iters=2)
             step = lambda: gstep()  # noqa: E731
             launch = "hipGraph replay" if not gstep.split else "two hipGraphs around an eager all-reduce"
         except Exception as e:  # e.g. capture refused next to a live RCCL communicator
@@ -251,13 +288,18 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
             torch.cuda.synchronize()
             if require_graph:
                 raise SystemExit(f"--require-graph: capture failed on rank {env.rank}: {fallback}")
+    launch_by_rank = [launch]
     if env.world > 1 and not single:  # every rank must take the same path (graphs imply a different collective order)
-        flag = torch.tensor([1 if launch == "eager" else 0], device=env.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()) == 1 and launch != "eager":
+        with _Watchdog("agreeing on the launch mode with the other ranks", env.rank):
+            modes = [None] * env.world
+            dist.all_gather_object(modes, launch)
+        launch_by_rank = modes  # what every rank ended its capture attempt in, before any fallback to a common mode
+        kinds = set(modes)
+        if len(kinds) > 1:  # mixed: a graph with the collective inside, split graphs and eager launches order it differently
             if require_graph:
-                raise SystemExit("--require-graph: another rank fell back to eager launches")
-            step, launch, fallback = eager_step, "eager", "another rank failed to capture"
+                raise SystemExit(f"--require-graph: the ranks ended in different launch modes: {modes}")
+            step, launch = eager_step, "eager"
+            fallback = fallback or f"the ranks ended in different launch modes ({modes}); all of them run eager launches"
 
     for _ in range(warmup):
         loss = step()
@@ -294,7 +336,7 @@ def run_workload(env, name, batch, steps, warmup, use_graph=True, require_graph=
     rec = {
         "images_per_s": value, "ms_per_step": elapsed / steps * 1e3, "timed_steps": steps, "timed_seconds": elapsed,
         "per_gpu_batch": batch,
-        "global_batch": batch * nranks, "launch": launch, "graph_fallback": fallback,
+        "global_batch": batch * nranks, "launch": launch, "graph_fallback": fallback, "launch_by_rank": launch_by_rank,
         # each rank's own clock between the two barriers (the job's rate uses the MAX)
         "per_rank_images_per_s": {"min": batch * steps / max(per_rank), "max": batch * steps / min(per_rank)},
         "grad_exchange": None if reducer is None else
@@ -725,6 +767,22 @@ def dp_parity(env, args, run):
     dp = run(name, args.batch, same_batch=True, keep_params=True)
     one = run(name, args.batch, same_batch=True, single=True, keep_params=True)
     ops.set_deterministic(was)
+    # SURVEY.md section 8(e)'s second equality: N DISTINCT shards == the 1-GPU step on the concatenated batch (loss = mean of the
+    # per-rank means, gradient = mean of the per-rank gradients; DistributedDataParallel's averaging, trainer.py:78-82). Not bit
+    # exact: the one replica sums N * B images in another order than N ranks sum B each (~1e-6 of a gradient tensor's maximum),
+    # and Adam's normalised update turns a relative change e of a gradient entry into e * lr per step.
+    w = WORKLOADS[name]
+    shards = [workload_input(name, synthetic_batch(args.batch, r, w["chw"])) for r in range(env.world)]
+    shard = run(name, args.batch, x_override=shards[env.rank], keep_params=True)
+    whole = run(name, args.batch, x_override=torch.cat(shards, 0), single=True, keep_params=True)
+    p_shard, p_whole = shard.pop("_flat_param"), whole.pop("_flat_param")
+    n_steps = (2 if shard["launch"] != "eager" else 0) + args.warmup + args.steps
+    sh = torch.tensor([float((p_shard - p_whole).abs().max()), float(p_whole.abs().max())], device=env.device, dtype=torch.float64)
+    if env.world > 1:
+        dist.all_reduce(sh, op=dist.ReduceOp.MAX)
+    shard_diff, shard_pmax = (float(v) for v in sh)
+    shard_tol = 5e-5 * shard_pmax + 3e-3 * n_steps * w["lr"]
+    shard_ok = shard_diff <= shard_tol
     mine, alone = dp.pop("_flat_param"), one.pop("_flat_param")
     root = mine.clone()
     if env.world > 1:
@@ -735,9 +793,8 @@ def dp_parity(env, args, run):
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     vs_root, vs_one, pmax = (float(v) for v in stats)
     pow2 = env.world & (env.world - 1) == 0
-    ok = vs_root == 0.0 and (vs_one == 0.0 if pow2 else vs_one <= 1e-6 * pmax)
+    ok = vs_root == 0.0 and (vs_one == 0.0 if pow2 else vs_one <= 1e-6 * pmax) and shard_ok
     if env.rank == 0:
-        w = WORKLOADS[name]
         digest = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16]  # noqa: E731
         print(json.dumps({
             "metric": f"training images/sec ({w['ctor']}, {w['chw'][1]}x{w['chw'][2]}x{w['chw'][0]}) with the data-parallel "
@@ -754,12 +811,20 @@ def dp_parity(env, args, run):
                 "steps_compared": 2 + args.warmup + args.steps if dp["launch"] != "eager" else args.warmup + args.steps,
                 "params_sha256_16": {"rank0_of_the_job": digest(mine), "one_rank_run": digest(alone)},
                 "what": "max over ranks of |params - rank 0's params| and |params - params of a 1-rank run of the same "
-                        "steps on the same batch| (SURVEY.md section 8(e): same batch on all ranks == 1 GPU)"},
+                        "steps on the same batch| (SURVEY.md section 8(e): same batch on all ranks == 1 GPU)",
+                "shards": {"ok": shard_ok, "max_abs_diff_vs_one_rank_run_on_the_concatenated_batch": shard_diff,
+                           "tolerance": shard_tol, "param_abs_max": shard_pmax, "steps_compared": n_steps,
+                           "launch": shard["launch"], "launch_by_rank": shard["launch_by_rank"],
+                           "what": "rank r trains on its own shard (seed 1234 + r), one replica on the concatenation of all "
+                                   "shards: SURVEY.md section 8(e)'s 'N distinct shards == 1 GPU on the concatenated batch' "
+                                   "(not bit exact: another summation order; tolerance 5e-5 max|p| + 3e-3 steps lr)"}},
+            "launch_by_rank": dp["launch_by_rank"],
             "one_rank_run": {"images_per_s": one["images_per_s"], "ms_per_step": one["ms_per_step"], "launch": one["launch"]},
             "scaling_efficiency_vs_n1": dp["images_per_s"] / (env.world * one["images_per_s"]),
         }), flush=True)
     if not ok:
-        raise SystemExit(f"--dp-parity FAILED on rank {env.rank}: |p - p_rank0| = {vs_root:.3e}, |p - p_1rank| = {vs_one:.3e}")
+        raise SystemExit(f"--dp-parity FAILED on rank {env.rank}: |p - p_rank0| = {vs_root:.3e}, |p - p_1rank| = {vs_one:.3e}, "
+                         f"shards: |p - p_concatenated| = {shard_diff:.3e} (tolerance {shard_tol:.3e})")
 
 
 def main():
@@ -859,6 +924,7 @@ def main():
                 "parallelism": f"dp{env.world}",
                 "launch": head["launch"],
                 "graph_fallback": head["graph_fallback"],
+                "launch_by_rank": head["launch_by_rank"],  # what every rank's capture attempt ended in (before a common fallback)
             },
             "loss_nats_per_image": head["loss_nats_per_image"],
             "bits_per_dim": head["bits_per_dim"],

@@ -169,6 +169,10 @@ def test_bench_py_dp_parity_mode():
     assert d["params_sha256_16"]["rank0_of_the_job"] == d["params_sha256_16"]["one_rank_run"]
     assert d["param_abs_max"] > 0 and rec["one_rank_run"]["images_per_s"] > 0
     assert 0 < rec["scaling_efficiency_vs_n1"] < 1.5
+    # the second equality of SURVEY.md section 8(e): distinct shards == one replica on the concatenated batch
+    sh = d["shards"]
+    assert sh["ok"] and 0 <= sh["max_abs_diff_vs_one_rank_run_on_the_concatenated_batch"] <= sh["tolerance"]
+    assert len(rec["launch_by_rank"]) == 2 and len(set(rec["launch_by_rank"])) == 1, rec["launch_by_rank"]
 
 
 def test_train_py_two_workers_through_trainer(tmp_path):

@@ -548,3 +548,15 @@ def test_shape_agnostic_entry_points_take_any_size(lib):
         for name, rc in calls:
             assert rc == _NO_DEVICE, (name, n, c, seq, h, w, rc)
     del keep
+
+
+def test_bench_watchdog_aborts_a_rank_that_blocks():
+    """bench.py's capture watchdog (a rank that BLOCKS in warm-up / capture next to a live communicator must end the job, not hang
+    it): armed with a 1-second limit around a block that sleeps, the process must exit with code 3 and say why."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench._Watchdog('a capture that blocks', 0):\n    time.sleep(30)\nprint('survived')") % root
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PG_BENCH_CAPTURE_TIMEOUT_S="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 3, (p.returncode, p.stderr.decode()[-500:])
+    assert b"did not finish within 1 s" in p.stderr and b"survived" not in p.stdout
