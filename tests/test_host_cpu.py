@@ -553,6 +553,9 @@ def test_shape_agnostic_entry_points_take_any_size(lib):
 def test_bench_watchdog_aborts_a_rank_that_blocks():
     """bench.py's capture watchdog (a rank that BLOCKS in warm-up / capture next to a live communicator must end the job, not hang
     it): armed with a 1-second limit around a block that sleeps, the process must exit with code 3 and say why."""
+    import subprocess
+    import sys
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
             "with bench._Watchdog('a capture that blocks', 0):\n    time.sleep(30)\nprint('survived')") % root
