@@ -6,7 +6,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_4x4x1f32((A), (B), (C), 0, 0, 0)
 
 template <int MODE>
-__global__ void __launch_bounds__(512) ub(float* out, int iters) {
+__global__ void __launch_bounds__(1024) ub(float* out, int iters) {
   f32x4 acc[8];
   float x[8];
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -34,6 +34,11 @@ __global__ void __launch_bounds__(512) ub(float* out, int iters) {
       if (MODE == 14) { acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i], 0, 0, 0); x[i] = __builtin_fmaf(x[i], b, a); x[(i + 1) & 7] = __builtin_fmaf(x[(i + 1) & 7], b, a); }
       if (MODE == 15) { acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i], 0, 0, 0); acc[(i + 4) & 7] = MFMA4(a, b, acc[(i + 4) & 7]); }
       if (MODE == 16) { acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i], 0, 0, 0); x[i] = __builtin_amdgcn_exp2f(x[i]); x[(i + 1) & 7] = __builtin_amdgcn_exp2f(x[(i + 1) & 7]); x[(i + 2) & 7] = __builtin_amdgcn_exp2f(x[(i + 2) & 7]); x[(i + 3) & 7] = __builtin_amdgcn_exp2f(x[(i + 3) & 7]); }
+      // round 6: the same bf16 MFMA as a DEPENDENT chain — 17: every MFMA on ONE accumulator, 18: two accumulators alternating,
+      // 19: four (the bf16x3 convolutions chain the six piece products of an accumulator)
+      if (MODE == 17) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[0], 0, 0, 0);
+      if (MODE == 18) acc[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i & 1], 0, 0, 0);
+      if (MODE == 19) acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[i & 3], 0, 0, 0);
       if (MODE == 8) pk[i] = __builtin_elementwise_fma(pk[i], pkb, pka);
       if (MODE == 9) { pk[i] = __builtin_elementwise_fma(pk[i], pkb, pka); acc[i] = MFMA16(a, b, acc[i]); }
       if (MODE == 10) { pk[i] = pk[i] + pka; }
@@ -62,6 +67,9 @@ extern "C" int ub_run(int mode, float* out, int iters, int blocks, int threads, 
     case 14: hipLaunchKernelGGL(ub<14>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 15: hipLaunchKernelGGL(ub<15>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 16: hipLaunchKernelGGL(ub<16>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
+    case 17: hipLaunchKernelGGL(ub<17>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
+    case 18: hipLaunchKernelGGL(ub<18>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
+    case 19: hipLaunchKernelGGL(ub<19>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 8: hipLaunchKernelGGL(ub<8>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 9: hipLaunchKernelGGL(ub<9>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
     case 10: hipLaunchKernelGGL(ub<10>, dim3(blocks), dim3(threads), 0, s, out, iters); break;
