@@ -238,6 +238,13 @@ int pg_act_bwd_from_out(const float* y, const float* res, const float* dy, float
                         int act, void* stream);
 /* out = a + b */
 int pg_add(const float* a, const float* b, float* out, size_t n, void* stream);
+/* out[i] = value: the zero fills of gradient sinks, loss scalars and the VD-VAE decoder's constant top input
+ * (torch.zeros on the reference path, e.g. vd_vae.py:379 torch.zeros_like(...)); a kernel, not a memset node
+ * (a hipMemset2DAsync node of a captured step went wrong from its second replay on: profiles/README.md round 4 item 12) */
+int pg_fill(float* out, float value, size_t n, void* stream);
+/* out[i] = sum_k rows[k][i], k < n_rows <= 32 (rows: HOST array of device pointers, copied into the launch): the sum over the
+ * per-block KL terms of a hierarchical VAE, vd_vae.py:400 `torch.stack(kl_divs).sum(dim=0)`, in one launch */
+int pg_sum_rows(const float* const* rows, int n_rows, float* out, size_t n, void* stream);
 /* y[n,i] = x[n,i] + p[i] (learned positional map, image_gpt.py:86,106); i < per */
 int pg_add_bcast_fwd(const float* x, const float* p, float* y, int N, size_t per, void* stream);
 /* dp[i] += sum_n dy[n,i] */
@@ -257,6 +264,10 @@ int pg_bce_logits_bwd(const float* z, const float* x, const float* gscale, float
 /* 2x2 average pool, stride 2: x (planes, 2*OH, 2*OW) -> y (planes, OH, OW); planes = N*C */
 int pg_avgpool2_fwd(const float* x, float* y, int planes, int OH, int OW, void* stream);
 int pg_avgpool2_bwd(const float* dy, float* dx, int planes, int OH, int OW, void* stream);
+/* the same with a second gradient of the pooled tensor's INPUT added in (dx = 0.25 * expand(dy) + res): the input of an
+ * encoder stack's AvgPool2d is also read by the decoder's top-down blocks (vd_vae.py:224, 141-189), whose gradients arrive
+ * through pass-through aliases — no gradient-sum kernel of autograd */
+int pg_avgpool2_bwd_res(const float* dy, const float* res, float* dx, int planes, int OH, int OW, void* stream);
 /* nearest-neighbour x2 upsample: x (planes, IH, IW) -> y (planes, 2*IH, 2*IW) */
 int pg_upsample2_fwd(const float* x, float* y, int planes, int IH, int IW, void* stream);
 int pg_upsample2_bwd(const float* dy, float* dx, int planes, int IH, int IW, void* stream);

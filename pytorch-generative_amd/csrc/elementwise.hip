@@ -121,6 +121,35 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
   }
 }
 
+__global__ void fill_kernel(float* __restrict__ out, float value, size_t n, int vec) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const size_t n4 = n >> 2;
+    const float4 v = make_float4(value, value, value, value);
+    for (; i < n4; i += stride) reinterpret_cast<float4*>(out)[i] = v;
+    for (size_t t = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) out[t] = value;
+  } else {
+    for (; i < n; i += stride) out[i] = value;
+  }
+}
+
+struct SumRowsArgs {
+  const float* rows[32];
+  float* out;
+  size_t n;
+  int n_rows;
+};
+
+__global__ void sum_rows_kernel(const SumRowsArgs a) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    float s = 0.f;
+    for (int k = 0; k < a.n_rows; ++k) s += a.rows[k][i];  // fixed order: bit-reproducible
+    a.out[i] = s;
+  }
+}
+
 __global__ void mul_inplace_kernel(float* __restrict__ w, const float* __restrict__ m, size_t n) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] *= m[i];
@@ -402,6 +431,28 @@ PG_EXPORT int pg_add(const float* a, const float* b, float* out, size_t n, void*
   hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(vec ? (n + 3) / 4 : n)), dim3(EW_THREADS), 0,
                      EW_STREAM, a, b, out, n, vec);
   PG_LAUNCH_CHECK("pg_add");
+  return 0;
+}
+
+PG_EXPORT int pg_fill(float* out, float value, size_t n, void* stream) {
+  PG_REQUIRE(out, PG_EINVAL, "pg_fill: null pointer");
+  if (n == 0) return 0;
+  const int vec = aligned16(out);
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(vec ? (n + 3) / 4 : n)), dim3(EW_THREADS), 0, EW_STREAM, out, value, n, vec);
+  PG_LAUNCH_CHECK("pg_fill");
+  return 0;
+}
+
+PG_EXPORT int pg_sum_rows(const float* const* rows, int n_rows, float* out, size_t n, void* stream) {
+  PG_REQUIRE(rows && out, PG_EINVAL, "pg_sum_rows: null pointer");
+  PG_REQUIRE(n_rows >= 1 && n_rows <= 32, PG_ESHAPE, "pg_sum_rows: 1..32 rows per launch, got %d", n_rows);
+  if (n == 0) return 0;
+  SumRowsArgs a;
+  for (int k = 0; k < 32; ++k) a.rows[k] = k < n_rows ? rows[k] : nullptr;
+  for (int k = 0; k < n_rows; ++k) PG_REQUIRE(a.rows[k], PG_EINVAL, "pg_sum_rows: null row %d", k);
+  a.out = out; a.n = n; a.n_rows = n_rows;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, EW_STREAM, a);
+  PG_LAUNCH_CHECK("pg_sum_rows");
   return 0;
 }
 

@@ -34,14 +34,15 @@ __global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restri
 
 // dx[2r+i, 2c+j] = 0.25 * dy[r, c]   (also the forward of "nearest upsample" with scale 1)
 __global__ void expand2_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t total,
-                               int OH, int OW, float scale) {  // total = elements of dst
+                               int OH, int OW, float scale, const float* __restrict__ res) {  // total = elements of dst
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int c = (int)(i % (2 * OW));
     const size_t t = i / (2 * OW);
     const int r = (int)(t % (2 * OH));
     const size_t plane = t / (2 * OH);
-    dst[i] = scale * src[(plane * OH + (r >> 1)) * (size_t)OW + (c >> 1)];
+    const float v = scale * src[(plane * OH + (r >> 1)) * (size_t)OW + (c >> 1)];
+    dst[i] = res ? v + res[i] : v;
   }
 }
 
@@ -188,15 +189,23 @@ PG_EXPORT int pg_avgpool2_fwd(const float* x, float* y, int planes, int OH, int 
 PG_EXPORT int pg_avgpool2_bwd(const float* dy, float* dx, int planes, int OH, int OW, void* stream) {
   PG_REQUIRE(dy && dx && planes > 0 && OH > 0 && OW > 0, PG_EINVAL, "pg_avgpool2_bwd: bad arguments");
   const size_t total = (size_t)planes * OH * OW * 4;
-  hipLaunchKernelGGL(expand2_kernel, dim3(vblocks(total)), dim3(VT), 0, VST, dy, dx, total, OH, OW, 0.25f);
+  hipLaunchKernelGGL(expand2_kernel, dim3(vblocks(total)), dim3(VT), 0, VST, dy, dx, total, OH, OW, 0.25f, (const float*)nullptr);
   PG_LAUNCH_CHECK("pg_avgpool2_bwd");
+  return 0;
+}
+
+PG_EXPORT int pg_avgpool2_bwd_res(const float* dy, const float* res, float* dx, int planes, int OH, int OW, void* stream) {
+  PG_REQUIRE(dy && res && dx && planes > 0 && OH > 0 && OW > 0, PG_EINVAL, "pg_avgpool2_bwd_res: bad arguments");
+  const size_t total = (size_t)planes * OH * OW * 4;
+  hipLaunchKernelGGL(expand2_kernel, dim3(vblocks(total)), dim3(VT), 0, VST, dy, dx, total, OH, OW, 0.25f, res);
+  PG_LAUNCH_CHECK("pg_avgpool2_bwd_res");
   return 0;
 }
 
 PG_EXPORT int pg_upsample2_fwd(const float* x, float* y, int planes, int IH, int IW, void* stream) {
   PG_REQUIRE(x && y && planes > 0 && IH > 0 && IW > 0, PG_EINVAL, "pg_upsample2_fwd: bad arguments");
   const size_t total = (size_t)planes * IH * IW * 4;
-  hipLaunchKernelGGL(expand2_kernel, dim3(vblocks(total)), dim3(VT), 0, VST, x, y, total, IH, IW, 1.0f);
+  hipLaunchKernelGGL(expand2_kernel, dim3(vblocks(total)), dim3(VT), 0, VST, x, y, total, IH, IW, 1.0f, (const float*)nullptr);
   PG_LAUNCH_CHECK("pg_upsample2_fwd");
   return 0;
 }

@@ -50,17 +50,22 @@ class BottleneckBlock(nn.Module):
             pg_nn.Conv2d(bottleneck_channels, out_channels, kernel_size=1),
         )
 
-    def forward(self, x, n_alias=0, x2=None):
+    def forward(self, x, n_alias=0, x2=None, x2_alias=False):
         """n_alias > 0 (extension) returns (out, x_1, .., x_n): pass-through aliases of x for the caller's other
         readers of x (ops.conv2d_taps, n_skip): their gradients are added in the first convolution's data-gradient
         epilogue instead of by autograd's gradient-sum kernels. x2 (extension): the block reads cat((x, x2), dim=1)
-        without that tensor being written (Conv2d.forward_cat2)."""
+        without that tensor being written (Conv2d.forward_cat2); x2_alias=True then returns (out, x2_next): the pass-through
+        alias of x2 for its next reader."""
         res = None
         k = n_alias + (1 if self._is_residual else 0)
         if x2 is not None:
             if k:
                 raise ValueError("BottleneckBlock: x2 is for the non-residual block without aliases")
-            h, al = self._net[1].forward_cat2(x, x2, in_act="gelu"), []
+            if x2_alias:
+                h, x2_next = self._net[1].forward_cat2(x, x2, in_act="gelu", skip_b=True)
+                al = []
+            else:
+                h, al = self._net[1].forward_cat2(x, x2, in_act="gelu"), []
         elif k:
             # the block's own residual add reads the first alias
             h, *al = self._net[1](x, in_act="gelu", n_skip=k)
@@ -71,6 +76,8 @@ class BottleneckBlock(nn.Module):
         h = self._net[3](h, in_act="gelu")
         h = self._net[5](h, in_act="gelu")
         out = self._net[7](h, in_act="gelu", res=res)
+        if x2 is not None and x2_alias:
+            return out, x2_next
         return (out, *al) if n_alias else out
 
 
@@ -87,7 +94,10 @@ class TopDownBlock(nn.Module):
         self._out = BottleneckBlock(n_channels, n_channels, bottleneck_channels,
                                     bottleneck_kernel_size=bottleneck_kernel_size, is_residual=True)
 
-    def forward(self, x, mixin=None):
+    def forward(self, x, mixin=None, more_readers=False):
+        """more_readers=True (extension, training): also returns the pass-through alias of `mixin` for the NEXT top-down block of
+        the stack — the encoder's feature map is read by every block of its resolution (vd_vae.py:177), and chained aliases
+        let each block's data-gradient kernel add the later blocks' gradients instead of autograd's gradient-sum kernels."""
         c = self._latent_channels
         n, _, h, w = x.shape
         # x has three readers (the prior's first convolution, the concatenation, the residual add): the last two
@@ -98,15 +108,20 @@ class TopDownBlock(nn.Module):
             z, kl_div = ops.gaussian_head_prior(prior, eps, c), None
             p_h = prior[:, 2 * c:]
         else:              # training: sample from the approximate posterior
-            post = self._posterior(x_cat, x2=mixin)  # the block of cat((x, mixin)), concatenation not materialised
+            if more_readers:
+                post, mixin = self._posterior(x_cat, x2=mixin, x2_alias=True)
+            else:
+                post = self._posterior(x_cat, x2=mixin)  # the block of cat((x, mixin)), concatenation not materialised
             # p_h = prior[:, 2c:] comes out of the head function: its gradient goes back into the prior's
             # gradient with one copy (no slice backward + full-size add)
             z, kl_div, p_h = ops.gaussian_head_pair(post, prior, eps, c, split_rest=True)
         if self._latents.two_residuals_ok(z):
             # x + p_h + latents(z): both adds in the 1x1 convolution's epilogue, p_h read in place (batch-strided)
-            return self._out(self._latents(z, res=x, res2=p_h)), kl_div
-        x_ph = ops.add(x, p_h.contiguous())
-        return self._out(self._latents(z, res=x_ph)), kl_div
+            y = self._out(self._latents(z, res=x, res2=p_h))
+        else:
+            x_ph = ops.add(x, p_h.contiguous())
+            y = self._out(self._latents(z, res=x_ph))
+        return (y, kl_div, mixin) if more_readers else (y, kl_div)
 
 
 class EncoderStack(nn.Module):
@@ -122,7 +137,11 @@ class EncoderStack(nn.Module):
 
     def forward(self, x):
         features = self._residuals(x)
-        x = ops.avg_pool2(features) if self._pool is not None else features
+        if self._pool is None:
+            return features, features
+        # the feature map has two kinds of readers — the pooling here and the decoder's top-down blocks (through `mixin`): the
+        # latter read a pass-through alias whose gradient the pooling's backward kernel adds
+        x, features = ops.avg_pool2(features, n_skip=1)
         return x, features
 
 
@@ -140,8 +159,12 @@ class DecoderStack(nn.Module):
         if self._unpool is not None:
             x = ops.upsample2_nearest(x)
         kl_divs = []
-        for topdown in self._topdowns:
-            x, kl_div = topdown(x, mixin)
+        last = len(self._topdowns) - 1
+        for i, topdown in enumerate(self._topdowns):
+            if mixin is not None and i < last:
+                x, kl_div, mixin = topdown(x, mixin, more_readers=True)
+            else:
+                x, kl_div = topdown(x, mixin)
             kl_divs.append(kl_div)
         return x, kl_divs
 
@@ -189,7 +212,7 @@ class VeryDeepVAE(vaes.VariationalAutoEncoder):
 
     def _top(self, n):
         b = self._biases[-1]
-        return torch.zeros((n,) + tuple(b.shape[1:]), device=b.device, dtype=torch.float32)
+        return ops.zeros((n,) + tuple(b.shape[1:]), b.device)
 
     def forward(self, x):
         """Returns (logits, kl_div) with kl_div the per-sample sum over all latents (not normalised)."""
@@ -206,7 +229,7 @@ class VeryDeepVAE(vaes.VariationalAutoEncoder):
             x = ops.add_broadcast_batch(x, bias)
             x, divs = stack(x, mixin)
             kl_divs.extend(divs)
-        kl_div = torch.stack(kl_divs).sum(dim=0)
+        kl_div = ops.sum_vectors(kl_divs)  # torch.stack(kl_divs).sum(dim=0) in one launch, no stacked tensor
         return self._output(x), kl_div
 
     def _sample(self, n_samples):

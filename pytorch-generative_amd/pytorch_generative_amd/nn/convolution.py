@@ -107,17 +107,22 @@ class Conv2d(nn.Conv2d):
         return (not self._down2) and ops.RowDecode.current is None and ops.conv_two_residuals_ok(
             x, self.weight, self._conv_spec(), crop)
 
-    def forward_cat2(self, xa, xb, *, in_act=None):
+    def forward_cat2(self, xa, xb, *, in_act=None, skip_b=False):
         """self(torch.cat((xa, xb), dim=1), in_act=in_act) for a 1x1 convolution WITHOUT the concatenated tensor:
         W [xa; xb] = W[:, :Ca] xa + W[:, Ca:] xb, the second product chained through the first one's residual input
-        (extension; VD-VAE's posterior reads cat(x, mixin), vd_vae.py:177)."""
+        (extension; VD-VAE's posterior reads cat(x, mixin), vd_vae.py:177).
+        skip_b=True returns (y, xb_alias): a pass-through alias of xb for its NEXT reader, whose gradient this convolution's
+        data-gradient kernel adds in its epilogue (ops.conv2d_taps, n_skip) — a tensor read by k blocks then needs no
+        gradient-sum kernels of autograd at all."""
         if (self._down2 or ops.RowDecode.current is not None or tuple(self.weight.shape[2:]) != (1, 1)
                 or xa.shape[1] + xb.shape[1] != self.weight.shape[1]):
-            return self.forward(torch.cat((xa, xb), dim=1), in_act=in_act)
+            y = self.forward(torch.cat((xa, xb), dim=1), in_act=in_act)
+            return (y, xb) if skip_b else y
         wa, wb = ops.split_in_channels(self.weight, xa.shape[1])
         spec = self._conv_spec()
         h = ops.conv2d_taps(xa, wa, None, spec, in_act=_ACTS[in_act])
-        return ops.conv2d_taps(xb, wb, self.bias, spec, in_act=_ACTS[in_act], res=h, bias_param=self.bias)
+        return ops.conv2d_taps(xb, wb, self.bias, spec, in_act=_ACTS[in_act], res=h, bias_param=self.bias,
+                               n_skip=1 if skip_b else 0)
 
     def forward(self, x, *, crop=None, in_act=None, res=None, out_act=None, out_pre_scaled=False,
                 in_post=None, n_skip=0, res2=None):

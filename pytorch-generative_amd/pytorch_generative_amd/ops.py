@@ -73,6 +73,19 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+def zeros(shape, device):
+    """torch.zeros(shape, dtype=float32) with the fill done by the library's own kernel (pg_fill): gradient sinks, loss scalars,
+    KL accumulators — no ATen fill kernel inside a captured step."""
+    t = torch.empty(shape, device=device, dtype=torch.float32)
+    if t.numel():
+        _lib.check(_lib.load().pg_fill(t.data_ptr(), 0.0, t.numel(), _stream()), "pg_fill")
+    return t
+
+
+def zeros_like(t):
+    return zeros(tuple(t.shape), t.device)
+
+
 def _sink(param):
     """Returns the direct gradient sink of a parameter (or None)."""
     return getattr(param, "_pg_grad", None) if param is not None else None
@@ -347,13 +360,13 @@ class _ConvTaps(torch.autograd.Function):
         if need_w or need_b:
             gw, gb = ctx.gw, ctx.gb
             if gw is None:
-                dw = torch.zeros_like(weight)
+                dw = zeros_like(weight)
                 gw_t = dw
             else:
                 gw_t = gw
             if need_b:
                 if gb is None:
-                    db = torch.zeros(cout, device=x.device, dtype=torch.float32)
+                    db = zeros((cout,), x.device)
                     gb_t = db
                 else:
                     gb_t = gb
@@ -555,7 +568,7 @@ class _MlpGelu(torch.autograd.Function):
                 grads.append(sink)
                 outs.append(None)
             else:
-                t = torch.zeros(c, device=x.device) if like is None else torch.zeros_like(like)
+                t = zeros((c,), x.device) if like is None else zeros_like(like)
                 grads.append(t)
                 outs.append(t)
         ws_n = lib.pg_mlp_gelu_bwd_workspace_floats(n, h * w)
@@ -594,7 +607,7 @@ def _grad_targets(params):
             tgt.append(sink)
             ret.append(None)
         else:
-            z = torch.zeros_like(p)
+            z = zeros_like(p)
             tgt.append(z)
             ret.append(z)
     return tgt, ret
@@ -633,7 +646,7 @@ class _GPTBlockHead(torch.autograd.Function):
                 raise RuntimeError("gpt_block_head: a deferred tail reduction is pending but the head has no gradient")
             return gx, None, None, None, None, None, None, None, None, None
         dqkv = _chk(dqkv, "gpt_block_head.dqkv")
-        gx = torch.zeros_like(x) if gx is None else _chk(gx, "gpt_block_head.gx")
+        gx = zeros_like(x) if gx is None else _chk(gx, "gpt_block_head.gx")
         dx = torch.empty_like(x)
         tgt, ret = _grad_targets(ctx.params)  # order: lnw, lnb, wq, bq, wkv, bkv
         ws_n = lib.pg_gpt_block_head_bwd_workspace_floats(n, h * w)
@@ -781,10 +794,10 @@ class _NCHWLayerNorm(torch.autograd.Function):
         dg = db = None
         gg, gb = ctx.gg, ctx.gb
         if gg is None:
-            dg = torch.zeros(c, device=x.device, dtype=torch.float32)
+            dg = zeros((c,), x.device)
             gg = dg
         if gb is None:
-            db = torch.zeros(c, device=x.device, dtype=torch.float32)
+            db = zeros((c,), x.device)
             gb = db
         ws_n = lib.pg_nchw_layernorm_bwd_workspace_floats(n, c, h * w)
         ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
@@ -971,7 +984,7 @@ class _MergeQKVWeight(torch.autograd.Function):
         lib = _lib.load()
         eq, cq = int(wq.shape[0]), int(wq.shape[1])
         ekv, ckv = int(wkv.shape[0]), int(wkv.shape[1])
-        w = torch.zeros((eq + ekv, ckv, 1, 1), device=wq.device, dtype=torch.float32)
+        w = zeros((eq + ekv, ckv, 1, 1), wq.device)
         b = torch.empty(eq + ekv, device=wq.device, dtype=torch.float32)
         st = _stream()
         _lib.check(lib.pg_copy_rows(wq.data_ptr(), w.data_ptr(), eq, cq, cq, ckv, 0, st), "pg_copy_rows")
@@ -1202,7 +1215,7 @@ class _AddBcast(torch.autograd.Function):
         gp = ctx.gp
         if ctx.needs_input_grad[1]:
             if gp is None:
-                dp = torch.zeros(ctx.pshape, device=dy.device, dtype=torch.float32)
+                dp = zeros(ctx.pshape, dy.device)
                 gp = dp
             per = gp.numel()
             _lib.check(lib.pg_add_bcast_bwd(dy.data_ptr(), gp.data_ptr(), dy.shape[0], per, _stream()),
@@ -1246,7 +1259,7 @@ class _BCEWithLogitsSumMean(torch.autograd.Function):
         if z.numel() != x.numel():
             raise ValueError("bce: logits/targets size mismatch")
         n = z.shape[0]
-        loss = torch.zeros(1, device=z.device, dtype=torch.float32)
+        loss = zeros((1,), z.device)
         _lib.check(lib.pg_bce_logits_fwd(z.data_ptr(), x.data_ptr(), loss.data_ptr(), n,
                                          z.numel() // n, _stream()), "pg_bce_logits_fwd")
         ctx.save_for_backward(z, x)
@@ -1273,7 +1286,7 @@ class _DmolLossSumMean(torch.autograd.Function):
         n, c, h, w = l.shape
         if c != 10 * n_mix or tuple(x.shape) != (n, 3, h, w):
             raise ValueError("dmol: expected (N, 10 * n_mix, H, W) parameters and (N, 3, H, W) images in [-1, 1]")
-        loss = torch.zeros(1, device=l.device, dtype=torch.float32)
+        loss = zeros((1,), l.device)
         _lib.check(lib.pg_dmol_fwd(l.data_ptr(), x.data_ptr(), loss.data_ptr(), n, n_mix, h * w, _stream()),
                    "pg_dmol_fwd")
         ctx.save_for_backward(l, x)
@@ -1310,7 +1323,7 @@ def bce_with_logits_sum_mean(logits, targets):
 # --------------------------------------------------------------------------------------------
 class _AvgPool2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, n_skip):
         lib = _lib.load()
         x = _chk(x, "avgpool2.x")
         n, c, h, w = x.shape
@@ -1319,22 +1332,70 @@ class _AvgPool2(torch.autograd.Function):
         y = torch.empty((n, c, h // 2, w // 2), device=x.device, dtype=torch.float32)
         _lib.check(lib.pg_avgpool2_fwd(x.data_ptr(), y.data_ptr(), n * c, h // 2, w // 2, _stream()),
                    "pg_avgpool2_fwd")
+        if n_skip:
+            # one pass-through alias of x for its other readers: their gradient comes back to THIS node and is added by the
+            # pooling's own backward kernel (the protocol of _ConvTaps' n_skip)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_skip=None):
         lib = _lib.load()
         dy = _chk(dy, "avgpool2.dy")
         n, c, oh, ow = dy.shape
         dx = torch.empty((n, c, 2 * oh, 2 * ow), device=dy.device, dtype=torch.float32)
-        _lib.check(lib.pg_avgpool2_bwd(dy.data_ptr(), dx.data_ptr(), n * c, oh, ow, _stream()),
-                   "pg_avgpool2_bwd")
-        return dx
+        if d_skip is not None:
+            d_skip = _chk(d_skip, "avgpool2.d_skip")
+            _lib.check(lib.pg_avgpool2_bwd_res(dy.data_ptr(), d_skip.data_ptr(), dx.data_ptr(), n * c, oh, ow, _stream()),
+                       "pg_avgpool2_bwd_res")
+        else:
+            _lib.check(lib.pg_avgpool2_bwd(dy.data_ptr(), dx.data_ptr(), n * c, oh, ow, _stream()),
+                       "pg_avgpool2_bwd")
+        return dx, None
 
 
-def avg_pool2(x):
-    """nn.AvgPool2d(kernel_size=2, stride=2)"""
-    return _AvgPool2.apply(x)
+def avg_pool2(x, n_skip=0):
+    """nn.AvgPool2d(kernel_size=2, stride=2). n_skip=1 (extension) returns (y, x_alias): x_alias is x for the caller's other
+    readers, whose gradient the pooling's backward kernel adds (no gradient-sum kernel of autograd)."""
+    if n_skip not in (0, 1):
+        raise ValueError("avg_pool2: n_skip is 0 or 1")
+    if n_skip and not (FUSE_SKIP and x.requires_grad):
+        return _AvgPool2.apply(x, 0), x
+    return _AvgPool2.apply(x, int(n_skip))
+
+
+class _SumVectors(torch.autograd.Function):
+    """out = sum of k equally shaped tensors in ONE launch (pg_sum_rows); every input's gradient is the output's."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        import ctypes
+
+        lib = _lib.load()
+        ts = [_chk(t, "sum_vectors.t") for t in ts]
+        if any(t.shape != ts[0].shape for t in ts):
+            raise ValueError("sum_vectors: shape mismatch")
+        out = torch.empty_like(ts[0])
+        acc = None
+        for i in range(0, len(ts), 31):  # 32 rows per launch, the running sum among them
+            grp = ([acc] if acc is not None else []) + ts[i:i + 31]
+            rows = (ctypes.c_void_p * len(grp))(*[t.data_ptr() for t in grp])
+            _lib.check(lib.pg_sum_rows(rows, len(grp), out.data_ptr(), out.numel(), _stream()), "pg_sum_rows")
+            acc = out
+        ctx.k = len(ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) * ctx.k
+
+
+def sum_vectors(ts):
+    """torch.stack(ts).sum(dim=0) (vd_vae.py:400, the sum of the per-block KL terms) without the stacked tensor."""
+    ts = list(ts)
+    if not ts:
+        raise ValueError("sum_vectors: empty list")
+    return ts[0] if len(ts) == 1 else _SumVectors.apply(*ts)
 
 
 class _Upsample2(torch.autograd.Function):
@@ -1388,7 +1449,7 @@ class _GaussHead(torch.autograd.Function):
         if tuple(eps.shape) != (n, latent, h, w):
             raise ValueError(f"gauss head: eps shape {tuple(eps.shape)} != {(n, latent, h, w)}")
         z = torch.empty((n, latent, h, w), device=ref.device, dtype=torch.float32)
-        kl = torch.zeros(n, device=ref.device, dtype=torch.float32)
+        kl = zeros((n,), ref.device)
         _lib.check(
             lib.pg_gauss_head_fwd(_p(q), _p(p), eps.data_ptr(), z.data_ptr(), kl.data_ptr(), n, latent,
                                   L, 0 if q is None else q.shape[1] * L,
@@ -1420,10 +1481,10 @@ class _GaussHead(torch.autograd.Function):
         dkl = _chk(dkl, "gauss.dkl") if (dkl is not None and mode != 2) else None
         dq = dp = None
         if q is not None:
-            dq = torch.empty_like(q) if q.shape[1] == 2 * latent else torch.zeros_like(q)
+            dq = torch.empty_like(q) if q.shape[1] == 2 * latent else zeros_like(q)
         rest_direct = ctx.split_rest and d_rest is not None
         if p is not None:
-            dp = torch.empty_like(p) if (p.shape[1] == 2 * latent or rest_direct) else torch.zeros_like(p)
+            dp = torch.empty_like(p) if (p.shape[1] == 2 * latent or rest_direct) else zeros_like(p)
         _lib.check(
             lib.pg_gauss_head_bwd(_p(q), _p(p), eps.data_ptr(), _p(dz), _p(dkl), _p(dq), _p(dp), n,
                                   latent, L, 0 if q is None else q.shape[1] * L,
@@ -1463,8 +1524,8 @@ class _ElboMean(torch.autograd.Function):
         lib = _lib.load()
         logits, x, kl = _chk(logits, "elbo.logits"), _chk(x, "elbo.x"), _chk(kl, "elbo.kl")
         n = logits.shape[0]
-        recon = torch.zeros(1, device=logits.device, dtype=torch.float32)
-        klm = torch.zeros(1, device=logits.device, dtype=torch.float32)
+        recon = zeros((1,), logits.device)
+        klm = zeros((1,), logits.device)
         _lib.check(lib.pg_bce_logits_fwd(logits.data_ptr(), x.data_ptr(), recon.data_ptr(), n,
                                          logits.numel() // n, _stream()), "pg_bce_logits_fwd")
         _lib.check(lib.pg_vec_mean_accum(kl.data_ptr(), n, klm.data_ptr(), _stream()),
@@ -1571,7 +1632,7 @@ class _PhaseWeights(torch.autograd.Function):
     def backward(ctx, *grads):
         a, b = ctx.shape[:2]
         like = next(g for g in grads if g is not None)
-        gs = [g if g is not None else torch.zeros_like(like) for g in grads]
+        gs = [g if g is not None else zeros_like(like) for g in grads]
         # back into (ur, vr, ...) order: entry [ur][vr] is phase (1 - ur, 1 - vr) = index 2 (1 - ur) + (1 - vr)
         dp = torch.stack([gs[3], gs[2], gs[1], gs[0]]).view(2, 2, *like.shape)
         if ctx.transposed:
@@ -1658,7 +1719,7 @@ class _Resample2(torch.autograd.Function):
         x = _chk(x, "resample2.x")
         n, c, h, w = x.shape
         if up:
-            xs = torch.zeros((4, n, c, h, w), device=x.device, dtype=torch.float32)
+            xs = zeros((4, n, c, h, w), x.device)
             xs[0].copy_(x)
             y = torch.empty((n, c, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
             _lib.check(lib.pg_phase_split2(y.data_ptr(), xs.data_ptr(), n * c, h, w, 1, _stream()), "pg_phase_split2")
