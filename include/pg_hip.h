@@ -274,6 +274,17 @@ int pg_upsample2_bwd(const float* dy, float* dx, int planes, int IH, int IW, voi
 /* 2x2 phase split (space-to-depth) and its inverse: x (planes, 2H, 2W) <-> xs (4, planes, H, W),
  * xs[2*pr+pc][plane][r][c] = x[plane][2r+pr][2c+pc]. merge==0 writes xs, merge==1 writes x. */
 int pg_phase_split2(float* x, float* xs, int planes, int H, int W, int merge, void* stream);
+/* the same between x and FOUR separate phase tensors p[2*pr+pc] (planes, H, W) (HOST array of 4 device pointers): the four phase
+ * convolutions of a 4x4 / stride-2 transposed convolution (vaes.py:228-235) write their own outputs, which are interleaved here
+ * without a stacked copy; merge == 0 scatters x's gradient back into four tensors */
+int pg_phase_merge4(float* x, float* const* p, int planes, int H, int W, int merge, void* stream);
+/* The four 2x2 phase kernels of a 4x4 / stride-2 weight, out (4, Co, Ci, 2, 2) contiguous:
+ *   transposed == 0 (Conv2d weight (Co, Ci, 4, 4), vaes.py:153-160):  out[2pr+pc][o][c][i][j] = w[o][c][2i+1-pr][2j+1-pc]
+ *   transposed == 1 (ConvTranspose2d weight (Ci, Co, 4, 4), vaes.py:228-235): out[2pr+pc][o][c][i][j] = w[c][o][2(1-i)+1-pr][2(1-j)+1-pc]
+ * A, B = the weight's first two dimensions. pg_phase_weights_bwd is the adjoint from four gradient tensors g[k] (Co, Ci, 2, 2)
+ * (HOST array of 4 device pointers, a null entry = no gradient): dw = (accumulate ? dw : 0) + scatter(g). */
+int pg_phase_weights(const float* w, float* out, int A, int B, int transposed, void* stream);
+int pg_phase_weights_bwd(const float* const* g, float* dw, int A, int B, int transposed, int accumulate, void* stream);
 /* Fused Gaussian head. q, p: (N, >=2C, L) conv outputs holding [mean | log_std] in channels
  * [0,C) / [C,2C), read in place through batch strides q_bs / p_bs (floats). eps, z: (N, C, L).
  *   mode 0: z = mu_q + exp(s_q) eps ; kl[n] += sum KL(q || N(0,1))       (vae.py:91-93)

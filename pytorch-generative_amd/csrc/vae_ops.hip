@@ -79,6 +79,53 @@ __global__ void phase_split_kernel(float* x, float* xs, size_t total,
   }
 }
 
+struct Phase4 { float* p[4]; };
+
+__global__ void phase_merge4_kernel(float* x, const Phase4 ph, size_t total, int H, int W, int merge) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;  // total = planes * 2H * 2W
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c2 = (int)(i % (2 * W));
+    const size_t t = i / (2 * W);
+    const int r2 = (int)(t % (2 * H));
+    const size_t plane = t / (2 * H);
+    float* q = ph.p[2 * (r2 & 1) + (c2 & 1)] + (plane * H + (r2 >> 1)) * (size_t)W + (c2 >> 1);
+    if (merge) x[i] = *q;
+    else *q = x[i];
+  }
+}
+
+// one thread per element of the (4, Co, Ci, 2, 2) phase-kernel tensor; `src` = its element of the 4x4 weight (a bijection)
+struct PhaseW { const float* g[4]; };
+__device__ __forceinline__ size_t phase_w_src(int idx, int A, int B, int transposed, int& k, int& rest) {
+  const int Co = transposed ? B : A, Ci = transposed ? A : B;
+  const int j = idx & 1, i = (idx >> 1) & 1;
+  int t = idx >> 2;
+  const int c = t % Ci; t /= Ci;
+  const int o = t % Co;
+  k = t / Co;
+  rest = ((o * Ci + c) * 2 + i) * 2 + j;
+  const int pr = k >> 1, pc = k & 1;
+  if (transposed) return (((size_t)c * B + o) * 4 + (2 * (1 - i) + 1 - pr)) * 4 + (2 * (1 - j) + 1 - pc);
+  return (((size_t)o * B + c) * 4 + (2 * i + 1 - pr)) * 4 + (2 * j + 1 - pc);
+}
+
+__global__ void phase_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int total, int A, int B, int transposed) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int k, rest;
+    out[idx] = w[phase_w_src(idx, A, B, transposed, k, rest)];
+  }
+}
+
+__global__ void phase_weights_bwd_kernel(const PhaseW g, float* __restrict__ dw, int total, int A, int B, int transposed,
+                                         int accumulate) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int k, rest;
+    const size_t src = phase_w_src(idx, A, B, transposed, k, rest);
+    const float v = g.g[k] ? g.g[k][rest] : 0.f;
+    dw[src] = accumulate ? dw[src] + v : v;
+  }
+}
+
 // ---- Gaussian heads --------------------------------------------------------------------------
 // q: (N, >=2C, L) with [mean | log_std] in channels [0,C) and [C,2C); p: same layout or NULL.
 //   p == NULL : KL(q || N(0,1)) = -0.5 (1 + 2 s - e^{2s} - mu^2)                 vaes.py:17-19
@@ -225,6 +272,37 @@ PG_EXPORT int pg_phase_split2(float* x, float* xs, int planes, int H, int W, int
   hipLaunchKernelGGL(phase_split_kernel, dim3(vblocks(total)), dim3(VT), 0, VST, x, xs, total, H, W,
                      (size_t)planes * H * W, merge);
   PG_LAUNCH_CHECK("pg_phase_split2");
+  return 0;
+}
+
+PG_EXPORT int pg_phase_merge4(float* x, float* const* p, int planes, int H, int W, int merge, void* stream) {
+  PG_REQUIRE(x && p && p[0] && p[1] && p[2] && p[3] && planes > 0 && H > 0 && W > 0, PG_EINVAL, "pg_phase_merge4: bad arguments");
+  Phase4 ph;
+  for (int k = 0; k < 4; ++k) ph.p[k] = p[k];
+  const size_t total = (size_t)planes * 4 * H * W;
+  hipLaunchKernelGGL(phase_merge4_kernel, dim3(vblocks(total)), dim3(VT), 0, VST, x, ph, total, H, W, merge);
+  PG_LAUNCH_CHECK("pg_phase_merge4");
+  return 0;
+}
+
+PG_EXPORT int pg_phase_weights(const float* w, float* out, int A, int B, int transposed, void* stream) {
+  PG_REQUIRE(w && out && A > 0 && B > 0, PG_EINVAL, "pg_phase_weights: bad arguments");
+  const long total = 16L * A * B;
+  PG_REQUIRE(total < (1L << 30), PG_ESHAPE, "pg_phase_weights: weight too large");
+  hipLaunchKernelGGL(phase_weights_kernel, dim3(vblocks((size_t)total)), dim3(VT), 0, VST, w, out, (int)total, A, B, transposed);
+  PG_LAUNCH_CHECK("pg_phase_weights");
+  return 0;
+}
+
+PG_EXPORT int pg_phase_weights_bwd(const float* const* g, float* dw, int A, int B, int transposed, int accumulate, void* stream) {
+  PG_REQUIRE(g && dw && A > 0 && B > 0, PG_EINVAL, "pg_phase_weights_bwd: bad arguments");
+  const long total = 16L * A * B;
+  PG_REQUIRE(total < (1L << 30), PG_ESHAPE, "pg_phase_weights_bwd: weight too large");
+  PhaseW pw;
+  for (int k = 0; k < 4; ++k) pw.g[k] = g[k];
+  hipLaunchKernelGGL(phase_weights_bwd_kernel, dim3(vblocks((size_t)total)), dim3(VT), 0, VST, pw, dw, (int)total, A, B, transposed,
+                     accumulate);
+  PG_LAUNCH_CHECK("pg_phase_weights_bwd");
   return 0;
 }
 

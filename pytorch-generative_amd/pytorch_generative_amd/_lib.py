@@ -104,6 +104,9 @@ SIGNATURES = {
     "pg_act_bwd_from_out": (c_i, [c_f, c_f, c_f, c_f, c_z, c_i, c_s]),
     "pg_add": (c_i, [c_f, c_f, c_f, c_z, c_s]),
     "pg_fill": (c_i, [c_f, c_flt, c_z, c_s]),
+    "pg_phase_merge4": (c_i, [c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_i, c_s]),
+    "pg_phase_weights": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
+    "pg_phase_weights_bwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_f, c_i, c_i, c_i, c_i, c_s]),
     "pg_sum_rows": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_f, c_z, c_s]),
     "pg_avgpool2_bwd_res": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_s]),
     "pg_add_bcast_fwd": (c_i, [c_f, c_f, c_f, c_i, c_z, c_s]),

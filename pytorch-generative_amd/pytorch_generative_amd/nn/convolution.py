@@ -220,7 +220,7 @@ class ConvTranspose2d(nn.ConvTranspose2d):
                 else:
                     y = ops.conv2d_taps(xs[k], wph[k], self.bias, spec, out_hw=x.shape[2:], in_act=_ACTS[in_act])
                 phases.append(y)
-        return ops.phase_merge(torch.stack(phases))
+        return ops.phase_merge4(phases)  # interleaves the four phase outputs without a stacked copy
 
 
 class CausalConv2d(Conv2d):

@@ -1605,41 +1605,45 @@ class _PhaseMerge(torch.autograd.Function):
 
 
 class _PhaseWeights(torch.autograd.Function):
-    """The four 2x2 phase kernels of a 4x4 / stride-2 weight with ONE copy kernel each way.
+    """The four 2x2 phase kernels of a 4x4 / stride-2 weight: ONE launch each way (pg_phase_weights / pg_phase_weights_bwd).
 
     transposed=False (Conv2d, weight (Co, Ci, 4, 4)): out[2 pr + pc] = w[:, :, (1 - pr)::2, (1 - pc)::2].
     transposed=True (ConvTranspose2d, weight (Ci, Co, 4, 4)): out[2 pr + pc] =
     w.transpose(0, 1)[:, :, (1 - pr)::2, (1 - pc)::2].flip(2, 3).
-    Written as slices these are four strided copies forward and, per slice, a zero fill, a strided copy and an add
-    into the weight's gradient backward (~300 tiny ATen launches per beta-VAE step)."""
+    (Written as slices these were four strided copies forward and, per slice, a zero fill, a strided copy and an add into the
+    weight's gradient backward; round 5 made them one permuted copy each way out of ATen's permute / flip / stack / contiguous;
+    round 6: the library's own kernels, and the backward adds straight into the parameter's flat-gradient slice when it has one.)"""
 
     @staticmethod
-    def forward(ctx, w, transposed):
+    def forward(ctx, w, transposed, sink):
         if w.dim() != 4 or tuple(w.shape[2:]) != (4, 4):
             raise ValueError("phase_weights: expected a (*, *, 4, 4) weight")
-        ctx.transposed, ctx.shape = bool(transposed), tuple(w.shape)
+        w = _chk(w, "phase_weights.w")
+        ctx.transposed, ctx.shape, ctx.sink = bool(transposed), tuple(w.shape), sink
         a, b = w.shape[:2]
-        v = w.contiguous().view(a, b, 2, 2, 2, 2)  # (a, b, i, ur, j, vr): tap u = 2 i + ur, v = 2 j + vr
-        if transposed:
-            p = v.permute(3, 5, 1, 0, 2, 4).flip(4, 5)  # (ur, vr, Co, Ci, 1 - i, 1 - j)
-        else:
-            p = v.permute(3, 5, 0, 1, 2, 4)             # (ur, vr, Co, Ci, i, j)
-        p = p.contiguous()
-        # phase (pr, pc) reads taps with ur = 1 - pr, vr = 1 - pc
-        return tuple(p[1 - pr, 1 - pc] for pr in (0, 1) for pc in (0, 1))
+        co, ci = (b, a) if transposed else (a, b)
+        p = torch.empty((4, co, ci, 2, 2), device=w.device, dtype=torch.float32)
+        _lib.check(_lib.load().pg_phase_weights(w.data_ptr(), p.data_ptr(), a, b, int(ctx.transposed), _stream()),
+                   "pg_phase_weights")
+        return tuple(p[k] for k in range(4))
 
     @staticmethod
     def backward(ctx, *grads):
+        import ctypes
+
         a, b = ctx.shape[:2]
-        like = next(g for g in grads if g is not None)
-        gs = [g if g is not None else zeros_like(like) for g in grads]
-        # back into (ur, vr, ...) order: entry [ur][vr] is phase (1 - ur, 1 - vr) = index 2 (1 - ur) + (1 - vr)
-        dp = torch.stack([gs[3], gs[2], gs[1], gs[0]]).view(2, 2, *like.shape)
-        if ctx.transposed:
-            dv = dp.flip(4, 5).permute(3, 2, 4, 0, 5, 1)  # (Ci, Co, i, ur, j, vr)
-        else:
-            dv = dp.permute(2, 3, 4, 0, 5, 1)             # (Co, Ci, i, ur, j, vr)
-        return dv.reshape(a, b, 4, 4), None
+        gs = [None if g is None else _chk(g, "phase_weights.g") for g in grads]
+        like = next(g for g in gs if g is not None)
+        ptrs = (ctypes.c_void_p * 4)(*[None if g is None else g.data_ptr() for g in gs])
+        sink = ctx.sink
+        if sink is not None:  # the parameter's slice of the flat gradient buffer: add in place, no gradient tensor for autograd
+            _lib.check(_lib.load().pg_phase_weights_bwd(ptrs, sink.data_ptr(), a, b, int(ctx.transposed), 1, _stream()),
+                       "pg_phase_weights_bwd")
+            return None, None, None
+        dw = torch.empty(ctx.shape, device=like.device, dtype=torch.float32)
+        _lib.check(_lib.load().pg_phase_weights_bwd(ptrs, dw.data_ptr(), a, b, int(ctx.transposed), 0, _stream()),
+                   "pg_phase_weights_bwd")
+        return dw, None, None
 
 
 class _SplitInChannels(torch.autograd.Function):
@@ -1662,7 +1666,7 @@ def split_in_channels(w, c1):
 
 
 def phase_weights(w, transposed=False):
-    return _PhaseWeights.apply(w, transposed)
+    return _PhaseWeights.apply(w, transposed, _sink(w))
 
 
 def phase_split(x):
@@ -1671,6 +1675,40 @@ def phase_split(x):
 
 def phase_merge(xs):
     return _PhaseMerge.apply(xs)
+
+
+class _PhaseMerge4(torch.autograd.Function):
+    """x[n, c, 2r + pr, 2q + pc] = p[2 pr + pc][n, c, r, q] from FOUR separate tensors (no stacked copy); backward scatters the
+    gradient into four tensors."""
+
+    @staticmethod
+    def forward(ctx, p0, p1, p2, p3):
+        import ctypes
+
+        ps = [_chk(t, "phase_merge4.p") for t in (p0, p1, p2, p3)]
+        if any(t.shape != ps[0].shape for t in ps):
+            raise ValueError("phase_merge4: shape mismatch")
+        n, c, h, w = ps[0].shape
+        x = torch.empty((n, c, 2 * h, 2 * w), device=ps[0].device, dtype=torch.float32)
+        ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ps])
+        _lib.check(_lib.load().pg_phase_merge4(x.data_ptr(), ptrs, n * c, h, w, 1, _stream()), "pg_phase_merge4")
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        import ctypes
+
+        dx = _chk(dx, "phase_merge4.dx")
+        n, c, h2, w2 = dx.shape
+        gs = [torch.empty((n, c, h2 // 2, w2 // 2), device=dx.device, dtype=torch.float32) for _ in range(4)]
+        ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in gs])
+        _lib.check(_lib.load().pg_phase_merge4(dx.data_ptr(), ptrs, n * c, h2 // 2, w2 // 2, 0, _stream()), "pg_phase_merge4")
+        return tuple(gs)
+
+
+def phase_merge4(phases):
+    """phase_merge(torch.stack(phases)) without the stacked tensor."""
+    return _PhaseMerge4.apply(*phases)
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,15 +1,18 @@
-"""ops.phase_weights (the four stride-2 phase kernels of a 4x4 weight, one copy each way) against the strided
-slices it replaces (nn/convolution.py: Conv2d._forward_down2, ConvTranspose2d.forward): values and gradients."""
+"""ops.phase_weights (the four stride-2 phase kernels of a 4x4 weight, one launch each way: pg_phase_weights / pg_phase_weights_bwd
+since round 6 — GPU tests) against the strided slices it replaces (nn/convolution.py: Conv2d._forward_down2,
+ConvTranspose2d.forward): values and gradients, with and without a flat-gradient sink; ops.split_in_channels (CPU)."""
 import pytest
 import torch
 
 from pytorch_generative_amd import ops
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("transposed", [False, True])
 def test_phase_weights_equal_the_slices(transposed):
     torch.manual_seed(0)
-    w = torch.randn(5, 3, 4, 4, requires_grad=True)
+    dev = torch.device("cuda:0")
+    w = torch.randn(5, 3, 4, 4, device=dev, requires_grad=True)
     w2 = w.detach().clone().requires_grad_(True)
     outs = ops.phase_weights(w, transposed)
     src = w2.transpose(0, 1) if transposed else w2
@@ -23,15 +26,38 @@ def test_phase_weights_equal_the_slices(transposed):
     sum((o * c).sum() for o, c in zip(refs, coef)).backward()
     assert all(torch.equal(o, r) for o, r in zip(outs, refs))
     assert torch.equal(w.grad, w2.grad)
+    # with a flat-gradient sink (optim.FlatAdam's `_pg_grad` view): the backward ADDS into it and hands autograd no gradient
+    w3 = w.detach().clone().requires_grad_(True)
+    w3._pg_grad = torch.full_like(w3, 0.5)
+    outs3 = ops.phase_weights(w3, transposed)
+    sum((o * c).sum() for o, c in zip(outs3, coef)).backward()
+    assert w3.grad is None and torch.equal(w3._pg_grad, w2.grad + 0.5)
 
 
+@pytest.mark.gpu
 def test_phase_weights_with_an_unused_phase():
-    w = torch.randn(2, 2, 4, 4, requires_grad=True)
+    w = torch.randn(2, 2, 4, 4, device="cuda:0", requires_grad=True)
     outs = ops.phase_weights(w)
     (outs[1].sum() * 2.0).backward()  # three of the four gradients are None
     ref = torch.zeros(2, 2, 4, 4)
     ref[:, :, 1::2, 0::2] = 2.0  # phase (0, 1): rows (1 - 0)::2, cols (1 - 1)::2
-    assert torch.equal(w.grad, ref)
+    assert torch.equal(w.grad.cpu(), ref)
+
+
+@pytest.mark.gpu
+def test_phase_merge4_equals_the_stacked_merge():
+    torch.manual_seed(2)
+    dev = torch.device("cuda:0")
+    ps = [torch.randn(3, 5, 6, 4, device=dev, requires_grad=True) for _ in range(4)]
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    a = ops.phase_merge4(ps)
+    b = ops.phase_merge(torch.stack(qs))
+    g = torch.randn_like(a)
+    a.backward(g)
+    b.backward(g)
+    assert torch.equal(a, b) and all(torch.equal(p.grad, q.grad) for p, q in zip(ps, qs))
+    x = a.detach()
+    assert torch.equal(x[:, :, 1::2, 0::2], ps[2].detach())  # phase (pr, pc) = (1, 0)
 
 
 def test_split_in_channels_equals_the_slices():
