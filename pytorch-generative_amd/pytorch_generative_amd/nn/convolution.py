@@ -168,8 +168,8 @@ class Conv2d(nn.Conv2d):
         of x: phase 0 (even rows/cols) pairs with taps u in (1, 3) at offsets (0, +1), phase 1 with
         u in (0, 2) at offsets (-1, 0) — four stride-1 2x2 tap convolutions chained through the
         fused residual input."""
-        xs = ops.phase_split(x)
-        _, _, _, h, w = xs.shape
+        xs = ops.phase_split4(x)  # four separate tensors: their gradients come back as four tensors, interleaved by one launch
+        _, _, h, w = xs[0].shape
         out = res
         wph = ops.phase_weights(self.weight)  # [2 pr + pc] = weight[:, :, (1 - pr)::2, (1 - pc)::2], one copy
         for pr in (0, 1):

@@ -73,3 +73,17 @@ def test_split_in_channels_equals_the_slices():
     _, b3 = ops.split_in_channels(w3, 2)
     (b3 * cb).sum().backward()  # the first half never used
     assert torch.equal(w3.grad[:, 2:], cb) and float(w3.grad[:, :2].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_phase_split4_equals_the_stacked_split():
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    x = torch.randn(2, 3, 8, 12, device=dev, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    ps = ops.phase_split4(x)
+    xs = ops.phase_split(x2)
+    cs = [torch.randn_like(p) for p in ps]
+    sum((p * c).sum() for p, c in zip(ps[:3], cs)).backward()      # the fourth phase unused: its gradient is None
+    sum((xs[k] * cs[k]).sum() for k in range(3)).backward()
+    assert all(torch.equal(p, xs[k]) for k, p in enumerate(ps)) and torch.equal(x.grad, x2.grad)
