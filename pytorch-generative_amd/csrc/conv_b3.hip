@@ -318,7 +318,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
       const long items = (long)N * ((OH * OW + 31) / 32);
       // resident workgroups per CU: what the registers allow (waves per SIMD = 4 / 3 / 2 for 1 / 2 / 3-4 output
       // tiles of 16 channels), LDS permitting
-      const int by_regs = pl.MT == 1 ? 4 : (pl.MT == 2 ? 3 : 2);
+      // (round 6: four output tiles WITHOUT the multi-stream epilogue hold their A fragments in halves: 167 registers, three too)
+      const int by_regs = pl.MT == 1 ? 4 : ((pl.MT == 2 || (pl.MT == 4 && !ms_pw && !gelu)) ? 3 : 2);
       const int by_lds = (int)((160 * 1024) / shmem);
       const int per_cu = by_lds < by_regs ? by_lds : by_regs;
       long gx = (long)256 * per_cu / chunks_y;

@@ -1117,7 +1117,8 @@ constexpr int PW_EPS = 36;   // floats per channel row of a wave's 16 x 32 trans
 constexpr int PW_WAVES = 4;
 
 template <bool GL, int MT, bool MS>
-__global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)) conv_b3_pw_kernel(const B3Args a) {
+__global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : ((MT == 2 || (MT == 4 && !MS && !GL)) ? 3 : 2)) conv_b3_pw_kernel(const B3Args a) {
+  constexpr int AH = (MT == 4 && !MS && !GL) ? 2 : MT;  // (the GELU instantiation spills 6 registers at 168: it keeps two waves)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1163,6 +1164,10 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
       DST[c] = f32x2{ok_ ? t_[0] : 0.f, ok_ ? t_[1] : 0.f};                                            \
     }                                                                                                  \
   }
+// AH = output tiles whose A fragments are resident at a time: all MT (one read per chunk), or — MT = 4 without the multi-stream
+// epilogue, round 6 — two, re-read per pixel group (24 LDS reads per chunk instead of 12, 24 fragment registers instead of 48):
+// that instantiation then fits 168 registers = THREE waves per SIMD instead of two (it is HBM bound: 3.0 TB/s of algorithmic
+// traffic on PixelCNN's 32 -> 64 at batch 1024 with two)
 #define PG_PW_MFMA(ACT)                                                                   \
   _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                         \
     float e_[8];                                                                          \
@@ -1172,15 +1177,20 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
     const bf16x8 bh = __builtin_bit_cast(bf16x8, h_);                                     \
     const bf16x8 bm = __builtin_bit_cast(bf16x8, m_);                                     \
     const bf16x8 bo = __builtin_bit_cast(bf16x8, l_);                                     \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                      \
-      f32x4 c = acc[m][n];                                                                \
-      c = MFMA16B(af[m][2], bh, c);                                                       \
-      c = MFMA16B(af[m][0], bo, c);                                                       \
-      c = MFMA16B(af[m][1], bm, c);                                                       \
-      c = MFMA16B(af[m][1], bh, c);                                                       \
-      c = MFMA16B(af[m][0], bm, c);                                                       \
-      c = MFMA16B(af[m][0], bh, c);                                                       \
-      acc[m][n] = c;                                                                      \
+    _Pragma("unroll") for (int mh = 0; mh < MT / AH; ++mh) {                              \
+      bf16x8 af[AH][3];                                                                   \
+      _Pragma("unroll") for (int m = 0; m < AH; ++m)                                      \
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) af[m][pc] = wl[((j * MT + mh * AH + m) * 3 + pc) * 64]; \
+      _Pragma("unroll") for (int m = 0; m < AH; ++m) {                                    \
+        f32x4 c = acc[mh * AH + m][n];                                                    \
+        c = MFMA16B(af[m][2], bh, c);                                                     \
+        c = MFMA16B(af[m][0], bo, c);                                                     \
+        c = MFMA16B(af[m][1], bm, c);                                                     \
+        c = MFMA16B(af[m][1], bh, c);                                                     \
+        c = MFMA16B(af[m][0], bm, c);                                                     \
+        c = MFMA16B(af[m][0], bh, c);                                                     \
+        acc[mh * AH + m][n] = c;                                                          \
+      }                                                                                   \
     }                                                                                     \
   }
 
@@ -1195,11 +1205,6 @@ __global__ void __launch_bounds__(64 * PW_WAVES, MT == 1 ? 4 : (MT == 2 ? 3 : 2)
       const bool lastj = j + 1 == nchunk;
       const int it2 = lastj ? it + GW : it, j2 = lastj ? 0 : j + 1;
       if (it2 < nitems) PG_PW_ISSUE(it2, j2, nxt)
-      bf16x8 af[MT][3];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) af[m][pc] = wl[((j * MT + m) * 3 + pc) * 64];
       switch (a.in_act) { /* wave-uniform */
         case PG_ACT_RELU: PG_PW_MFMA(PG_ACT_RELU) break;
         case PG_ACT_ELU:  PG_PW_MFMA(PG_ACT_ELU) break;

@@ -49,4 +49,16 @@ if "--wide" in sys.argv:
         for _ in range(launches):
             ops.conv2d_taps(xw, ww, bw, spec, out_hw=(32, 32))
     torch.cuda.synchronize()
+# round 6: the overlapped 16-wave kernel (conv_b3q_kernel, two tiles per workgroup) on the shape it is routed for — PixelCNN++'s 2x3
+# 160 -> 320 at batch 64 — and, for comparison, the same launch count of GatedPixelCNN's 2x1 256 -> 256 on the wide kernel
+if "--q" in sys.argv:
+    for cin, cout, k, pad, batch in ((160, 320, (2, 3), (1, 1), 64), (256, 256, (2, 1), (2, 0), 512)):
+        xq = torch.randn(batch, cin, 32, 32, device=dev)
+        wq = torch.randn(cout, cin, *k, device=dev) * 0.05
+        bq = torch.zeros(cout, device=dev)
+        spec = ops.ConvSpec(k[0], k[1], pad[0], pad[1])
+        with torch.no_grad():
+            for _ in range(launches):
+                ops.conv2d_taps(xq, wq, bq, spec, out_hw=(32, 32))
+        torch.cuda.synchronize()
 print(json.dumps(out))
