@@ -473,11 +473,13 @@ def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32, k=(2, 2, 1, 1))
     return {"launch_ms": ms, "flop_per_launch": flop, "tflops": flop / ms / 1e9}
 
 
-def measured_traffic(batch, kernel, files=("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json",
-                                           "r01_traffic.json")):
+def measured_traffic(batch, kernel, files=("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json",
+                                           "r02_traffic.json", "r01_traffic.json"), with_counters=False):
     """(HBM bytes per launch, source file) of a kernel from the COMMITTED PMC profiles (collected in separate
     rocprofv3 --pmc passes, see profiles/README.md; newest round first); (None, None) when no committed profile holds
-    this kernel at this batch. The figure is not measured by this run — the line names the file it comes from."""
+    this kernel at this batch. The figure is not measured by this run — the line names the file it comes from.
+    with_counters: a third value, the kernel's counter record of that file ({"mfma_busy_frac", "waves_per_simd", ...} or None)."""
+    none = (None, None, None) if with_counters else (None, None)
     for name in files:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -487,12 +489,28 @@ def measured_traffic(batch, kernel, files=("r05_traffic.json", "r04_traffic.json
             per = t.get("kernels", {})
             for k, v in per.items():
                 if kernel in k and "hbm_read_bytes" in v:
-                    return v["hbm_read_bytes"] + v["hbm_write_bytes"], "profiles/" + name
+                    out = (v["hbm_read_bytes"] + v["hbm_write_bytes"], "profiles/" + name)
+                    return out + (v,) if with_counters else out
             if kernel.startswith("attn_dkv") and "attn_bwd_dkv_bytes_per_launch" in t:
-                return t["attn_bwd_dkv_bytes_per_launch"], "profiles/" + name
+                out = (t["attn_bwd_dkv_bytes_per_launch"], "profiles/" + name)
+                return out + (None,) if with_counters else out
         except (OSError, ValueError, AttributeError):
             pass
-    return None, None
+    return none
+
+
+def _counter_fields(traffic, counters, launch_ms):
+    """north_star: "rocprof counters reported as achieved HBM GB/s and MFMA utilisation": the committed counter pass of the
+    kernel (bytes, matrix-pipe busy fraction, resident waves) next to THIS run's launch time."""
+    out = {"hbm_gbps_achieved": None if traffic is None else traffic / (launch_ms * 1e-3) / 1e9,
+           "hbm_gbps_what": "HBM bytes per launch of the committed rocprofv3 --pmc pass / this run's HIP-event launch time; "
+                            "peak 8000 GB/s spec, 6290 GB/s measured copy (MI355X_MICROARCH.md)"}
+    if counters:
+        out["mfma_busy_frac"] = counters.get("mfma_busy_frac")
+        out["waves_per_simd"] = counters.get("waves_per_simd")
+        if counters.get("SQ_INSTS_MFMA"):
+            out["valu_per_mfma"] = counters.get("SQ_INSTS_VALU", 0.0) / counters["SQ_INSTS_MFMA"]
+    return out
 
 
 def _physical_cores():
@@ -619,11 +637,11 @@ DOMINANT = {}
 
 def _dominant_kernel(model):
     """(name, share of kernel time, average microseconds) of the top kernel in the newest committed rocprofv3 table of this
-    workload, profiles/r05_<model>_kernel_stats.csv (else r04): a committed profile, not a measurement of this run."""
+    workload, profiles/r06_<model>_kernel_stats.csv (else r05, r04): a committed profile, not a measurement of this run."""
     import csv
 
     try:
-        path = next(p for p in (os.path.join(ROOT, "profiles", f"{r}_{model}_kernel_stats.csv") for r in ("r05", "r04"))
+        path = next(p for p in (os.path.join(ROOT, "profiles", f"{r}_{model}_kernel_stats.csv") for r in ("r06", "r05", "r04"))
                     if os.path.exists(p))
         with open(path) as f:
             rows = list(csv.DictReader(f))
@@ -958,7 +976,8 @@ def main():
         if env.world == 1:
             r = attention_kernel_roofline(args.batch, env.device, 4, 4, 4, 28, False)
             dom = "bwd" if "bwd" in r else "dkv"
-            traffic, traffic_src = measured_traffic(args.batch, "attn_bwd_m44_kernel" if dom == "bwd" else "attn_dkv_m44_kernel")
+            traffic, traffic_src, counters = measured_traffic(args.batch, "attn_bwd_m44_kernel" if dom == "bwd" else "attn_dkv_m44_kernel",
+                                                              with_counters=True)
             out["roofline"] = {
                 "bound": "mfma",  # fp32: matrix peak == vector peak == 157.3 TF on gfx950; the
                                   # kernel is 4x4x1-MFMA + v_exp issue bound
@@ -971,6 +990,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,  # a committed rocprofv3 --pmc pass of this kernel at this batch, not this run
                 "launch_ms": r[dom]["launch_ms"],
+                **_counter_fields(traffic, counters, r[dom]["launch_ms"]),
                 "flop_per_launch": r[dom]["flop_per_launch"],
                 "flop_accounting": "algorithmic: 6 d_k + 4 d_v = 40 FLOP per allowed (query, key) pair, every product once",
                 "other_kernels": {"attn_fwd_m44_kernel": r["fwd"],
@@ -997,8 +1017,9 @@ def main():
                 else:
                     waves = 4 if e("PG_CONV_B3P_WAVES") == "4" else 8
                     ck, cdesc = f"conv_b3p_kernel<2, {waves}>", f"fp32 products as 6 bf16 MFMAs, {waves} waves per workgroup"
-                snail_traffic, snail_src = measured_traffic(args.snail_batch, ck.split("<")[0],
-                                                            ("r05_snail_conv_pmc.json", "r04_snail_conv_pmc.json"))
+                snail_traffic, snail_src, snail_ctr = measured_traffic(
+                    args.snail_batch, ck.split("<")[0], ("r06_snail_conv_pmc.json", "r05_snail_conv_pmc.json", "r04_snail_conv_pmc.json"),
+                    with_counters=True)
                 out["pixel_snail"]["roofline"] = {
                     "bound": "mfma",
                     "kernel": f"{ck} (pg_conv2d_mfma: 2x2 64->64 convolution, ELU prologue; {cdesc})",
@@ -1008,6 +1029,7 @@ def main():
                     "frac": c["tflops"] / b3_ceiling,
                     "frac_of_fp32_matrix_peak": c["tflops"] / FP32_PEAK_TFLOPS,
                     "launch_ms": c["launch_ms"],
+                    **_counter_fields(snail_traffic, snail_ctr, c["launch_ms"]),
                     "flop_per_launch": c["flop_per_launch"],
                     # HBM bytes of the SAME launch (shape and batch) from separate rocprofv3 --pmc passes
                     # (profiles/r04_snail_conv_pmc.json: calibrated on an add kernel in the same process); algorithmic =

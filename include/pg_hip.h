@@ -242,9 +242,12 @@ int pg_add(const float* a, const float* b, float* out, size_t n, void* stream);
  * (torch.zeros on the reference path, e.g. vd_vae.py:379 torch.zeros_like(...)); a kernel, not a memset node
  * (a hipMemset2DAsync node of a captured step went wrong from its second replay on: profiles/README.md round 4 item 12) */
 int pg_fill(float* out, float value, size_t n, void* stream);
-/* out[i] = sum_k rows[k][i], k < n_rows <= 32 (rows: HOST array of device pointers, copied into the launch): the sum over the
- * per-block KL terms of a hierarchical VAE, vd_vae.py:400 `torch.stack(kl_divs).sum(dim=0)`, in one launch */
-int pg_sum_rows(const float* const* rows, int n_rows, float* out, size_t n, void* stream);
+/* out[b * per + i] = sum_k rows[k][b * batch_strides[k] + i], b < n_batch, i < per, k < n_rows <= 32 (rows, batch_strides: HOST
+ * arrays copied into the launch; batch_strides == NULL: every row dense, stride per): (a) the sum over the per-block KL terms of a
+ * hierarchical VAE, vd_vae.py:400 `torch.stack(kl_divs).sum(dim=0)`, in one launch; (b) the gradient of a tensor with several
+ * readers (autograd's chain of `add` kernels) in one launch, where a gradient may be a channel slice of a wider tensor (dense per
+ * image, batch stride > per) */
+int pg_sum_rows(const float* const* rows, const long* batch_strides, int n_rows, float* out, long n_batch, long per, void* stream);
 /* y[n,i] = x[n,i] + p[i] (learned positional map, image_gpt.py:86,106); i < per */
 int pg_add_bcast_fwd(const float* x, const float* p, float* y, int N, size_t per, void* stream);
 /* dp[i] += sum_n dy[n,i] */

@@ -136,16 +136,23 @@ __global__ void fill_kernel(float* __restrict__ out, float value, size_t n, int 
 
 struct SumRowsArgs {
   const float* rows[32];
+  long bs[32];
   float* out;
+  long per;
   size_t n;
-  int n_rows;
+  int n_rows, dense;
 };
 
 __global__ void sum_rows_kernel(const SumRowsArgs a) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
     float s = 0.f;
-    for (int k = 0; k < a.n_rows; ++k) s += a.rows[k][i];  // fixed order: bit-reproducible
+    if (a.dense) {
+      for (int k = 0; k < a.n_rows; ++k) s += a.rows[k][i];  // fixed order: bit-reproducible
+    } else {
+      const long b = (long)(i / (size_t)a.per), r = (long)(i - (size_t)b * a.per);
+      for (int k = 0; k < a.n_rows; ++k) s += a.rows[k][b * a.bs[k] + r];
+    }
     a.out[i] = s;
   }
 }
@@ -443,15 +450,25 @@ PG_EXPORT int pg_fill(float* out, float value, size_t n, void* stream) {
   return 0;
 }
 
-PG_EXPORT int pg_sum_rows(const float* const* rows, int n_rows, float* out, size_t n, void* stream) {
+PG_EXPORT int pg_sum_rows(const float* const* rows, const long* batch_strides, int n_rows, float* out, long n_batch, long per,
+                          void* stream) {
   PG_REQUIRE(rows && out, PG_EINVAL, "pg_sum_rows: null pointer");
   PG_REQUIRE(n_rows >= 1 && n_rows <= 32, PG_ESHAPE, "pg_sum_rows: 1..32 rows per launch, got %d", n_rows);
-  if (n == 0) return 0;
+  PG_REQUIRE(n_batch >= 0 && per >= 0, PG_EINVAL, "pg_sum_rows: negative size");
+  if (n_batch == 0 || per == 0) return 0;
   SumRowsArgs a;
-  for (int k = 0; k < 32; ++k) a.rows[k] = k < n_rows ? rows[k] : nullptr;
-  for (int k = 0; k < n_rows; ++k) PG_REQUIRE(a.rows[k], PG_EINVAL, "pg_sum_rows: null row %d", k);
-  a.out = out; a.n = n; a.n_rows = n_rows;
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, EW_STREAM, a);
+  a.dense = 1;
+  for (int k = 0; k < 32; ++k) {
+    a.rows[k] = k < n_rows ? rows[k] : nullptr;
+    a.bs[k] = (k < n_rows && batch_strides) ? batch_strides[k] : per;
+    if (k < n_rows) {
+      PG_REQUIRE(a.rows[k], PG_EINVAL, "pg_sum_rows: null row %d", k);
+      PG_REQUIRE(a.bs[k] >= per, PG_EINVAL, "pg_sum_rows: batch stride of row %d below the row length", k);
+      if (a.bs[k] != per) a.dense = 0;
+    }
+  }
+  a.out = out; a.per = per; a.n = (size_t)n_batch * (size_t)per; a.n_rows = n_rows;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(ew_blocks(a.n)), dim3(EW_THREADS), 0, EW_STREAM, a);
   PG_LAUNCH_CHECK("pg_sum_rows");
   return 0;
 }

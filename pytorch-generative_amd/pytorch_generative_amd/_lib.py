@@ -107,7 +107,7 @@ SIGNATURES = {
     "pg_phase_merge4": (c_i, [c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_i, c_s]),
     "pg_phase_weights": (c_i, [c_f, c_f, c_i, c_i, c_i, c_s]),
     "pg_phase_weights_bwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_f, c_i, c_i, c_i, c_i, c_s]),
-    "pg_sum_rows": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_f, c_z, c_s]),
+    "pg_sum_rows": (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long), c_i, c_f, c_l, c_l, c_s]),
     "pg_avgpool2_bwd_res": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_s]),
     "pg_add_bcast_fwd": (c_i, [c_f, c_f, c_f, c_i, c_z, c_s]),
     "pg_add_bcast_bwd": (c_i, [c_f, c_f, c_i, c_z, c_s]),

@@ -55,11 +55,14 @@ class GatedResnet(nn.Module):
         self._gate = pg_nn.GatedActivation(activation_fn=nn.Identity())
 
     def forward(self, x, aux=None):
+        # x has two readers (the activation and the gate's residual): two pass-through aliases, whose gradients one launch sums
+        # (ops.fanout) instead of autograd's add kernel
+        x, x_res = ops.fanout(x, 2)
         c1 = self._conv_in(ops.concat_elu(x))
         if aux is not None:
             c1 = self._nin(ops.concat_elu(aux), res=c1)
         c2 = self._conv_out(ops.concat_elu(c1))
-        return self._gate(c2, res=x)
+        return self._gate(c2, res=x_res)
 
 
 class PixelCNNpp(base.AutoregressiveModel):
@@ -99,20 +102,29 @@ class PixelCNNpp(base.AutoregressiveModel):
         if h % 4 or w % 4:
             raise ValueError("PixelCNNpp: H and W must be multiples of 4 (two stride-2 levels)")
         xp = ops.concat_channels([x, torch.ones((n, 1, h, w), device=x.device, dtype=x.dtype)])
-        u = [self._u_in(xp)]
-        ul = [self._ul_in_b(xp, res=self._ul_in_a(xp))]
+        # Every stream tensor of the up pass has two readers — the next layer and, later, the down pass's short-cut (a tensor
+        # of the u stream a third one: the ul stream's layer of the same step): each reader takes its own pass-through alias
+        # (ops.fanout), so that the gradients are summed by one launch per tensor instead of autograd's chains of add kernels.
+        # `u_cur` / `ul_cur` = the alias for the next layer, u / ul = the stacks of short-cut aliases.
+        u_cur, a = ops.fanout(self._u_in(xp), 2)
+        ul_cur, b = ops.fanout(self._ul_in_b(xp, res=self._ul_in_a(xp)), 2)
+        u, ul = [a], [b]
         for s in range(3):  # up pass: towards the coarse resolution
             for ru, rul in zip(self._up_u[s], self._up_ul[s]):
-                u.append(ru(u[-1]))
-                ul.append(rul(ul[-1], aux=u[-1]))
+                u_cur, u_aux, a = ops.fanout(ru(u_cur), 3)
+                ul_cur, b = ops.fanout(rul(ul_cur, aux=u_aux), 2)
+                u.append(a)
+                ul.append(b)
             if s < 2:
-                u.append(ops.subsample2(self._down_u_conv[s](u[-1])))
-                ul.append(ops.subsample2(self._down_ul_conv[s](ul[-1])))
-        hu, hul = u.pop(), ul.pop()
+                u_cur, a = ops.fanout(ops.subsample2(self._down_u_conv[s](u_cur)), 2)
+                ul_cur, b = ops.fanout(ops.subsample2(self._down_ul_conv[s](ul_cur)), 2)
+                u.append(a)
+                ul.append(b)
+        hu, hul = u.pop(), ul.pop()  # (the last tensors' "next layer" aliases stay unused: they carry no gradient)
         for s in range(3):  # down pass: back to the fine resolution, short-cuts from the up pass
             for ru, rul in zip(self._dn_u[s], self._dn_ul[s]):
-                hu = ru(hu, aux=u.pop())
-                hul = rul(hul, aux=ops.concat_channels([hu, ul.pop()]))
+                hu, hu_cat = ops.fanout(ru(hu, aux=u.pop()), 2)  # read by the ul stream's concatenation and by the next layer
+                hul = rul(hul, aux=ops.concat_channels([hu_cat, ul.pop()]))
             if s < 2:
                 hu = self._up_u_conv[s](ops.zero_insert2(hu))
                 hul = self._up_ul_conv[s](ops.zero_insert2(hul))

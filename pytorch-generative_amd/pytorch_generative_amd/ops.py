@@ -1364,30 +1364,64 @@ def avg_pool2(x, n_skip=0):
     return _AvgPool2.apply(x, int(n_skip))
 
 
+def _sum_into(out, ts):
+    """out = sum of the tensors ts (same shape as out; each dense, or dense per image with a larger batch stride) in one
+    pg_sum_rows launch per 31 tensors."""
+    import ctypes
+
+    lib = _lib.load()
+    n_batch, per = (int(out.shape[0]), out.numel() // max(int(out.shape[0]), 1)) if out.dim() == 4 else (1, out.numel())
+    acc = None
+    for i in range(0, len(ts), 31):  # 32 rows per launch, the running sum among them
+        grp = ([acc] if acc is not None else []) + list(ts[i:i + 31])
+        rows = (ctypes.c_void_p * len(grp))(*[t.data_ptr() for t in grp])
+        bs = (ctypes.c_long * len(grp))(*[(int(t.stride(0)) if t.dim() == 4 else per) for t in grp])
+        _lib.check(lib.pg_sum_rows(rows, bs, len(grp), out.data_ptr(), n_batch, per, _stream()), "pg_sum_rows")
+        acc = out
+    return out
+
+
 class _SumVectors(torch.autograd.Function):
     """out = sum of k equally shaped tensors in ONE launch (pg_sum_rows); every input's gradient is the output's."""
 
     @staticmethod
     def forward(ctx, *ts):
-        import ctypes
-
-        lib = _lib.load()
         ts = [_chk(t, "sum_vectors.t") for t in ts]
         if any(t.shape != ts[0].shape for t in ts):
             raise ValueError("sum_vectors: shape mismatch")
-        out = torch.empty_like(ts[0])
-        acc = None
-        for i in range(0, len(ts), 31):  # 32 rows per launch, the running sum among them
-            grp = ([acc] if acc is not None else []) + ts[i:i + 31]
-            rows = (ctypes.c_void_p * len(grp))(*[t.data_ptr() for t in grp])
-            _lib.check(lib.pg_sum_rows(rows, len(grp), out.data_ptr(), out.numel(), _stream()), "pg_sum_rows")
-            acc = out
         ctx.k = len(ts)
-        return out
+        return _sum_into(torch.empty_like(ts[0]), ts)
 
     @staticmethod
     def backward(ctx, g):
         return (g,) * ctx.k
+
+
+class _Fanout(torch.autograd.Function):
+    """k pass-through aliases of x for k readers: autograd then never sums gradients for x with its own chain of k - 1 `add`
+    kernels — the k gradients come back HERE and are summed by one launch (pg_sum_rows), each read where it lies (a gradient
+    that is a channel slice of a wider tensor, e.g. out of concat_channels' backward, with its batch stride: no copy)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g if (g.dim() == 4 and _dense_per_image(g)) else _chk(g, "fanout.g") for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty(gs[0].shape, device=gs[0].device, dtype=torch.float32)
+        return _sum_into(out, gs), None
+
+
+def fanout(x, k):
+    """k aliases of x, one per reader (see _Fanout); x itself when it needs no gradient or k < 2."""
+    if k < 2 or not FUSE_SKIP or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * max(int(k), 1)
+    return _Fanout.apply(x, int(k))
 
 
 def sum_vectors(ts):
@@ -1647,22 +1681,45 @@ class _PhaseWeights(torch.autograd.Function):
 
 
 class _SplitInChannels(torch.autograd.Function):
-    """(w[:, :c1], w[:, c1:]) as two contiguous tensors; backward = one concatenation (as slices: two zero fills, two
-    strided copies and an add into the weight's gradient)."""
+    """(w[:, :c1], w[:, c1:]) as two contiguous tensors: two row copies (pg_copy_rows) each way; the backward adds straight
+    into the parameter's flat-gradient slice when it has one (as slices: two zero fills, two strided copies and an add into
+    the weight's gradient; round 5: two ATen copies + a concatenation + autograd's accumulation)."""
 
     @staticmethod
-    def forward(ctx, w, c1):
+    def forward(ctx, w, c1, sink):
         if not 0 < c1 < w.shape[1]:
             raise ValueError("split_in_channels: split point outside the weight's input channels")
-        return w[:, :c1].contiguous(), w[:, c1:].contiguous()
+        lib = _lib.load()
+        w = _chk(w, "split_in_channels.w")
+        co, ci = w.shape[0], w.shape[1]
+        k = int(w[0, 0].numel())  # kh * kw
+        ctx.shape, ctx.c1, ctx.sink, ctx.k = tuple(w.shape), c1, sink, k
+        wa = torch.empty((co, c1) + tuple(w.shape[2:]), device=w.device, dtype=torch.float32)
+        wb = torch.empty((co, ci - c1) + tuple(w.shape[2:]), device=w.device, dtype=torch.float32)
+        _lib.check(lib.pg_copy_rows(w.data_ptr(), wa.data_ptr(), co, c1 * k, ci * k, c1 * k, 0, _stream()), "pg_copy_rows")
+        _lib.check(lib.pg_copy_rows(w.data_ptr() + 4 * c1 * k, wb.data_ptr(), co, (ci - c1) * k, ci * k, (ci - c1) * k, 0,
+                                    _stream()), "pg_copy_rows")
+        return wa, wb
 
     @staticmethod
-    def backward(ctx, ga, gb):  # autograd materialises an unused half's gradient as zeros
-        return torch.cat((ga, gb), dim=1), None
+    def backward(ctx, ga, gb):
+        lib = _lib.load()
+        co, ci = ctx.shape[:2]
+        c1, k, sink = ctx.c1, ctx.k, ctx.sink
+        like = ga if ga is not None else gb
+        acc = 1 if sink is not None else 0
+        dst = sink if sink is not None else zeros(ctx.shape, like.device)
+        for g, off, n in ((ga, 0, c1), (gb, c1, ci - c1)):
+            if g is None:
+                continue
+            g = _chk(g, "split_in_channels.g")
+            _lib.check(lib.pg_copy_rows(g.data_ptr(), dst.data_ptr() + 4 * off * k, co, n * k, n * k, ci * k, acc, _stream()),
+                       "pg_copy_rows")
+        return (None if sink is not None else dst), None, None
 
 
 def split_in_channels(w, c1):
-    return _SplitInChannels.apply(w, int(c1))
+    return _SplitInChannels.apply(w, int(c1), _sink(w))
 
 
 def phase_weights(w, transposed=False):

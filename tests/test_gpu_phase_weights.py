@@ -1,6 +1,6 @@
 """ops.phase_weights (the four stride-2 phase kernels of a 4x4 weight, one launch each way: pg_phase_weights / pg_phase_weights_bwd
 since round 6 — GPU tests) against the strided slices it replaces (nn/convolution.py: Conv2d._forward_down2,
-ConvTranspose2d.forward): values and gradients, with and without a flat-gradient sink; ops.split_in_channels (CPU)."""
+ConvTranspose2d.forward): values and gradients, with and without a flat-gradient sink; ops.split_in_channels (pg_copy_rows)."""
 import pytest
 import torch
 
@@ -60,19 +60,28 @@ def test_phase_merge4_equals_the_stacked_merge():
     assert torch.equal(x[:, :, 1::2, 0::2], ps[2].detach())  # phase (pr, pc) = (1, 0)
 
 
+@pytest.mark.gpu
 def test_split_in_channels_equals_the_slices():
     torch.manual_seed(1)
-    w = torch.randn(4, 6, 1, 1, requires_grad=True)
+    w = torch.randn(4, 6, 1, 1, device="cuda:0", requires_grad=True)
     w2 = w.detach().clone().requires_grad_(True)
     a, b = ops.split_in_channels(w, 2)
     ca, cb = torch.randn_like(a), torch.randn_like(b)
     ((a * ca).sum() + (b * cb).sum()).backward()
     ((w2[:, :2] * ca).sum() + (w2[:, 2:] * cb).sum()).backward()
     assert torch.equal(a, w2[:, :2]) and torch.equal(b, w2[:, 2:]) and torch.equal(w.grad, w2.grad)
-    w3 = torch.randn(4, 6, 1, 1, requires_grad=True)
+    w3 = torch.randn(4, 6, 1, 1, device="cuda:0", requires_grad=True)
     _, b3 = ops.split_in_channels(w3, 2)
     (b3 * cb).sum().backward()  # the first half never used
     assert torch.equal(w3.grad[:, 2:], cb) and float(w3.grad[:, :2].abs().max()) == 0.0
+    # 3x3 weight and a flat-gradient sink: the backward adds into it and hands autograd nothing
+    w4 = torch.randn(5, 7, 3, 3, device="cuda:0", requires_grad=True)
+    w4._pg_grad = torch.full_like(w4, 0.25)
+    a4, b4 = ops.split_in_channels(w4, 3)
+    c4a, c4b = torch.randn_like(a4), torch.randn_like(b4)
+    ((a4 * c4a).sum() + (b4 * c4b).sum()).backward()
+    assert torch.equal(a4, w4[:, :3]) and torch.equal(b4, w4[:, 3:]) and w4.grad is None
+    assert torch.equal(w4._pg_grad, torch.cat((c4a, c4b), dim=1) + 0.25)
 
 
 @pytest.mark.gpu
@@ -87,3 +96,25 @@ def test_phase_split4_equals_the_stacked_split():
     sum((p * c).sum() for p, c in zip(ps[:3], cs)).backward()      # the fourth phase unused: its gradient is None
     sum((xs[k] * cs[k]).sum() for k in range(3)).backward()
     assert all(torch.equal(p, xs[k]) for k, p in enumerate(ps)) and torch.equal(x.grad, x2.grad)
+
+
+@pytest.mark.gpu
+def test_fanout_sums_the_readers_gradients_in_one_launch():
+    """ops.fanout: k aliases for k readers; the gradient of x is the sum of the readers' gradients, also when one of them is a
+    channel slice of a wider tensor (the backward of concat_channels), and when a reader is unused."""
+    torch.manual_seed(4)
+    dev = torch.device("cuda:0")
+    x = torch.randn(3, 4, 6, 8, device=dev, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    other = torch.randn(3, 2, 6, 8, device=dev)
+    a, b, c, unused = ops.fanout(x, 4)
+    wide = ops.concat_channels([other, b])          # b's gradient comes back as a batch-strided slice
+    g_a, g_w, g_c = torch.randn_like(a), torch.randn_like(wide), torch.randn_like(c)
+    ((a * g_a).sum() + (wide * g_w).sum() + (ops.relu(c) * g_c).sum()).backward()
+    ((x2 * g_a).sum() + (torch.cat([other, x2], 1) * g_w).sum() + (torch.relu(x2) * g_c).sum()).backward()
+    assert torch.allclose(x.grad, x2.grad, rtol=0, atol=1e-6)
+    # 40 vectors through sum_vectors: two launches with the running sum among the rows
+    vs = [torch.randn(7, device=dev, requires_grad=True) for _ in range(40)]
+    s = ops.sum_vectors(vs)
+    s.backward(torch.ones_like(s))
+    assert torch.allclose(s, torch.stack([v.detach() for v in vs]).sum(0), atol=1e-5) and all(float(v.grad.min()) == 1.0 for v in vs)
