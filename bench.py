@@ -994,7 +994,7 @@ def main():
                 "flop_per_launch": r[dom]["flop_per_launch"],
                 "flop_accounting": "algorithmic: 6 d_k + 4 d_v = 40 FLOP per allowed (query, key) pair, every product once",
                 "other_kernels": {"attn_fwd_m44_kernel": r["fwd"],
-                                  "two_kernel_backward (PG_ATTN_FUSED_BWD=0)": {"attn_dq_m44_kernel": r["dq"],
+                                  "two_kernel_backward (pg_attn_fused_bwd(0) = ops.set_deterministic)": {"attn_dq_m44_kernel": r["dq"],
                                                                                 "attn_dkv_m44_kernel": r["dkv"]}},
                 # whole step; attention counted on the causal triangle, algorithmic (no recomputation)
                 "step_tflops": head["step_tflops"],
@@ -1040,7 +1040,7 @@ def main():
                     "other_kernels": {"conv_wgrad_b3_kernel<4> + wgrad_reduce_kernel": w,
                                       "attn_fwd_k4_kernel": a["fwd"],
                                       "attn_delta_k4 + attn_bwd_k4_kernel (fused backward)": a.get("bwd"),
-                                      "two_kernel_backward (PG_ATTN_FUSED_BWD_K4=0)": {"attn_dq_k4_kernel": a["dq"],
+                                      "two_kernel_backward (pg_attn_fused_bwd(0) = ops.set_deterministic)": {"attn_dq_k4_kernel": a["dq"],
                                                                                      "attn_dkv_k4_kernel": a["dkv"]}},
                 }
             if not args.no_cpu_baseline:

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 # PG_ABLATE=1: the timing-only ablation build (-DPG_ABLATE: PG_B3_DBG / PG_WB_DBG are compiled in) as a SEPARATE
 # library, lib/libpg_hip_ablate.so, for tools/exp — the production library never contains those switches
 ABLATE = os.environ.get("PG_ABLATE") == "1"
-# PG_VARIANT=<name>: an EXPERIMENT build with -DPG_<NAME> (e.g. PG_VARIANT=bufload -> -DPG_BUFLOAD, common.h) as a
+# PG_VARIANT=<name>: an EXPERIMENT build with -DPG_<NAME> (e.g. PG_VARIANT=ab -> -DPG_AB: the kernels' A/B switches live, common.h) as a
 # separate library lib/libpg_hip_<name>.so; tests / bench pick it up with PG_HIP_LIB=<path> (pytorch_generative_amd/_lib.py)
 VARIANT = os.environ.get("PG_VARIANT", "")
 _TAG = "ablate" if ABLATE else VARIANT

@@ -374,6 +374,24 @@ def test_lds_zero_fills_are_ordered_before_the_first_commit():
     # VALU tap kernel and fp32 weight-gradient kernel: the chunk / tile loop opens with a barrier
     assert "__syncthreads();" in between("conv_direct.hip", "i < a.CIB * a.ch_stride; i += blockDim.x) lds[i] = 0.f;", "pg_stage_rows_vec4<ACT>")
     assert "__syncthreads();" in between("conv_wgrad.hip", "i < lds_floats; i += WG_THREADS) lds[i] = 0.f;", "PG_WG_COMMIT_X(PG_ACT_RELU) break;")
+    # the overlapped 16-wave kernel (round 6)
+    assert "__syncthreads();" in between("conv_b3q_kernel.h", "i < NXT * 2 * xbuf16; i += B3Q_THREADS) lds16[i]", "PG_Q_COMMIT_X(0)")
+
+
+def test_lds_dma_slabs_are_waited_for_before_the_barrier_that_publishes_them():
+    """Source-level guard for the weight slabs moved by LDS-DMA (global_load_lds_dwordx4 issued by inline asm: INVISIBLE to the compiler's
+    waitcnt model, advisor finding of round 5): between every DMA issue inside a step loop and the workgroup barrier that lets other waves
+    read the slab there must be an explicit s_waitcnt vmcnt. The behavioural checks are the convolution parity cases (destinations up to
+    150 KB into LDS in conv_b3q_kernel: every launch of tests/test_gpu_ops.py's 6-tap cases) and the twin-process tier."""
+    csrc = os.path.join(ROOT, "pytorch-generative_amd", "csrc")
+    for path, dma, stop in (("conv_b3_kernels.h", "if (more) PG_B3_WGLDS(step + 1)", "if (more) __syncthreads();"),
+                            ("conv_b3_kernels.h", "PG_B3_WGLDS(0)", "__syncthreads();"),
+                            ("conv_b3q_kernel.h", "PG_Q_DMA(nj_, same_ ? ks + 1 : 0, stage ^ 1)", "if (more_q) __syncthreads();"),
+                            ("conv_b3q_kernel.h", "PG_Q_DMA(0, 0, 0)", "__syncthreads();")):
+        text = open(os.path.join(csrc, path)).read()
+        i = text.index(dma)
+        seg = text[i:text.index(stop, i)]
+        assert re.search(r's_waitcnt vmcnt\(', seg), f"{path}: no explicit vmcnt wait between `{dma}` and the barrier"
 
 
 # ---- planners without a GPU ------------------------------------------------------------------------------------------
