@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
 def run(conv, x, kw, mfma):
-    ops.CONV_MFMA = mfma
+    ops.conv.CONV_MFMA = mfma  # (the flag lives in the ops.conv module since the round-6 split)
     x = x.clone().requires_grad_(True)
     y = conv(x, **kw)
     g = torch.ones_like(y) * 0.5 + torch.arange(y.numel(), device=dev).reshape(y.shape).remainder(7) * 0.1
@@ -62,12 +62,12 @@ for name, ctor, shape, kw in CASES:
     ex = float((dx1 - dx0).abs().max() / dx0.abs().max())
     ew = float((dw1 - dw0).abs().max() / dw0.abs().max())
     def fwd(m):
-        ops.CONV_MFMA = m
+        ops.conv.CONV_MFMA = m
         with torch.no_grad():
             conv(x, **kw)
     xg = x.clone().requires_grad_(True)
     def fb(m):
-        ops.CONV_MFMA = m
+        ops.conv.CONV_MFMA = m
         y = conv(xg, **kw)
         y.backward(y0)
     t0, t1 = timeit(lambda: fwd(False)), timeit(lambda: fwd(True))
