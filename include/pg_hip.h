@@ -372,6 +372,15 @@ int pg_gpt_block_head_bwd_with_tail(const float* x, const float* ln_w, const flo
                                     size_t workspace_floats, const float* tail_workspace, float* t_dw1,
                                     float* t_db1, float* t_dw2, float* t_db2, float* t_dwp, float* t_dbp,
                                     float* t_dln_w, float* t_dln_b, void* stream);
+/* Round 6: the same head backward WITHOUT its reduction (partial rows stay in `workspace`), and ONE launch that adds the partial
+ * rows of up to 8 blocks' head and tail kernels into their gradients at the end of the backward pass (at the reference's batch 64
+ * the eight per-block reduce launches were 3.9 % of a step's kernel time). grads: n_blocks x 14 device pointers (HOST array), per
+ * block dln1_w, dln1_b, dwq, dbq, dwkv, dbkv, then the tail's dw1, db1, dw2, db2, dwp, dbp, dln2_w, dln2_b. */
+int pg_gpt_block_head_bwd_partial(const float* x, const float* ln_w, const float* ln_b, const float* wq, const float* wkv,
+                                  const float* dqkv, const float* gx, float* dx, int N, int C, int L, float eps,
+                                  float* workspace, size_t workspace_floats, void* stream);
+int pg_gpt_blocks_reduce(int n_blocks, const float* const* head_ws, const float* const* tail_ws, float* const* grads,
+                         int N, int C, int L, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Incremental autoregressive sampling (models/base.py:97-120 runs H*W full forwards; the causal

@@ -529,6 +529,42 @@ __global__ void __launch_bounds__(256) seg_reduce2_kernel(const SegArgs2 a2) {
   }
 }
 
+// Round 6: the reductions of up to 8 blocks (16 jobs) in ONE launch at the end of the backward pass — at the reference's batch 64 a
+// replayed step is ~83 launches of which ~45 run at the ~4.5 us floor of a graph kernel node; the eight per-block reduce launches
+// were 3.9 % of its kernel time (profiles/r05_image_gpt_b64_kernel_stats.csv).
+constexpr int SEG_MAX_JOBS = 16;
+struct SegArgsN { SegArgs j[SEG_MAX_JOBS]; int first[SEG_MAX_JOBS + 1]; int n; };
+__global__ void __launch_bounds__(256) seg_reduceN_kernel(const SegArgsN an) {
+  __shared__ float red[32][9];
+  int job = 0;
+  while (job + 1 < an.n && (int)blockIdx.x >= an.first[job + 1]) ++job;
+  const SegArgs& a = an.j[job];
+  const int blk = blockIdx.x - an.first[job];
+  const int sl = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int s = blk * 8 + sl;
+  float a0 = 0.f, a1 = 0.f;
+  if (s < a.stride) {
+    const float* p = a.part + s;
+    int r = rg;
+    for (; r + 32 < a.rows; r += 64) {
+      a0 += p[(size_t)r * a.stride];
+      a1 += p[(size_t)(r + 32) * a.stride];
+    }
+    if (r < a.rows) a0 += p[(size_t)r * a.stride];
+  }
+  red[rg][sl] = a0 + a1;
+  __syncthreads();
+  if (rg != 0 || s >= a.stride) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) acc += red[r][sl];
+  int begin = 0;
+  for (int k = 0; k < a.nseg; ++k) {
+    if (s < a.end[k]) { a.dst[k][s - begin] += acc; return; }
+    begin = a.end[k];
+  }
+}
+
 // Workgroups per launch: whole rounds of resident waves (256 CUs x 4 SIMDs; the kernels hold 5 / 3 / 4 / 2
 // waves per SIMD by their register counts), at least `min_tiles` tiles per wave. which: 0 head fwd,
 // 1 head bwd, 2 tail fwd, 3 tail bwd. PG_BLOCK_GRID="a,b,c,d" overrides the caps (tuning).
@@ -616,12 +652,26 @@ SegArgs tail_seg_args(const float* workspace, int rows, float* dw1, float* db1, 
   return r;
 }
 
+SegArgs head_seg_args(const float* workspace, int rows, float* dln_w, float* dln_b, float* dwq, float* dbq, float* dwkv,
+                      float* dbkv) {
+  SegArgs r = {};
+  r.part = workspace; r.rows = rows; r.stride = H_PART; r.nseg = 6;
+  r.end[0] = H_WKV; r.dst[0] = dwq;
+  r.end[1] = H_BQ; r.dst[1] = dwkv;
+  r.end[2] = H_BKV; r.dst[2] = dbq;
+  r.end[3] = H_G1; r.dst[3] = dbkv;
+  r.end[4] = H_BE1; r.dst[4] = dln_w;
+  r.end[5] = H_PART; r.dst[5] = dln_b;
+  return r;
+}
+
+// defer != 0: the partial rows stay in `workspace` (pg_gpt_blocks_reduce adds them later); the gradient pointers are then unused
 int head_bwd_impl(const float* x, const float* ln_w, const float* ln_b, const float* wq, const float* wkv,
                   const float* dqkv, const float* gx, float* dx, float* dln_w, float* dln_b, float* dwq,
                   float* dbq, float* dwkv, float* dbkv, int N, int Cc, int L, float eps, float* workspace,
-                  size_t workspace_floats, const SegArgs* tail, void* stream) {
-  PG_REQUIRE(x && ln_w && ln_b && wq && wkv && dqkv && gx && dx && dln_w && dln_b && dwq && dbq && dwkv &&
-                 dbkv && workspace, PG_EINVAL, "pg_gpt_block_head_bwd: null pointer");
+                  size_t workspace_floats, const SegArgs* tail, void* stream, int defer = 0) {
+  PG_REQUIRE(x && ln_w && ln_b && wq && wkv && dqkv && gx && dx && workspace &&
+                 (defer || (dln_w && dln_b && dwq && dbq && dwkv && dbkv)), PG_EINVAL, "pg_gpt_block_head_bwd: null pointer");
   int rc = check_shape("pg_gpt_block_head_bwd", N, Cc, L);
   if (rc) return rc;
   PG_REQUIRE(workspace_floats >= pg_gpt_block_head_bwd_workspace_floats(N, L), PG_EINVAL,
@@ -636,14 +686,8 @@ int head_bwd_impl(const float* x, const float* ln_w, const float* ln_b, const fl
   const size_t tr = (size_t)4 * C * TS, rd = (size_t)4 * H_PART;
   hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)blocks), dim3(GB_THREADS), (tr > rd ? tr : rd) * sizeof(float), st, a);
   PG_LAUNCH_CHECK("pg_gpt_block_head_bwd");
-  SegArgs r = {};
-  r.part = workspace; r.rows = blocks; r.stride = H_PART; r.nseg = 6;
-  r.end[0] = H_WKV; r.dst[0] = dwq;
-  r.end[1] = H_BQ; r.dst[1] = dwkv;
-  r.end[2] = H_BKV; r.dst[2] = dbq;
-  r.end[3] = H_G1; r.dst[3] = dbkv;
-  r.end[4] = H_BE1; r.dst[4] = dln_w;
-  r.end[5] = H_PART; r.dst[5] = dln_b;
+  if (defer) return 0;
+  const SegArgs r = head_seg_args(workspace, blocks, dln_w, dln_b, dwq, dbq, dwkv, dbkv);
   if (tail) {  // one launch for this block's two reductions
     SegArgs2 r2;
     r2.j[0] = r; r2.j[1] = *tail; r2.blocks0 = (H_PART + 7) / 8;
@@ -680,6 +724,40 @@ PG_EXPORT int pg_gpt_block_head_bwd_with_tail(const float* x, const float* ln_w,
                                      t_dln_w, t_dln_b);
   return head_bwd_impl(x, ln_w, ln_b, wq, wkv, dqkv, gx, dx, dln_w, dln_b, dwq, dbq, dwkv, dbkv, N, Cc, L, eps,
                        workspace, workspace_floats, &tail, stream);
+}
+
+// head backward WITHOUT its reduction: the partial rows stay in `workspace` for pg_gpt_blocks_reduce
+PG_EXPORT int pg_gpt_block_head_bwd_partial(const float* x, const float* ln_w, const float* ln_b, const float* wq,
+                                            const float* wkv, const float* dqkv, const float* gx, float* dx, int N, int Cc,
+                                            int L, float eps, float* workspace, size_t workspace_floats, void* stream) {
+  return head_bwd_impl(x, ln_w, ln_b, wq, wkv, dqkv, gx, dx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, Cc, L,
+                       eps, workspace, workspace_floats, nullptr, stream, 1);
+}
+
+// ONE launch for the weight-gradient reductions of n_blocks (<= 8) blocks whose head (pg_gpt_block_head_bwd_partial) and tail
+// (pg_gpt_block_tail_bwd_partial) kernels left their partial rows. grads: n_blocks x 14 destinations, per block in the order
+// dln1_w, dln1_b, dwq, dbq, dwkv, dbkv (head) | t_dw1, t_db1, t_dw2, t_db2, t_dwp, t_dbp, t_dln_w, t_dln_b (tail); added to.
+PG_EXPORT int pg_gpt_blocks_reduce(int n_blocks, const float* const* head_ws, const float* const* tail_ws, float* const* grads,
+                                   int N, int Cc, int L, void* stream) {
+  PG_REQUIRE(head_ws && tail_ws && grads, PG_EINVAL, "pg_gpt_blocks_reduce: null pointer");
+  PG_REQUIRE(n_blocks >= 1 && 2 * n_blocks <= SEG_MAX_JOBS, PG_ESHAPE, "pg_gpt_blocks_reduce: 1..8 blocks per launch, got %d", n_blocks);
+  if (int rc = check_shape("pg_gpt_blocks_reduce", N, Cc, L)) return rc;
+  SegArgsN an = {};
+  int nb = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    float* const* g = grads + 14 * b;
+    PG_REQUIRE(head_ws[b] && tail_ws[b], PG_EINVAL, "pg_gpt_blocks_reduce: null workspace of block %d", b);
+    for (int k = 0; k < 14; ++k) PG_REQUIRE(g[k], PG_EINVAL, "pg_gpt_blocks_reduce: null gradient %d of block %d", k, b);
+    an.j[2 * b] = head_seg_args(head_ws[b], grid_blocks(1, N, L), g[0], g[1], g[2], g[3], g[4], g[5]);
+    an.first[2 * b] = nb; nb += (H_PART + 7) / 8;
+    an.j[2 * b + 1] = tail_seg_args(tail_ws[b], bwd_blocks(N, L), g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13]);
+    an.first[2 * b + 1] = nb; nb += (T_PART + 7) / 8;
+  }
+  an.n = 2 * n_blocks;
+  an.first[an.n] = nb;
+  hipLaunchKernelGGL(seg_reduceN_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, an);
+  PG_LAUNCH_CHECK("pg_gpt_blocks_reduce");
+  return 0;
 }
 
 PG_EXPORT int pg_gpt_block_tail_fwd(const float* o, const float* x, const float* wp, const float* bp,

@@ -62,6 +62,9 @@ SIGNATURES = {
     "pg_gpt_block_head_fwd": (c_i, [c_f] * 8 + [c_i, c_i, c_i, c_flt, c_s]),
     "pg_gpt_block_head_bwd": (c_i, [c_f] * 14 + [c_i, c_i, c_i, c_flt, c_f, c_z, c_s]),
     "pg_gpt_block_head_bwd_workspace_floats": (c_z, [c_i, c_i]),
+    "pg_gpt_block_head_bwd_partial": (c_i, [c_f] * 8 + [c_i, c_i, c_i, c_flt, c_f, c_z, c_s]),
+    "pg_gpt_blocks_reduce": (c_i, [c_i, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                   ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_s]),
     "pg_gpt_block_tail_fwd": (c_i, [c_f] * 11 + [c_i, c_i, c_i, c_i, c_flt, c_s]),
     "pg_gpt_block_tail_bwd": (c_i, [c_f] * 20 + [c_i, c_i, c_i, c_i, c_flt, c_f, c_z, c_s]),
     "pg_gpt_block_tail_bwd_workspace_floats": (c_z, [c_i, c_i]),

@@ -7,6 +7,8 @@ NCHW LayerNorm, 1x1 convs (residual adds fused into the projection / MLP-out ker
 GELU, and the fused causal attention core.
 """
 
+import os
+
 import torch
 from torch import nn
 
@@ -14,6 +16,9 @@ from pytorch_generative_amd import _lib
 from pytorch_generative_amd import nn as pg_nn
 from pytorch_generative_amd import ops
 from pytorch_generative_amd.models import base
+
+# A/B (measurement only): 0 = one weight-gradient reduction launch per block instead of one per model (round 6)
+_BLOCK_CHAIN = os.environ.get("PG_BLOCK_CHAIN", "1") != "0"
 
 
 class TransformerBlock(nn.Module):
@@ -37,13 +42,17 @@ class TransformerBlock(nn.Module):
         return ops.gpt_block_supported(x, self._ln1, self._attn._q, self._attn._kv, self._attn._proj,
                                        self._ln2, self._out[0], self._out[2])
 
-    def forward_plus_input(self, x):
+    def forward_plus_input(self, x, chain=None, flush=False):
         """x + self(x) — what the model loop computes (reference image_gpt.py:107) — on the fused
-        head / attention / tail kernels (gpt_block.hip) when the block has the BASELINE shape."""
+        head / attention / tail kernels (gpt_block.hip) when the block has the BASELINE shape.
+        chain / flush (round 6): a queue shared by all blocks of the model, flushed by the block whose backward runs last —
+        the weight-gradient rows of all blocks are then reduced by ONE launch (ops.gpt_block_head)."""
         if not self._fused_ok(x):
             return ops.add(x, self.forward(x))
         attn = self._attn
         pair = {}  # lets the block's two backward kernels share one weight-gradient reduction launch
+        if chain is not None:
+            pair["chain"], pair["flush"] = chain, flush
         qkv, xs = ops.gpt_block_head(x, self._ln1, attn._q, attn._kv, pair)
         o = ops.causal_attention_qkv(qkv, attn._n_heads, attn._embed_channels, attn._out_channels,
                                      attn._mask_center)
@@ -190,8 +199,15 @@ class ImageGPT(base.AutoregressiveModel):
 
     def forward(self, x):
         x = self._input(ops.add_broadcast_batch(x, self._pos))
-        for block in self._transformer:
-            x = block.forward_plus_input(x)
+        # one queue for the blocks' weight-gradient partial rows, flushed by the FIRST block (its backward runs last) — only when
+        # every block takes the fused kernels and a backward pass with a gradient for the first block's input will run
+        blocks = list(self._transformer)
+        chain = None
+        if (ops.DEFER_BLOCK_REDUCE and _BLOCK_CHAIN and torch.is_grad_enabled() and x.requires_grad and len(blocks) > 1
+                and all(b._fused_ok(x) for b in blocks)):
+            chain = ops.new_block_chain()
+        for i, block in enumerate(blocks):
+            x = block.forward_plus_input(x, chain, flush=(i == 0))
         return self._out(self._ln(x))
 
 

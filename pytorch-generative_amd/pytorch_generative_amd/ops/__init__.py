@@ -82,6 +82,9 @@ from pytorch_generative_amd.ops.gpt_block import (  # noqa: F401
     FUSE_BLOCK,
     DEFER_BLOCK_REDUCE,
     _grad_targets,
+    new_block_chain,
+    assert_no_pending_block_reductions,
+    flush_block_reductions,
     _GPTBlockHead,
     _GPTBlockTail,
     gpt_block_supported,

@@ -106,6 +106,47 @@ def _grad_targets(params):
     return tgt, ret
 
 
+_open_chains = []  # weak references to the queues handed out by new_block_chain(): optim.FlatAdam.step() checks that none is pending
+
+
+def new_block_chain():
+    """A queue for the deferred weight-gradient reductions of a model's blocks (see gpt_block_head)."""
+    import weakref
+
+    class _Chain(dict):
+        pass
+
+    chain = _Chain(jobs=[])
+    _open_chains[:] = [r for r in _open_chains if r() is not None]
+    _open_chains.append(weakref.ref(chain))
+    return chain
+
+
+def assert_no_pending_block_reductions():
+    """Raises if a backward pass left deferred reductions unflushed (the block that flushes never ran backward): the queued
+    gradients would silently be missing from the step."""
+    for r in _open_chains:
+        c = r()
+        if c is not None and c["jobs"]:
+            raise RuntimeError(f"{len(c['jobs'])} deferred GPT-block weight-gradient reductions were never flushed: the first "
+                               "block's backward did not run (set PG_BLOCK_REDUCE_MERGED=0 to reduce per block)")
+
+
+def flush_block_reductions(chain, n, c, L):
+    """Adds the partial weight-gradient rows of every block queued in `chain` (8 blocks per launch) and empties the queue."""
+    import ctypes
+
+    lib = _lib.load()
+    jobs = chain["jobs"]
+    for i in range(0, len(jobs), 8):
+        grp = jobs[i:i + 8]
+        hw = (ctypes.c_void_p * len(grp))(*[j[0].data_ptr() for j in grp])
+        tw = (ctypes.c_void_p * len(grp))(*[j[1].data_ptr() for j in grp])
+        gr = (ctypes.c_void_p * (14 * len(grp)))(*[ptr for j in grp for ptr in j[2]])
+        _lib.check(lib.pg_gpt_blocks_reduce(len(grp), hw, tw, gr, n, c, L, _stream()), "pg_gpt_blocks_reduce")
+    jobs.clear()
+
+
 class _GPTBlockHead(torch.autograd.Function):
     """(qkv, x) = ([W_q; W_kv] LN1(x) + b, x). The second output aliases x: whatever gradient reaches it
     (the residual routes of the block) is added to LN1's input gradient inside the backward kernel."""
@@ -149,6 +190,21 @@ class _GPTBlockHead(torch.autograd.Function):
                      tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr(),
                      tgt[3].data_ptr(), tgt[4].data_ptr(), tgt[5].data_ptr(), n, c,
                      h * w, ctx.eps, ws.data_ptr(), ws_n)
+        chain = ctx.pair.get("chain") if ctx.pair is not None else None
+        if pending is not None and chain is not None and all(r is None for r in ret):
+            # round 6: a model-level chain of blocks (ImageGPT passes one list to all of its blocks): this block's head kernel
+            # leaves its partial rows as well, and the LAST block to run backward (the model's first) adds the rows of every
+            # block with ONE launch (pg_gpt_blocks_reduce) instead of one reduce launch per block
+            t_ws, t = pending
+            _lib.check(lib.pg_gpt_block_head_bwd_partial(*head_args[:8], *head_args[14:], _stream()),
+                       "pg_gpt_block_head_bwd_partial")
+            # 14 destinations in the C-ABI's order: head lnw, lnb, wq, bq, wkv, bkv | tail w1, b1, w2, b2, wp, bp, lnw, lnb
+            chain["jobs"].append((ws, t_ws, [g.data_ptr() for g in tgt] + [t[4].data_ptr(), t[5].data_ptr(), t[6].data_ptr(),
+                                                                          t[7].data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
+                                                                          t[2].data_ptr(), t[3].data_ptr()], (tgt, t)))
+            if ctx.pair.get("flush"):
+                flush_block_reductions(chain, n, c, h * w)
+            return (dx, *ret, None, None, None)
         if pending is not None:  # this block's tail kernel left its partial rows: ONE reduce launch for both
             t_ws, t = pending    # t order: wp, bp, lnw, lnb, w1, b1, w2, b2
             _lib.check(
@@ -236,7 +292,8 @@ def gpt_block_supported(x, ln1, q, kv, proj, ln2, fc1, fc2):
 
 def gpt_block_head(x, ln1, q, kv, pair=None):
     """pair: a dict shared with gpt_block_tail of the SAME block (one per forward): lets the two backward
-    kernels share one weight-gradient reduction launch."""
+    kernels share one weight-gradient reduction launch. pair["chain"] = {"jobs": []} shared by ALL blocks of a model and
+    pair["flush"] = True on the block whose backward runs last (the model's first block): one reduction launch per 8 blocks."""
     params = (ln1.weight, ln1.bias, q.weight, q.bias, kv.weight, kv.bias)
     return _GPTBlockHead.apply(x, *params, float(ln1.eps), params, pair)
 

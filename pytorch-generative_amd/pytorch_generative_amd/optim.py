@@ -143,7 +143,9 @@ class FlatAdam(torch.optim.Optimizer):
         return self.state_block[_NORM]
 
     def zero_grad(self, set_to_none=False):
-        self.flat_grad.zero_()
+        # the library's own fill kernel (no ATen launch inside a captured step)
+        _lib.check(_lib.load().pg_fill(self.flat_grad.data_ptr(), 0.0, self.flat_grad.numel(),
+                                       torch.cuda.current_stream().cuda_stream), "pg_fill")
         for p in self._params:  # keep the views attached (autograd may have replaced them)
             if p.grad is not p._pg_grad:
                 p.grad = p._pg_grad
@@ -152,6 +154,9 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise ValueError("FlatAdam does not support closures")
+        from pytorch_generative_amd.ops import gpt_block as _gb
+
+        _gb.assert_no_pending_block_reductions()  # gradients parked in a deferred reduction must have reached the flat buffer
         if not all(p.requires_grad for p in self._params):
             raise RuntimeError("FlatAdam: a parameter was frozen after the optimizer was built; the flat "
                                "update covers every slice — rebuild FlatAdam over the trainable set")
