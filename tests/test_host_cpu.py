@@ -581,3 +581,54 @@ def test_bench_watchdog_aborts_a_rank_that_blocks():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode == 3, (p.returncode, p.stderr.decode()[-500:])
     assert b"did not finish within 1 s" in p.stderr and b"survived" not in p.stdout
+
+
+def test_ops_package_reexports_every_operator_name():
+    """Round 6 split ops.py into the package ops/ (one module per kernel family): every public operator and every helper the
+    tests / tools / nn modules reach through `ops.<name>` must still resolve on the package."""
+    from pytorch_generative_amd import ops
+
+    for name in ("conv2d_taps", "conv2d_pair", "ConvSpec", "causal_attention", "causal_attention_qkv", "set_deterministic",
+                 "gated_activation", "nchw_layernorm", "nchw_layernorm_skip", "image_positional_encoding", "mul_inplace_",
+                 "bce_with_logits_sum_mean", "dmol_loss_sum_mean", "elbo_terms", "gaussian_head_unit", "gaussian_head_pair",
+                 "avg_pool2", "upsample2_nearest", "phase_split", "phase_split4", "phase_merge", "phase_merge4", "phase_weights",
+                 "split_in_channels", "concat_elu", "concat_channels", "subsample2", "zero_insert2", "fanout", "sum_vectors",
+                 "zeros", "zeros_like", "gpt_block_head", "gpt_block_tail", "gpt_block_supported", "mlp_gelu", "RowDecode",
+                 "add", "add_broadcast_batch", "relu", "elu", "gelu", "merge_qkv_weight", "new_block_chain",
+                 "_use_mfma", "_pack_frag", "_adjacent_view", "_Act", "_ACT_IDS", "_sink", "_chk", "_dense_per_image",
+                 "ACT_NONE", "ACT_RELU", "ACT_ELU", "ACT_GELU", "ACT_ELU_OUT", "GATE_TANH", "GATE_IDENTITY",
+                 "CONV_FMT_B3", "FUSE_SKIP", "FUSE_PAIR", "FUSE_BLOCK", "DEFER_BLOCK_REDUCE"):
+        assert hasattr(ops, name), name
+    assert ops.conv2d_taps.__module__ == "pytorch_generative_amd.ops.conv"
+    assert ops.causal_attention.__module__ == "pytorch_generative_amd.ops.attention"
+
+
+def test_bench_reads_the_committed_counter_passes():
+    """bench.py's roofline fields that come from the tracked rocprofv3 --pmc passes (profiles/r06_*.json): bytes, source file,
+    matrix-pipe busy fraction, VALU instructions per MFMA, and the achieved HBM rate derived from a launch time."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    traffic, src, ctr = bench.measured_traffic(1024, "attn_bwd_m44_kernel", with_counters=True)
+    assert src == "profiles/r06_traffic.json" and 4.0e8 < traffic < 4.5e8
+    f = bench._counter_fields(traffic, ctr, 0.62)
+    assert 0.45 < f["mfma_busy_frac"] < 0.56 and 600 < f["hbm_gbps_achieved"] < 750 and f["valu_per_mfma"] > 1
+    t2, src2 = bench.measured_traffic(1024, "attn_bwd_m44_kernel")
+    assert (t2, src2) == (traffic, src)
+    assert bench.measured_traffic(7, "attn_bwd_m44_kernel", with_counters=True) == (None, None, None)
+    dom = bench._dominant_kernel("gated_pixel_cnn")
+    assert dom["source"] == "profiles/r06_gated_pixel_cnn_kernel_stats.csv" and dom["share_of_kernel_time"] > 0.4
+
+
+def test_deferred_block_reductions_must_be_flushed_before_a_step():
+    from pytorch_generative_amd import ops
+
+    chain = ops.new_block_chain()
+    ops.assert_no_pending_block_reductions()
+    chain["jobs"].append(("head_ws", "tail_ws", [0] * 14, None))
+    with pytest.raises(RuntimeError, match="never flushed"):
+        ops.assert_no_pending_block_reductions()
+    chain["jobs"].clear()
+    ops.assert_no_pending_block_reductions()
