@@ -104,6 +104,15 @@ int pg_conv2d_mfma_ex(const float* in, const float* wfrag, const float* bias, co
                       const int* tap_dr, const int* tap_dc, int in_act, const float* dact_src,
                       int dact, int out_act, int fmt, const float* res2, long res_bs, long res2_bs,
                       void* stream);
+/* Round 6: the convolution of a gated block together with its GatedActivation (+ residual) — nn/convolution.py:62-66 behind the
+ * 2C-channel convolution of pixel_snail.py:41-56: out (N, 128, OH, OW) = conv(in_act(in)) + bias is written as usual (the gate's
+ * backward, pg_gated_bwd, reads it) and gate_out (N, 64, OH, OW) = gate_res + act(out[:, :64]) * sigmoid(out[:, 64:]); gate_res may be
+ * NULL. Exactly 128 output channels on the bf16x3 format's wide kernel (the two 64-channel chunks of a workgroup are the gate's
+ * halves); pg_conv_gate_fusable() returns 1 for the shapes it takes. wfrag: pg_pack_conv_weight_frag(fmt = PG_CONV_FMT_B3). */
+int pg_conv_gate_fusable(int Cin, int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc);
+int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const float* bias, float* out, int N, int Cin, int IH, int IW,
+                        int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc, int in_act, int gate,
+                        const float* gate_res, float* gate_out, void* stream);
 /* Two arithmetic back ends share this entry point; they differ in the weight-fragment FORMAT:
  *   PG_CONV_FMT_F32: v_mfma_f32_16x16x4_f32 on fp32 fragments (csrc/conv_mfma.hip);
  *   PG_CONV_FMT_B3:  every fp32 product as six v_mfma_f32_16x16x32_bf16 on exact three-way bf16

@@ -224,6 +224,12 @@ size_t pg_b3_frag_floats(int Kc, int M, int T) {
   return (size_t)b3_chunks(M) * (Kc / pl.CIB) * pl.ksteps * pl.MT * 3 * 64 * 4;
 }
 
+int pg_b3_gate_fusable(int Cin, int Cout, int T, int OH, int OW, int hr, int hc) {
+  if (Cout != 2 * B3_CO_CHUNK || T < 2 || OW > 256 || OH * OW < 16) return 0;  // (one tap with <= 64 input channels runs without an x tile)
+  const B3Plan pl = b3_plan(Cin, Cout, T);
+  return pl.ok && !pl.pipelined && !pl.w9 && pl.MT == 4 && b3_rows(T, OH, OW, hr, hc, pl.px_cap) >= 1;
+}
+
 static int b3_pack_job(B3PackJob& p, float* wfrag, int Cout, int Cin, int T, int transpose) {
   p.wfrag = reinterpret_cast<unsigned int*>(wfrag);
   p.transpose = transpose;
@@ -260,11 +266,19 @@ int pg_b3_pack2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout, 
   return 0;
 }
 
+// gate != 0 (1 + PG_GATE_*; round 6): the launch must be the wide kernel's plain epilogue with Cout == 128 — it then also writes
+// gate_out = gate_res + act(a) * sigmoid(b) for [a | b] = out; pg_b3_gate_fusable() says beforehand whether a shape qualifies
+int pg_b3_gate_fusable(int Cin, int Cout, int T, int OH, int OW, int hr, int hc);
 int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const float* res, float* out,
                int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
                const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
-               const float* res2, long res_bs, long res2_bs, hipStream_t st) {
+               const float* res2, long res_bs, long res2_bs, hipStream_t st, int gate, const float* gate_res,
+               float* gate_out) {
   B3Args a;
+  a.gate = gate; a.gate_res = gate_res; a.gate_out = gate_out;
+  PG_REQUIRE(gate == 0 || (gate_out && !res && !res2 && !dact_src && out_act == PG_ACT_NONE &&
+                           (gate == 1 + PG_GATE_TANH || gate == 1 + PG_GATE_IDENTITY)), PG_EINVAL,
+             "pg_conv2d_mfma_gate: the fused gate takes no residual / derivative / output activation of the convolution itself");
   a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
   PG_REQUIRE(res2 == nullptr || res != nullptr, PG_EINVAL, "pg_conv2d_mfma(bf16x3): res2 without res");
   // the weight slabs are moved by LDS-DMA in 16-byte units (conv_b3_kernel, round 5)
@@ -306,7 +320,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     // backward): one stream, added twice
     const bool twice = res2 != nullptr && res2 == res && a.res2_bs == a.res_bs;
     const bool ms_pw = twice ? ((dact_src != nullptr) || a.res_bs != (long)Cout * OH * OW) : ms;
-    if (pw_on && (!ms_pw || pl.MT == 4) && T == 1 && pl.ksteps == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
+    if (pw_on && !gate && (!ms_pw || pl.MT == 4) && T == 1 && pl.ksteps == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
         (OH * OW) % 2 == 0 && (((uintptr_t)in) & 7) == 0 && wbytes <= 24 * 1024) {
       a.TR = 0; a.tile_h = a.tile_w = a.plane16 = a.tiles_per_img = 0;
       a.xslots = 0; a.dump16 = 0; a.w_off16 = 0;
@@ -327,7 +341,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
       if (gx < 1) gx = 1;
       const dim3 grid((unsigned)gx, (unsigned)chunks_y);
       if (twice) { a.res2 = nullptr; a.res_scale = 2.f; }
-      const B3Launch l = {1, pl.MT, 0, 1, ms_pw ? 1 : 0, 0, grid, shmem};
+      const B3Launch l = {1, pl.MT, 0, 1, ms_pw ? 1 : 0, 0, 0, grid, shmem};
       if (gelu) pg_b3_dispatch_gelu(a, l, st);
       else b3_dispatch<false>(a, l, st);
       PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, 1x1)");
@@ -352,6 +366,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.TR = TR; a.tile_h = TR + hr; a.tile_w = OW + hc;
   a.plane16 = ((a.tile_h * a.tile_w + 15) / 16) * 16;
   a.tiles_per_img = (OH + TR - 1) / TR;
+  PG_REQUIRE(!gate || (!pl.pipelined && !pl.w9 && pl.MT == 4 && Cout == 2 * B3_CO_CHUNK && !gelu), PG_ESHAPE,
+             "pg_conv2d_mfma_gate: the fused gate needs the wide bf16x3 kernel with exactly 128 output channels");
   if (pl.pipelined && a.tile_h * a.tile_w <= B3P_PX) {
     // ---- the pipelined kernel: LDS = x[2][3 pieces][plane16] | dump entry | w[2][768] | 4 x epilogue scratch | bias, taps
     for (int g = 0; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }
@@ -377,7 +393,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     long gx = (want / a.tiles_per_img) * a.tiles_per_img;
     if (gx > (long)N * a.tiles_per_img) gx = (long)N * a.tiles_per_img;
     const dim3 grid((unsigned)gx, (unsigned)chunks_y);
-    const B3Launch l = {2, 4, nt, p_waves, 0, 0, grid, shmem};
+    const B3Launch l = {2, 4, nt, p_waves, 0, 0, 0, grid, shmem};
     if (gelu) pg_b3_dispatch_gelu(a, l, st);
     else b3_dispatch<false>(a, l, st);
     PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, pipelined)");
@@ -403,7 +419,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     const long tail = (long)(NCH * B3_CO_CHUNK + B3_MAXG + 4) * 4 + 16 * 16 + 256;
     long cap = (160L * 1024 - 2L * NCH * B3Q_SLAB16 * 16 - tail) / ((long)NXT * 2 * pl.cgs * 48);
     cap = (cap / 16) * 16;
-    const bool q_shape = stm ? (T >= 6 && (Cin >= 256 || Cout >= 256)) : q_cg;
+    const bool q_shape = !gate && (stm ? (T >= 6 && (Cin >= 256 || Cout >= 256)) : q_cg);
     const int TRq = (q_on && q_shape && pl.MT == 4 && !pl.pipelined && cap >= 64) ? b3_rows(T, OH, OW, hr, hc, (int)cap) : 0;
     if (TRq >= 1) {
       const int th = TRq + hr, tw = OW + hc;
@@ -436,7 +452,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
         const long units = (stm ? (long)(N + 1) / 2 : (long)N) * a.tiles_per_img;  // ST: a workgroup takes images in pairs
         if (gx > units) gx = units;
         const dim3 grid((unsigned)gx, (unsigned)chunks_y);
-        const B3Launch l = {3, 4, xs, stm ? 1 : 0, 0, 0, grid, shmem};
+        const B3Launch l = {3, 4, xs, stm ? 1 : 0, 0, 0, 0, grid, shmem};
         if (gelu) pg_b3_dispatch_gelu(a, l, st);
         else b3_dispatch<false>(a, l, st);
         PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, overlapped)");
@@ -456,7 +472,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.w_off16 = (int)(((x16 + 1 + 15) / 16) * 16);
   // wide workgroups (two output chunks share one staged x tile): default; PG_CONV_B3_WIDE=0 for A/B
   static const bool wide_on = []() { const char* e = PG_AB_ENV("PG_CONV_B3_WIDE"); return !(e && e[0] == '0'); }();
-  const int CG = (wide_on && !pl.w9 && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0) ? 2 : 1;
+  const int CG = ((wide_on || gate) && !pl.w9 && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0) ? 2 : 1;
   size_t shmem = (size_t)a.w_off16 * 16 + pl.w_bytes * CG;
   a.ep_off = (int)(shmem / 4);
   shmem += (size_t)4 * CG * 16 * 68 * 4;
@@ -472,7 +488,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   dim3 grid((unsigned)gx, (unsigned)chunks_y);
   PG_REQUIRE(!ms || pl.MT == 4, PG_ESHAPE,
              "pg_conv2d_mfma_ex(bf16x3): the multi-stream epilogue is instantiated for >= 64 output channels");
-  const B3Launch l = {0, pl.MT, nt, CG, ms ? 1 : 0, pl.w9, grid, shmem};
+  PG_REQUIRE(!gate || (CG == 2 && !ms), PG_ESHAPE, "pg_conv2d_mfma_gate: not the wide kernel's plain epilogue");
+  const B3Launch l = {0, pl.MT, nt, CG, ms ? 1 : 0, pl.w9, gate ? 1 : 0, grid, shmem};
   if (gelu) pg_b3_dispatch_gelu(a, l, st);
   else b3_dispatch<false>(a, l, st);
   PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3)");

@@ -28,6 +28,12 @@ struct B3Args {
   int w_off16, b_off, ep_off, dump16;  // LDS offsets: weights (16-byte units), bias / epilogue scratch (floats), dump entry
   int xslots, wslab4;             // staging slots per step; float4 per step's weight slab
   int in_act, dact, out_act;
+  // fused GatedActivation (round 6, conv_b3_kernel<.., GT = true>: Cout == 128, the two 64-channel chunks of a workgroup are the
+  // gate's two halves): gate_out (N, 64, L) = gate_res + act(a) * sigmoid(b) with [a | b] = this convolution's output, which is
+  // still written to `out` (the gate's backward reads it). gate = 0: none, 1 + PG_GATE_*.
+  const float* gate_res;
+  float* gate_out;
+  int gate;
   int dbg;                        // ablation switches (PG_B3_DBG; -DPG_ABLATE builds only), 0 otherwise
   int g_tapoff[B3_MAXG];          // per group: tap offset in tile pixels
   int g_cg[B3_MAXG];              // per group: channel group of the chunk
@@ -57,6 +63,7 @@ struct B3Args {
 struct B3Launch {
   int pw;            // 3: conv_b3q_kernel (overlapped, 16 waves), 2: conv_b3p_kernel (pipelined, 4 taps), 1: conv_b3_pw_kernel, 0: conv_b3_kernel
   int MT, nt, CG, ms, w9;
+  int gate;          // the wide kernel's gate-fusing instantiation
   dim3 grid;
   size_t shmem;
 };
@@ -139,8 +146,14 @@ __device__ __forceinline__ void split8t(const float (&x)[8], u32x4& h, u32x4& m,
 // W9 ("wide weights"): 9 weight slots and 2 x slots per thread instead of 6 and 4 — the plan of a 3x3 with 64 output
 // channels (8-channel chunks: one channel group x 9 taps = 3 K steps, a 36 KB weight slab per step), which otherwise
 // does not fit the staging slots and runs on the fp32-MFMA kernel.
-template <bool GL, int MT, int NT, int CG, bool MS = false, bool W9 = false>
+// GT ("gate", round 6; CG = 2, plain epilogue only): the workgroup's two output chunks are the two halves [a | b] of a
+// GatedActivation input (Cout == 128: PixelSNAIL's ResidualBlock, pixel_snail.py:41-56) — after a 16-channel tile has been
+// transposed into the waves' scratch and stored, the wave pair of a pixel quarter reads EACH OTHER's scratch (raw tile + the
+// partner's bias) and writes y = res + act(a) * sigmoid(b) for half of the tiles each: the standalone gate kernel read [a | b]
+// back from HBM (2 of its 4 streams; 4.3 % of PixelSNAIL's step in round 5's table).
+template <bool GL, int MT, int NT, int CG, bool MS = false, bool W9 = false, bool GT = false>
 __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kernel(const B3Args a) {
+  static_assert(!GT || (CG == 2 && MT == 4 && !MS && !W9), "gate fusion: the wide kernel's plain epilogue");
   constexpr int THREADS = B3_THREADS * CG;
   constexpr int XS = W9 ? 2 : (CG == 1 ? B3_XS : (B3_XS + 1) / 2);  // the tile's slots over twice the threads
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -413,6 +426,32 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
         for (int m = 0; m < MT; ++m) {
           PG_B3_TILE_BODY(m)
           PG_B3_TILE_STORE(m)
+          if constexpr (GT) {
+            __syncthreads();  // every wave's scratch holds its RAW tile m (bias not yet added)
+            // tiles 0, 1 are gated by the a-wave (chunk 0), tiles 2, 3 by the b-wave (chunk 1) of the pixel quarter
+            if ((m < MT / 2) == (cgp == 0)) {
+              const float* epo = lds + a.ep_off + (wave_all ^ 4) * (16 * EPS);           // the partner's scratch
+              const float* blo = lds + a.b_off + (cgp ^ 1) * B3_CO_CHUNK + m * 16;       // ... and bias
+              float o[16], r[16];
+#pragma unroll
+              for (int c = 0; c < 16; ++c) o[c] = epo[c * EPS + lane] + blo[c];
+              const float* gres = a.gate_res + ((size_t)n_img * B3_CO_CHUNK + m * 16) * Lv;
+              float* gout = a.gate_out + ((size_t)n_img * B3_CO_CHUNK + m * 16) * Lv;
+#pragma unroll
+              for (int c = 0; c < 16; ++c) r[c] = a.gate_res ? (gres + (size_t)c * Lv)[lane_px] : 0.f;
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                const float av = cgp == 0 ? v[c] : o[c], bv = cgp == 0 ? o[c] : v[c];
+                const float f = a.gate == 1 + PG_GATE_TANH ? tanhf(av) : av;
+                r[c] += f * (1.f / (1.f + expf(-bv)));
+              }
+              if (sok) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) (gout + (size_t)c * Lv)[lane_px] = r[c];
+              }
+            }
+            __syncthreads();  // the partner may overwrite its scratch with the next tile
+          }
         }
       } else {
         if constexpr (MS) {
@@ -1336,17 +1375,17 @@ if constexpr (GL) {
 
 #include "conv_b3q_kernel.h"
 
-template <bool GL, int MT, int CG = 1, bool MS = false, bool W9 = false>
+template <bool GL, int MT, int CG = 1, bool MS = false, bool W9 = false, bool GT = false>
 void b3_launch(const B3Args& a, int nt, dim3 grid, size_t shmem, hipStream_t st) {
   // the LDS opt-in is set once per instantiation by a function-local static initialiser: thread-safe
   // (the library is entered from the main thread and from the autograd thread)
 #define PG_B3_L(NTV)                                                                                  \
   {                                                                                                   \
     static const hipError_t attr_##NTV = hipFuncSetAttribute(                                         \
-        reinterpret_cast<const void*>(conv_b3_kernel<GL, MT, NTV, CG, MS, W9>),                           \
+        reinterpret_cast<const void*>(conv_b3_kernel<GL, MT, NTV, CG, MS, W9, GT>),                       \
         hipFuncAttributeMaxDynamicSharedMemorySize, CG == 1 ? 80 * 1024 : 160 * 1024);                \
     (void)attr_##NTV;                                                                                 \
-    hipLaunchKernelGGL((conv_b3_kernel<GL, MT, NTV, CG, MS, W9>), grid, dim3(B3_THREADS * CG), shmem, st, a); \
+    hipLaunchKernelGGL((conv_b3_kernel<GL, MT, NTV, CG, MS, W9, GT>), grid, dim3(B3_THREADS * CG), shmem, st, a); \
   }
   switch (nt) {
     case 1: PG_B3_L(1) break;
@@ -1410,7 +1449,9 @@ void b3_dispatch(const B3Args& a, const B3Launch& l, hipStream_t st) {
   }
   if (l.CG == 2) {
     if (l.ms) b3_launch<GL, 4, 2, true>(a, l.nt, l.grid, l.shmem, st);
-    else b3_launch<GL, 4, 2>(a, l.nt, l.grid, l.shmem, st);
+    else if (l.gate) {
+      if constexpr (!GL) b3_launch<GL, 4, 2, false, false, true>(a, l.nt, l.grid, l.shmem, st);  // (no GELU variant: the host refuses)
+    } else b3_launch<GL, 4, 2>(a, l.nt, l.grid, l.shmem, st);
     return;
   }
   if (l.w9) {

@@ -485,7 +485,9 @@ int pg_b3_pack2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout, 
 int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const float* res, float* out,
                int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
                const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
-               const float* res2, long res_bs, long res2_bs, hipStream_t st);
+               const float* res2, long res_bs, long res2_bs, hipStream_t st, int gate = 0, const float* gate_res = nullptr,
+               float* gate_out = nullptr);
+int pg_b3_gate_fusable(int Cin, int Cout, int T, int OH, int OW, int hr, int hc);
 
 // Geometry of one fp32-MFMA launch: pixel tile, channel chunk, LDS layout. Needs a.N / Cin / IW / Cout / OH / OW / T; hr / hc = row /
 // column extent of the tap list. Shared by the launch (pg_conv2d_mfma_ex) and by the routing query (pg_conv_mfma_supported), so that
@@ -633,6 +635,34 @@ PG_EXPORT int pg_pack_conv_weight_frag(const float* w, float* wfrag, int Cout, i
                                        int transpose, int fmt, void* stream) {
   return pg_pack_conv_weight_frag2(w, transpose ? nullptr : wfrag, transpose ? wfrag : nullptr, Cout,
                                    Cin, KH, KW, T, tap_u, tap_v, fmt, fmt, stream);
+}
+
+// Round 6: convolution + GatedActivation (+ the block's residual) in one launch — nn/convolution.py:62-66 behind a 2C-channel
+// convolution, pixel_snail.py:41-56. out (N, 128, OH, OW) = the convolution (kept: the gate's backward reads it), gate_out
+// (N, 64, OH, OW) = gate_res + act(out[:, :64]) * sigmoid(out[:, 64:]) (gate_res may be NULL).
+PG_EXPORT int pg_conv_gate_fusable(int Cin, int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc) {
+  if (!tap_dr || !tap_dc || T < 1 || T > PG_MAX_TAPS) return 0;
+  int a0 = tap_dr[0], a1 = tap_dr[0], b0 = tap_dc[0], b1 = tap_dc[0];
+  for (int t = 1; t < T; ++t) {
+    a0 = tap_dr[t] < a0 ? tap_dr[t] : a0; a1 = tap_dr[t] > a1 ? tap_dr[t] : a1;
+    b0 = tap_dc[t] < b0 ? tap_dc[t] : b0; b1 = tap_dc[t] > b1 ? tap_dc[t] : b1;
+  }
+  return pg_b3_gate_fusable(Cin, Cout, T, OH, OW, a1 - a0, b1 - b0);
+}
+
+PG_EXPORT int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const float* bias, float* out, int N, int Cin, int IH,
+                                  int IW, int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc, int in_act,
+                                  int gate, const float* gate_res, float* gate_out, void* stream) {
+  PG_REQUIRE(in && wfrag && out && gate_out && tap_dr && tap_dc, PG_EINVAL, "pg_conv2d_mfma_gate: null pointer");
+  PG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, PG_EINVAL,
+             "pg_conv2d_mfma_gate: non-positive dimension");
+  PG_REQUIRE(T >= 1 && T <= PG_MAX_TAPS, PG_ESHAPE, "pg_conv2d_mfma_gate: T=%d not in [1,%d]", T, PG_MAX_TAPS);
+  PG_REQUIRE(in_act >= PG_ACT_NONE && in_act < PG_ACT_GELU, PG_EINVAL, "pg_conv2d_mfma_gate: bad input activation (none / relu / elu)");
+  PG_REQUIRE(gate == PG_GATE_TANH || gate == PG_GATE_IDENTITY, PG_EINVAL, "pg_conv2d_mfma_gate: bad gate id");
+  PG_REQUIRE(pg_conv_gate_fusable(Cin, Cout, OH, OW, T, tap_dr, tap_dc), PG_ESHAPE,
+             "pg_conv2d_mfma_gate: shape not covered (pg_conv_gate_fusable)");
+  return pg_b3_conv(in, wfrag, bias, nullptr, out, N, Cin, IH, IW, Cout, OH, OW, T, tap_dr, tap_dc, in_act, nullptr, PG_ACT_NONE,
+                    PG_ACT_NONE, nullptr, 0, 0, (hipStream_t)stream, 1 + gate, gate_res, gate_out);
 }
 
 PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* bias,

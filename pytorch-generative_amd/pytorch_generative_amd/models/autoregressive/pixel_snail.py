@@ -44,6 +44,11 @@ class ResidualBlock(nn.Module):
             # stored output) in the second convolution's data-gradient epilogue
             out, *xs = self._input_conv(x, crop=(h, w), in_act="elu", out_act="elu", out_pre_scaled=True,
                                         n_skip=k)
+            if self._output_conv.gate_ok(out, (h, w)):
+                # round 6: the gate and the block's residual add in the second convolution's launch (the wide kernel's two
+                # 64-channel chunks are the gate's halves): the standalone gate kernel read the 128-channel output back
+                y = self._output_conv(out, crop=(h, w), in_post="elu", gate=self._activation._gate, gate_res=xs[0])
+                return (y, xs[1]) if extra_skip else y
             out = self._output_conv(out, crop=(h, w), in_post="elu")
         else:
             out, *xs = self._input_conv(x, crop=(h, w), in_act="elu", n_skip=k)

@@ -124,10 +124,22 @@ class Conv2d(nn.Conv2d):
         return ops.conv2d_taps(xb, wb, self.bias, spec, in_act=_ACTS[in_act], res=h, bias_param=self.bias,
                                n_skip=1 if skip_b else 0)
 
+    def gate_ok(self, x, crop=None):
+        """True if forward(..., gate=...) can run this convolution's GatedActivation in the same launch (ops.conv_gate_ok)."""
+        return (not self._down2) and ops.RowDecode.current is None and ops.conv_gate_ok(x, self.weight, self._conv_spec(), crop)
+
     def forward(self, x, *, crop=None, in_act=None, res=None, out_act=None, out_pre_scaled=False,
-                in_post=None, n_skip=0, res2=None):
+                in_post=None, n_skip=0, res2=None, gate=None, gate_res=None):
         """n_skip > 0 (extension) returns (y, x_1, .., x_n): pass-through aliases of x for the skip
-        connections that also read x, see ops.conv2d_taps."""
+        connections that also read x, see ops.conv2d_taps.
+        gate = ops.GATE_TANH / GATE_IDENTITY (extension, round 6; only where gate_ok()): returns the GatedActivation of this
+        convolution's output (+ gate_res) — half the channels — from the same launch."""
+        if gate is not None:
+            if res is not None or res2 is not None or out_act is not None or out_pre_scaled or not self.gate_ok(x, crop):
+                raise ValueError("Conv2d: gate= needs a plain convolution on a shape gate_ok() accepts")
+            return ops.conv2d_taps(x, self.weight, self.bias, self._conv_spec(), out_hw=crop, in_act=_ACTS[in_act],
+                                   weight_param=self.weight, bias_param=self.bias, in_post=_ACTS[in_post], n_skip=n_skip,
+                                   gate=gate, gate_res=gate_res)
         if res2 is not None and not self.two_residuals_ok(x, crop):
             y = self.forward(x, crop=crop, in_act=in_act, res=res, out_act=out_act,
                              out_pre_scaled=out_pre_scaled, in_post=in_post, n_skip=n_skip)
@@ -288,7 +300,9 @@ class GatedConv(nn.Module):
 
     mask_center: None = plain convolution, True / False = CausalConv2d of type A / B.
     forward(x, crop=, in_act=, res=): `crop` / `in_act` as Conv2d.forward; `res` is added to the gated output in
-    the gate kernel.
+    the gate kernel. Where the convolution has 128 output channels on the wide bf16x3 kernel (Conv2d.gate_ok: PixelSNAIL's
+    ResidualBlock) the gate and `res` run in the convolution's own epilogue — one launch, the 128-channel pre-gate tensor is
+    written once for backward and never read back in forward.
     """
 
     def __init__(self, in_channels, out_channels, kernel_size=1, padding=0, mask_center=None,
@@ -302,6 +316,8 @@ class GatedConv(nn.Module):
         self.gate = GatedActivation(activation_fn)
 
     def forward(self, x, *, crop=None, in_act=None, res=None):
+        if self.conv.gate_ok(x, crop):
+            return self.conv(x, crop=crop, in_act=in_act, gate=self.gate._gate, gate_res=res)
         return self.gate(self.conv(x, crop=crop, in_act=in_act), res=res)
 
 

@@ -73,6 +73,8 @@ from pytorch_generative_amd.ops.conv import (  # noqa: F401
     conv_mfma_ok,
     conv_two_residuals_ok,
     conv2d_taps,
+    conv_gate_ok,
+    FUSE_GATE,
 )
 from pytorch_generative_amd.ops.gpt_block import (  # noqa: F401
     FUSE_MLP,

@@ -127,8 +127,9 @@ def _pack(lib, weight, spec, transpose):
 class _ConvTaps(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, res, spec, out_hw, in_act, gw, gb, out_act=ACT_NONE,
-                out_pre_scaled=False, in_post=ACT_NONE, n_skip=0, res2=None):
+                out_pre_scaled=False, in_post=ACT_NONE, n_skip=0, res2=None, gate=None, gate_res=None):
         lib = _lib.load()
+        ctx.gate = gate
         x = _chk(x, "conv2d.x")
         weight = _chk(weight, "conv2d.weight")
         n, cin, ih, iw = x.shape
@@ -163,6 +164,37 @@ class _ConvTaps(torch.autograd.Function):
             raise ValueError("conv2d: fused output activations need the matrix-core path "
                              "(check ops.conv_mfma_ok first)")
         ctx.wfrag_t = None
+        if gate is not None:
+            # GatedActivation (+ the residual behind it) in the convolution's epilogue: `out` keeps the pre-gate values for
+            # backward, y is what the caller sees
+            if mfma != CONV_FMT_B3 or res is not None or res2 is not None or out_act != ACT_NONE:
+                raise ValueError("conv2d: gate= needs a plain bf16x3 convolution (check ops.conv_gate_ok first)")
+            if gate_res is not None:
+                gate_res = _chk(gate_res, "conv2d.gate_res")
+                if tuple(gate_res.shape) != (n, cout // 2, oh, ow):
+                    raise ValueError("conv2d: gate_res shape mismatch")
+            fmt_t = _use_mfma(lib, cout, cin, spec, (ih, iw), ow) if ctx.needs_input_grad[0] else 0
+            if fmt_t:
+                wfrag, ctx.wfrag_t = _pack_frag_both(lib, weight, spec, mfma, fmt_t)
+            else:
+                wfrag = _pack_frag(lib, weight, spec, False, mfma)
+            y = torch.empty((n, cout // 2, oh, ow), device=x.device, dtype=torch.float32)
+            _lib.check(
+                lib.pg_conv2d_mfma_gate(
+                    x.data_ptr(), wfrag.data_ptr(), _p(bias), out.data_ptr(), n, cin, ih, iw, cout, oh, ow,
+                    len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, gate, _p(gate_res), y.data_ptr(), _stream(),
+                ),
+                "pg_conv2d_mfma_gate",
+            )
+            ctx.save_for_backward(x, weight, out)
+            ctx.spec, ctx.in_act, ctx.has_bias, ctx.has_res, ctx.has_res2 = spec, in_act, bias is not None, False, False
+            ctx.has_gate_res = gate_res is not None
+            ctx.gw, ctx.gb = gw, gb
+            ctx.out_act, ctx.out_pre_scaled, ctx.in_post = ACT_NONE, False, in_post
+            ctx.n_skip = n_skip
+            if n_skip:
+                return (y,) + tuple(x.view_as(x) for _ in range(n_skip))
+            return y
         if mfma:
             fmt_t = _use_mfma(lib, cout, cin, spec, (ih, iw), ow) if ctx.needs_input_grad[0] else 0
             if fmt_t:
@@ -206,9 +238,22 @@ class _ConvTaps(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *d_skips):
         need = ctx.needs_input_grad
+        d_gate_res = None
+        if ctx.gate is not None:
+            # through the gate first: dz (both halves) from the stored pre-gate output, then the usual data / weight gradients
+            lib = _lib.load()
+            z = ctx.saved_tensors[2]
+            dy = _chk(dy, "conv2d.dy")
+            nz, c2, hz, wz = z.shape
+            dz = torch.empty_like(z)
+            _lib.check(lib.pg_gated_bwd(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), nz, c2 // 2, hz * wz, ctx.gate,
+                                        _stream()), "pg_gated_bwd")
+            d_gate_res = dy if ctx.has_gate_res else None
+            dy = dz
         return _ConvTaps.backward_impl(ctx, dy, need[0], need[1], ctx.has_bias and need[2],
                                        d_skips=d_skips) + (None, None, None, None,
-                                                           dy if getattr(ctx, "has_res2", False) else None)
+                                                           dy if getattr(ctx, "has_res2", False) else None,
+                                                           None, d_gate_res)
 
     @staticmethod
     def backward_impl(ctx, dy, need_dx, need_w, need_b, d_skips=()):
@@ -411,7 +456,7 @@ def conv_two_residuals_ok(x, weight, spec, out_hw=None):
 
 def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
                 weight_param=None, bias_param=None, out_act=ACT_NONE, out_pre_scaled=False,
-                in_post=ACT_NONE, n_skip=0, res2=None):
+                in_post=ACT_NONE, n_skip=0, res2=None, gate=None, gate_res=None):
     """y = out_act(conv(in_act(x)) + bias) (+ res), cropped to out_hw (defaults to the full extent).
 
     out_act (matrix-core path only): activation fused into the epilogue; its backward recovers act'
@@ -432,8 +477,24 @@ def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
         raise ValueError(f"conv2d: requested output {out_hw} exceeds the full extent {full}")
     if n_skip and not FUSE_SKIP:
         y = _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act, _sink(weight_param),
-                            _sink(bias_param), out_act, bool(out_pre_scaled), in_post, 0, res2)
+                            _sink(bias_param), out_act, bool(out_pre_scaled), in_post, 0, res2, gate, gate_res)
         return (y,) + (x,) * int(n_skip)
     return _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act,
                            _sink(weight_param), _sink(bias_param), out_act, bool(out_pre_scaled),
-                           in_post, int(n_skip), res2)
+                           in_post, int(n_skip), res2, gate, gate_res)
+
+
+FUSE_GATE = os.environ.get("PG_FUSE_GATE", "1") != "0"  # A/B: 0 = the standalone gate kernel behind the convolution
+
+
+def conv_gate_ok(x, weight, spec, out_hw=None):
+    """True if conv2d_taps(..., gate=...) can fuse the GatedActivation that follows this convolution into its launch
+    (pg_conv_gate_fusable: bf16x3 format, exactly 128 output channels, at least two taps)."""
+    if not FUSE_GATE or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    lib = _lib.load()
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    oh, ow = out_hw if out_hw is not None else spec.full_out(x.shape[2], x.shape[3])
+    if _use_mfma(lib, cin, cout, spec, (oh, ow), x.shape[3]) != CONV_FMT_B3:
+        return False
+    return bool(lib.pg_conv_gate_fusable(cin, cout, oh, ow, len(spec.fwd_taps), spec.f_dr, spec.f_dc))

@@ -553,7 +553,12 @@ GATED_CONV_CASES = [
     (2, 128, 16, 16, 128, 3, 1, False, "tanh", None, False),     # GatedPixelCNN-style masked stack (type B)
     (2, 16, 12, 12, 8, 3, 1, True, "tanh", None, False),         # type A, narrow: fp32-MFMA / VALU kernels
     (2, 64, 28, 28, 32, 1, 0, None, "tanh", "relu", True),       # 1x1
+    # round 6: 128 output channels on the wide kernel = the gate (and res) in the convolution's epilogue (Conv2d.gate_ok)
+    (1, 64, 28, 28, 64, 2, 1, None, "identity", "elu", False),   # batch 1, no residual, 28 wide (ragged pixel tiles)
+    (5, 32, 12, 12, 64, 3, 1, False, "tanh", None, True),        # masked type B: 5 taps, tanh gate, several images per tile
+    (2, 128, 9, 11, 64, 3, 1, True, "tanh", "relu", True),       # type A: 4 taps, odd sizes
 ]
+FUSED_GATE_CASES = {0, 4, 5, 6}  # indices of GATED_CONV_CASES the fused epilogue must take (asserted: a routing change is a finding)
 
 
 @pytest.mark.parametrize("case", GATED_CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
@@ -581,12 +586,46 @@ def test_gated_conv(dev, case):
     yo.backward(g)
     m = m.to(dev)
     xg = x.to(dev).requires_grad_(True)
-    yg = m(xg, crop=(h, w), in_act=in_act, res=None if res is None else res.to(dev))
+    assert m.conv.gate_ok(xg, (h, w)) == (GATED_CONV_CASES.index(case) in FUSED_GATE_CASES)
+    rg = None if res is None else res.to(dev).requires_grad_(True)
+    yg = m(xg, crop=(h, w), in_act=in_act, res=rg)
     _util.assert_close(yg, yo, TOL, "gated conv")
     yg.backward(g.to(dev))
     _util.assert_close(xg.grad, xo.grad, TOL, "dx")
     _util.assert_close(m.conv.weight.grad, wo.grad, TOL, "dw")
     _util.assert_close(m.conv.bias.grad, bo.grad, TOL, "db")
+    if rg is not None:
+        assert torch.equal(rg.grad.cpu(), g), "the residual's gradient is dy itself"
+
+
+@pytest.mark.parametrize("case", [GATED_CONV_CASES[i] for i in sorted(FUSED_GATE_CASES)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_gated_conv_fused_gate_equals_separate_kernels(dev, case, monkeypatch):
+    """The gate in the convolution's epilogue against the same convolution followed by the standalone gate kernel (PG_FUSE_GATE=0):
+    same accumulators, so output and every gradient agree to rounding of the sigmoid (1e-6), and the pre-gate tensor kept for
+    backward is bit-identical to the unfused convolution's output."""
+    from torch import nn as tnn
+
+    from pytorch_generative_amd import nn as pg_nn
+    from pytorch_generative_amd.ops import conv as ops_conv
+
+    n, cin, h, w, cout, k, pad, mc, kind, in_act, use_res = case
+    torch.manual_seed(0)
+    fn = torch.tanh if kind == "tanh" else tnn.Identity()
+    m = pg_nn.GatedConv(cin, cout, k, padding=pad, mask_center=mc, activation_fn=fn).to(dev)
+    x, g = _rand(n, cin, h, w, seed=1).to(dev), _rand(n, cout, h, w, seed=2).to(dev)
+    res = _rand(n, cout, h, w, seed=3).to(dev) if use_res else None
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops_conv, "FUSE_GATE", fused)
+        m.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        assert m.conv.gate_ok(xg, (h, w)) == fused
+        y = m(xg, crop=(h, w), in_act=in_act, res=res)
+        y.backward(g)
+        got[fused] = (y.detach(), xg.grad, m.conv.weight.grad.clone(), m.conv.bias.grad.clone())
+    for a, b, what in zip(got[True], got[False], ("y", "dx", "dw", "db")):
+        _util.assert_close(a, b.cpu(), 2e-6, what)
 
 
 def test_add_and_broadcast_add(dev):
