@@ -108,7 +108,7 @@ int pg_conv2d_mfma_ex(const float* in, const float* wfrag, const float* bias, co
  * 2C-channel convolution of pixel_snail.py:41-56: out (N, 128, OH, OW) = conv(in_act(in)) + bias is written as usual (the gate's
  * backward, pg_gated_bwd, reads it) and gate_out (N, 64, OH, OW) = gate_res + act(out[:, :64]) * sigmoid(out[:, 64:]); gate_res may be
  * NULL. Exactly 128 output channels on the bf16x3 format's wide kernel (the two 64-channel chunks of a workgroup are the gate's
- * halves); pg_conv_gate_fusable() returns 1 for the shapes it takes. wfrag: pg_pack_conv_weight_frag(fmt = PG_CONV_FMT_B3). */
+ * halves); pg_conv_gate_fusable() returns 1 for the shapes it takes. wfrag: pg_pack_conv_weight_frag(fmt = PG_CONV_FMT_B3_GATE). */
 int pg_conv_gate_fusable(int Cin, int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc);
 int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const float* bias, float* out, int N, int Cin, int IH, int IW,
                         int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc, int in_act, int gate,
@@ -121,6 +121,10 @@ int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const float* bias, 
  * input rows of IW, tap-list extent hr x hc) problem, or 0 (call pg_conv2d_taps instead). */
 #define PG_CONV_FMT_F32 1
 #define PG_CONV_FMT_B3 2
+/* pack-only (forward orientation, Cout == 128): PG_CONV_FMT_B3 fragments with the output channels ordered so that each 64-channel
+ * chunk holds 32 gate channels' two halves — tile m of chunk c = channels 64 (m >> 1) + 32 c + 16 (m & 1) + 0..15. The format
+ * pg_conv2d_mfma_gate reads (one wave then owns both operands of its gate channels); `out` is still written in natural order. */
+#define PG_CONV_FMT_B3_GATE 3
 int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, int IW, int hr, int hc);
 /* floats pg_pack_conv_weight_frag writes for K_channels contracted into M_channels over T taps */
 size_t pg_conv_frag_floats(int K_channels, int M_channels, int T, int fmt);

@@ -35,6 +35,8 @@ namespace {
 struct B3PackJob {
   unsigned int* wfrag;
   int transpose, M, Kc, MT, chunks, CIB, cgs, groups, ksteps, nchunk;
+  int gate_order;  // PG_CONV_FMT_B3_GATE (M == 128): m-tile m of chunk c holds channels 64 (m >> 1) + 32 c + 16 (m & 1) + ..,
+                   // i.e. each chunk = 32 gate channels' [a | b] halves (conv_b3_kernel<.., GT = true> gates inside one wave)
   long total;  // lanes (pieces inside)
 };
 
@@ -58,7 +60,8 @@ __global__ void b3_pack_kernel(const B3PackArgs a) {
     const int ks = (int)(rest % p.ksteps); rest /= p.ksteps;
     const int j = (int)(rest % p.nchunk);
     const int chunk = (int)(rest / p.nchunk);
-    const int o = chunk * B3_CO_CHUNK + m * 16 + (lane & 15);
+    const int o = p.gate_order ? (m >> 1) * B3_CO_CHUNK + chunk * 32 + (m & 1) * 16 + (lane & 15)
+                               : chunk * B3_CO_CHUNK + m * 16 + (lane & 15);
     const int g = 4 * ks + (lane >> 4);
     float x[8];
 #pragma unroll
@@ -230,9 +233,12 @@ int pg_b3_gate_fusable(int Cin, int Cout, int T, int OH, int OW, int hr, int hc)
   return pl.ok && !pl.pipelined && !pl.w9 && pl.MT == 4 && b3_rows(T, OH, OW, hr, hc, pl.px_cap) >= 1;
 }
 
-static int b3_pack_job(B3PackJob& p, float* wfrag, int Cout, int Cin, int T, int transpose) {
+static int b3_pack_job(B3PackJob& p, float* wfrag, int Cout, int Cin, int T, int transpose, int gate_order = 0) {
   p.wfrag = reinterpret_cast<unsigned int*>(wfrag);
   p.transpose = transpose;
+  p.gate_order = gate_order;
+  PG_REQUIRE(!gate_order || (!transpose && Cout == 2 * B3_CO_CHUNK), PG_ESHAPE,
+             "pg_pack_conv_weight_frag: the gate-interleaved order is for forward fragments with 128 output channels");
   p.M = transpose ? Cin : Cout;
   p.Kc = transpose ? Cout : Cin;
   const B3Plan pl = b3_plan(p.Kc, p.M, T);
@@ -245,11 +251,11 @@ static int b3_pack_job(B3PackJob& p, float* wfrag, int Cout, int Cin, int T, int
 
 // either destination may be null (then only the other orientation is packed)
 int pg_b3_pack2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout, int Cin, int KH, int KW,
-                int T, const int* tap_u, const int* tap_v, hipStream_t st) {
+                int T, const int* tap_u, const int* tap_v, hipStream_t st, int gate_order) {
   B3PackArgs a;
   a.w = w; a.Cout = Cout; a.Cin = Cin; a.KH = KH; a.KW = KW; a.T = T; a.njobs = 0;
   if (wfrag_fwd) {
-    const int rc = b3_pack_job(a.job[a.njobs++], wfrag_fwd, Cout, Cin, T, 0);
+    const int rc = b3_pack_job(a.job[a.njobs++], wfrag_fwd, Cout, Cin, T, 0, gate_order);
     if (rc) return rc;
   }
   if (wfrag_dgrad) {

@@ -146,11 +146,12 @@ __device__ __forceinline__ void split8t(const float (&x)[8], u32x4& h, u32x4& m,
 // W9 ("wide weights"): 9 weight slots and 2 x slots per thread instead of 6 and 4 — the plan of a 3x3 with 64 output
 // channels (8-channel chunks: one channel group x 9 taps = 3 K steps, a 36 KB weight slab per step), which otherwise
 // does not fit the staging slots and runs on the fp32-MFMA kernel.
-// GT ("gate", round 6; CG = 2, plain epilogue only): the workgroup's two output chunks are the two halves [a | b] of a
-// GatedActivation input (Cout == 128: PixelSNAIL's ResidualBlock, pixel_snail.py:41-56) — after a 16-channel tile has been
-// transposed into the waves' scratch and stored, the wave pair of a pixel quarter reads EACH OTHER's scratch (raw tile + the
-// partner's bias) and writes y = res + act(a) * sigmoid(b) for half of the tiles each: the standalone gate kernel read [a | b]
-// back from HBM (2 of its 4 streams; 4.3 % of PixelSNAIL's step in round 5's table).
+// GT ("gate", round 6; CG = 2, Cout == 128): convolution + GatedActivation (+ residual) of PixelSNAIL's ResidualBlock
+// (pixel_snail.py:41-56) in one launch. The fragments come in the gate-interleaved order (PG_CONV_FMT_B3_GATE): each chunk = the
+// [a | b] halves of 32 gate channels, so a wave holds both operands of its gate channels in its own accumulators and writes
+// z (natural order, for backward) and y = res + act(a) * sigmoid(b) from the same transposed tiles. (A first version kept the natural
+// order and exchanged tiles between the two waves of a pixel quarter through their scratch, two barriers per tile: +0.7 % on
+// PixelSNAIL instead of the gate kernel's 4.3 % — with one workgroup per CU every barrier behind a global load idles the CU.)
 template <bool GL, int MT, int NT, int CG, bool MS = false, bool W9 = false, bool GT = false>
 __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kernel(const B3Args a) {
   static_assert(!GT || (CG == 2 && MT == 4 && !MS && !W9), "gate fusion: the wide kernel's plain epilogue");
@@ -421,37 +422,45 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
       }                                                                       \
     }                                                                         \
   }
-      if (!has_res && !has_ds) {
+      if constexpr (GT) {
+        // Gate-interleaved fragments (PG_CONV_FMT_B3_GATE): tile m of this wave's chunk holds z channels
+        // 64 (m >> 1) + 32 cgp + 16 (m & 1) + 0..15 — tiles h and 2 + h are the [a | b] halves of gate channels 32 cgp + 16 h + 0..15,
+        // so the gate needs no exchange between waves. z goes out in its natural channel order (backward reads it), y beside it.
+        float* zb = a.out + (size_t)n_img * a.Cout * Lv;
+        const size_t go = (size_t)n_img * B3_CO_CHUNK * Lv;
+        const float* ball = lds + a.b_off;
+#define PG_B3_TILE_T(M, V, CH0)                                                                  \
+  _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[M][n][r]; \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+  _Pragma("unroll") for (int c = 0; c < 16; ++c) V[c] = ep[c * EPS + lane] + ball[(CH0) + c];    \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+  if (sok) { _Pragma("unroll") for (int c = 0; c < 16; ++c) (zb + (size_t)((CH0) + c) * Lv)[lane_px] = V[c]; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int gc0 = cgp * 32 + h * 16;  // uniform
+          float r[16], va[16], vb[16];
+          // the residual's loads first: they are in flight over both transpositions
+#pragma unroll
+          for (int c = 0; c < 16; ++c) r[c] = (a.gate_res && sok) ? (a.gate_res + go + (size_t)(gc0 + c) * Lv)[lane_px] : 0.f;
+          PG_B3_TILE_T(h, va, gc0)
+          PG_B3_TILE_T(2 + h, vb, B3_CO_CHUNK + gc0)
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            const float f = a.gate == 1 + PG_GATE_TANH ? tanhf(va[c]) : va[c];
+            r[c] += f * (1.f / (1.f + expf(-vb[c])));
+          }
+          if (sok) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) (a.gate_out + go + (size_t)(gc0 + c) * Lv)[lane_px] = r[c];
+          }
+        }
+#undef PG_B3_TILE_T
+      } else if (!has_res && !has_ds) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           PG_B3_TILE_BODY(m)
           PG_B3_TILE_STORE(m)
-          if constexpr (GT) {
-            __syncthreads();  // every wave's scratch holds its RAW tile m (bias not yet added)
-            // tiles 0, 1 are gated by the a-wave (chunk 0), tiles 2, 3 by the b-wave (chunk 1) of the pixel quarter
-            if ((m < MT / 2) == (cgp == 0)) {
-              const float* epo = lds + a.ep_off + (wave_all ^ 4) * (16 * EPS);           // the partner's scratch
-              const float* blo = lds + a.b_off + (cgp ^ 1) * B3_CO_CHUNK + m * 16;       // ... and bias
-              float o[16], r[16];
-#pragma unroll
-              for (int c = 0; c < 16; ++c) o[c] = epo[c * EPS + lane] + blo[c];
-              const float* gres = a.gate_res + ((size_t)n_img * B3_CO_CHUNK + m * 16) * Lv;
-              float* gout = a.gate_out + ((size_t)n_img * B3_CO_CHUNK + m * 16) * Lv;
-#pragma unroll
-              for (int c = 0; c < 16; ++c) r[c] = a.gate_res ? (gres + (size_t)c * Lv)[lane_px] : 0.f;
-#pragma unroll
-              for (int c = 0; c < 16; ++c) {
-                const float av = cgp == 0 ? v[c] : o[c], bv = cgp == 0 ? o[c] : v[c];
-                const float f = a.gate == 1 + PG_GATE_TANH ? tanhf(av) : av;
-                r[c] += f * (1.f / (1.f + expf(-bv)));
-              }
-              if (sok) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) (gout + (size_t)c * Lv)[lane_px] = r[c];
-              }
-            }
-            __syncthreads();  // the partner may overwrite its scratch with the next tile
-          }
         }
       } else {
         if constexpr (MS) {

@@ -481,7 +481,7 @@ static void mf_pack_job(FragPackJob& j, float* wfrag, int Cout, int Cin, int T, 
 int pg_b3_applicable(int Kc, int M, int T, int OH, int OW, int hr, int hc);
 size_t pg_b3_frag_floats(int Kc, int M, int T);
 int pg_b3_pack2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout, int Cin, int KH, int KW,
-                int T, const int* tap_u, const int* tap_v, hipStream_t st);
+                int T, const int* tap_u, const int* tap_v, hipStream_t st, int gate_order = 0);
 int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const float* res, float* out,
                int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
                const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
@@ -584,7 +584,7 @@ PG_EXPORT int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, i
 }
 
 PG_EXPORT size_t pg_conv_frag_floats(int K_channels, int M_channels, int T, int fmt) {
-  if (fmt == PG_CONV_FMT_B3) return pg_b3_frag_floats(K_channels, M_channels, T);
+  if (fmt == PG_CONV_FMT_B3 || fmt == PG_CONV_FMT_B3_GATE) return pg_b3_frag_floats(K_channels, M_channels, T);
   const size_t KQ = (size_t)((K_channels + 3) / 4) * T;
   return (size_t)mf_chunks(M_channels) * KQ * mf_mt(M_channels) * 64;
 }
@@ -601,10 +601,11 @@ PG_EXPORT int pg_pack_conv_weight_frag2(const float* w, float* wfrag_fwd, float*
                "pg_pack_conv_weight_frag: tap %d (%d,%d) outside %dx%d", t, tap_u[t], tap_v[t], KH, KW);
   hipStream_t st = (hipStream_t)stream;
   {
-    float* b3_fwd = (wfrag_fwd && fmt_fwd == PG_CONV_FMT_B3) ? wfrag_fwd : nullptr;
+    const bool gate_order = wfrag_fwd && fmt_fwd == PG_CONV_FMT_B3_GATE;  // pg_conv2d_mfma_gate's forward fragments
+    float* b3_fwd = (wfrag_fwd && (fmt_fwd == PG_CONV_FMT_B3 || gate_order)) ? wfrag_fwd : nullptr;
     float* b3_dgrad = (wfrag_dgrad && fmt_dgrad == PG_CONV_FMT_B3) ? wfrag_dgrad : nullptr;
     if (b3_fwd || b3_dgrad) {  // both orientations in one launch
-      const int rc = pg_b3_pack2(w, b3_fwd, b3_dgrad, Cout, Cin, KH, KW, T, tap_u, tap_v, st);
+      const int rc = pg_b3_pack2(w, b3_fwd, b3_dgrad, Cout, Cin, KH, KW, T, tap_u, tap_v, st, gate_order);
       if (rc) return rc;
       if (b3_fwd) wfrag_fwd = nullptr;
       if (b3_dgrad) wfrag_dgrad = nullptr;

@@ -31,6 +31,7 @@ from pytorch_generative_amd.ops._common import (  # noqa: F401
     _sink,
     CONV_FMT_F32,
     CONV_FMT_B3,
+    CONV_FMT_B3_GATE,
     FUSE_SKIP,
     _dense_per_image,
 )

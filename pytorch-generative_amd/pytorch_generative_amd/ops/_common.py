@@ -82,7 +82,7 @@ def _sink(param):
     return getattr(param, "_pg_grad", None) if param is not None else None
 
 
-CONV_FMT_F32, CONV_FMT_B3 = 1, 2  # include/pg_hip.h PG_CONV_FMT_*
+CONV_FMT_F32, CONV_FMT_B3, CONV_FMT_B3_GATE = 1, 2, 3  # include/pg_hip.h PG_CONV_FMT_*
 FUSE_SKIP = os.environ.get("PG_FUSE_SKIP", "1") != "0"  # A/B: 0 = plain fan-out, autograd sums the gradients
 
 

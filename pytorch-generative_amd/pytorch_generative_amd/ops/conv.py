@@ -14,6 +14,7 @@ from pytorch_generative_amd.ops._common import (
     ACT_NONE,
     ACT_RELU,
     CONV_FMT_B3,
+    CONV_FMT_B3_GATE,
     FUSE_SKIP,
     _chk,
     _dense_per_image,
@@ -174,10 +175,11 @@ class _ConvTaps(torch.autograd.Function):
                 if tuple(gate_res.shape) != (n, cout // 2, oh, ow):
                     raise ValueError("conv2d: gate_res shape mismatch")
             fmt_t = _use_mfma(lib, cout, cin, spec, (ih, iw), ow) if ctx.needs_input_grad[0] else 0
+            # forward fragments in the gate-interleaved channel order (each wave owns both halves of its gate channels)
             if fmt_t:
-                wfrag, ctx.wfrag_t = _pack_frag_both(lib, weight, spec, mfma, fmt_t)
+                wfrag, ctx.wfrag_t = _pack_frag_both(lib, weight, spec, CONV_FMT_B3_GATE, fmt_t)
             else:
-                wfrag = _pack_frag(lib, weight, spec, False, mfma)
+                wfrag = _pack_frag(lib, weight, spec, False, CONV_FMT_B3_GATE)
             y = torch.empty((n, cout // 2, oh, ow), device=x.device, dtype=torch.float32)
             _lib.check(
                 lib.pg_conv2d_mfma_gate(
