@@ -386,6 +386,230 @@ __global__ void __launch_bounds__(64 * WV, WV / 2) conv_wgrad_b3_kernel(const Wb
   }
 }
 
+// ---- "row ring" variant (round 6): 64 co x 64 ci per workgroup, one image row per tile, x rows kept in an LDS ring ----------
+// The kernel above re-stages what it already had: with a row halo (2x2: TR + 1 x rows per TR output rows) and 32 x channels
+// per workgroup it reads AND SPLITS dy once per 32-channel ci chunk and every halo row twice — 1.70x the algorithmic bytes
+// on PixelSNAIL's 2x2 64 -> 64 (profiles/r06_wgrad_pmc.json) and, what matters more for a kernel bound by its staging
+// arithmetic (5.5 VALU instructions per MFMA), 224 channel-rows of three-way splits per output row and 64 x channels where
+// 128 suffice. Here a workgroup walks CONSECUTIVE rows of an image segment; a tile is ONE row (W == 32: exactly one K step of
+// 4 pixel blocks), its dy row (64 channels) is staged once and meets all 64 x channels, and of x only the NEW row is staged —
+// the rows above it are still in the ring (hr + 1 rows; a segment starts with hr x-only steps). 512 threads: waves 0-3 stage
+// the dy row, waves 4-7 the x row (one 8-pixel slot per thread); every wave owns one 16-channel dy tile x two ci tiles x T taps.
+// LDS: dy 12 KB + x copies * (hr + 1) * 12 KB (2x2: 60 KB, two workgroups per CU).
+struct WrArgs {
+  const float* x; const float* dy; float* part;
+  long part_stride;
+  int N, Cin, Cout, H, W, T;
+  int nseg, seg_rows, units;   // row segments per image, rows per segment, N * nseg work units (strided over blockIdx.x)
+  int P, RB;                   // x-only steps in front of a segment (= hr), ring rows (= hr + 1)
+  int max_dr;
+  int ndc, dcs[3];             // distinct column shifts (copies)
+  int x_off16;                 // first 16-byte entry of the x area
+  int in_act, has_bias;
+  int dbg;                     // ablation switches (PG_WB_DBG: 1 no loads, 2 no commit, 4 no MFMA, 8 no fragment reads either), 0 in production
+  int copy_of[4], q_of[4];     // per tap: its x copy; rows back from the newest ring row (max_dr - dr)
+};
+
+template <int T, int D = 3>
+__global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) {
+  // D = prefetch distance in steps (register sets in flight). A step is short (one row: ~1.5 us of MFMA for the CU's two
+  // workgroups), the loaded-HBM latency is not: with one set in flight the phases added up — ablation on the 2x2 64 -> 64 at
+  // batch 1024 (profiles/r06_wgrad_ring_ablation.txt): launch 282 us = 39 (empty loop + reduce) + 105 loads + 45 commit + 117 MFMA.
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 3, wi = wave >> 2;   // dy channel tile; pair of ci tiles
+  const bool is_x = wave >= 4;               // staging role (wave-uniform)
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  constexpr int DPLANE = 4 * 4 * 16;         // entries per dy piece plane: 4 channel tiles x 4 pixel blocks x 16 channels
+  const int xplane = 4 * a.RB * 4 * 16;      // entries per x (copy, piece) plane: [ci tile][ring row][pixel block][16 channels]
+  // this thread's staging slot: 8 pixels (column block cb) of channel 16 ct + i of the row
+  const int se = tid & 255;
+  const int s_i = se & 15, s_cb = (se >> 4) & 3, s_ct = se >> 6;
+  const int goff = (s_ct * 16 + s_i) * a.H * a.W + 8 * s_cb;
+  const int d_ent = (s_ct * 4 + s_cb) * 16 + s_i;
+  const int x_ent = a.x_off16 + (s_ct * a.RB * 4 + s_cb) * 16 + s_i;   // + ring row * 64
+  float4 v0[D], v1[D];
+  float e0[D], e1[D];  // the pixel left / right of the slot's 8 (x slots)
+  bool ok[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    v0[k] = v1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    e0[k] = e1[k] = 0.f;
+    ok[k] = false;
+  }
+
+  // step (unit, s): s in [-P, seg_rows): output row seg * seg_rows + s; the x row staged with it is that row + max_dr
+#define PG_WR_ISSUE(K, UNIT, S)                                                                    \
+  {                                                                                                \
+    /* UNCONDITIONAL loads straight into set K (a load under `if (ok)` becomes load-to-temporary + select, i.e. a      */ \
+    /* s_waitcnt vmcnt right behind the issue: measured, the loads then never overlap the MFMA phase); rows outside the */ \
+    /* image / segment and steps past the workgroup's last are clamped to a valid address and zeroed at commit          */ \
+    const int u_ = PG_DBG_BIT(a.dbg, 16) ? 0 : ((UNIT) < a.units ? (UNIT) : a.units - 1);   /* 16: cache-resident loads */ \
+    const int n_ = u_ / a.nseg;                                                                    \
+    const int row_ = (u_ - n_ * a.nseg) * a.seg_rows + (S);                                        \
+    int go_ = goff;                                                                                \
+    asm volatile("" : "+v"(go_));                                                                  \
+    /* both roles issue the SAME four loads per set (the dy waves' two neighbour loads are unused): the compiler's     */ \
+    /* wait in front of a commit is then vmcnt(4 (D - 1)) for every wave — with 2 loads on one path and 4 on the other */ \
+    /* it merged the paths to vmcnt(4), which made the x waves wait for the set they had issued one step earlier       */ \
+    const int ir_ = is_x ? row_ + a.max_dr : row_;                                                 \
+    ok[K] = is_x ? (ir_ >= 0 && ir_ < a.H) : (S) >= 0;                                             \
+    const int rc_ = ir_ < 0 ? 0 : (ir_ >= a.H ? a.H - 1 : ir_);                                    \
+    const float* q_ = (is_x ? a.x + ((long)n_ * a.Cin + ci0) * a.H * (long)a.W                     \
+                            : a.dy + ((long)n_ * a.Cout + co0) * a.H * (long)a.W) + (long)rc_ * a.W + go_; \
+    const float4* p_ = reinterpret_cast<const float4*>(q_);                                        \
+    v0[K] = p_[0]; v1[K] = p_[1];                                                                  \
+    /* the pixel left / right of the slot: edge slots load an in-row neighbour instead (zeroed at commit) */ \
+    e0[K] = q_[s_cb == 0 ? 0 : -1];                                                                \
+    e1[K] = q_[s_cb == 3 ? 7 : 8];                                                                 \
+  }
+
+#define PG_WR_COMMIT_X(K, ACT, ROW)                                                                \
+  {                                                                                                \
+    const float r_[8] = {v0[K].x, v0[K].y, v0[K].z, v0[K].w, v1[K].x, v1[K].y, v1[K].z, v1[K].w};  \
+    float x_[8];                                                                                   \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = ok[K] ? pg_apply_act(r_[c], ACT) : 0.f;  \
+    u32x4 p_[3];                                                                                   \
+    split8(x_, p_[0], p_[1], p_[2]);                                                               \
+    const int ent_ = x_ent + (ROW) * 64;                                                           \
+    _Pragma("unroll") for (int v = 0; v < 3; ++v) {                                                \
+      if (v < a.ndc) {                                                                             \
+        const int dc_ = a.dcs[v];                                                                  \
+        u32x4* dst_ = lds16 + ent_ + v * 3 * xplane;                                               \
+        if (dc_ == 0) {                                                                            \
+          _Pragma("unroll") for (int q = 0; q < 3; ++q) dst_[q * xplane] = p_[q];                  \
+        } else {                                                                                   \
+          unsigned int s_[3];                                                                      \
+          const bool edge_ = dc_ < 0 ? s_cb == 0 : s_cb == 3;                                      \
+          split1(ok[K] && !edge_ ? pg_apply_act(dc_ < 0 ? e0[K] : e1[K], ACT) : 0.f, s_[0], s_[1], s_[2]); \
+          _Pragma("unroll") for (int q = 0; q < 3; ++q)                                            \
+            dst_[q * xplane] = dc_ < 0 ? shift_right1(p_[q], s_[q]) : shift_left1(p_[q], s_[q]);   \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+  }
+#define PG_WR_ADVANCE(U, S) { (S) += 1; if ((S) == a.seg_rows) { (U) += (int)gridDim.x; (S) = -a.P; } }
+
+  f32x4 acc[2][T];
+  f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool bias_wave = a.has_bias && wi == 0 && blockIdx.z == 0;  // wave-uniform
+  bf16x8 ones;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
+  const bf16x8* L = reinterpret_cast<const bf16x8*>(lds16) + lane;
+  const int a_base = wc * 64;
+  int b_copy[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) b_copy[t] = a.x_off16 + a.copy_of[t] * 3 * xplane + wi * 2 * a.RB * 64;
+
+  int unit = blockIdx.x, s = -a.P;   // the step being committed / multiplied
+  int unit_i = unit, s_i2 = s;       // the step whose loads are issued next (D steps ahead)
+  int rb = 0;  // ring row the current step writes: (s + P) mod RB
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    if (!PG_DBG_BIT(a.dbg, 1)) PG_WR_ISSUE(k, unit_i, s_i2)
+    PG_WR_ADVANCE(unit_i, s_i2)
+  }
+  while (unit < a.units) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      if (unit >= a.units) break;
+      __syncthreads();  // the previous step's fragment reads are done
+      // every register of THIS set is "used" here: one counted s_waitcnt vmcnt at this point (the younger sets stay in flight)
+      if (!PG_DBG_BIT(a.dbg, 8))
+      asm volatile("" :: "v"(v0[k].x), "v"(v0[k].y), "v"(v0[k].z), "v"(v0[k].w), "v"(v1[k].x), "v"(v1[k].y), "v"(v1[k].z),
+                         "v"(v1[k].w), "v"(e0[k]), "v"(e1[k]));
+      if (PG_DBG_BIT(a.dbg, 8)) {  // ablation: the loads stay in flight, the commit works on constants (no wait for them)
+        v0[k] = v1[k] = make_float4(1.f, 2.f, 3.f, 4.f);
+        e0[k] = e1[k] = 0.5f;
+      }
+      if (PG_DBG_BIT(a.dbg, 2)) {
+      } else if (!is_x) {
+        if (s >= 0) {
+          const float r[8] = {v0[k].x, v0[k].y, v0[k].z, v0[k].w, v1[k].x, v1[k].y, v1[k].z, v1[k].w};
+          u32x4 h, m, l;
+          split8(r, h, m, l);
+          u32x4* dst = lds16 + d_ent;
+          dst[0] = h; dst[DPLANE] = m; dst[2 * DPLANE] = l;
+        }
+      } else {
+        switch (a.in_act) {  // wave-uniform
+          case PG_ACT_RELU: PG_WR_COMMIT_X(k, PG_ACT_RELU, rb) break;
+          case PG_ACT_ELU:  PG_WR_COMMIT_X(k, PG_ACT_ELU, rb) break;
+          case PG_ACT_GELU: PG_WR_COMMIT_X(k, PG_ACT_GELU, rb) break;
+          default:          PG_WR_COMMIT_X(k, PG_ACT_NONE, rb) break;
+        }
+      }
+      __syncthreads();
+      if (!PG_DBG_BIT(a.dbg, 1)) PG_WR_ISSUE(k, unit_i, s_i2)
+      PG_WR_ADVANCE(unit_i, s_i2)
+      if (s >= 0 && !PG_DBG_BIT(a.dbg, 4)) {
+        bf16x8 af[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[p] = L[a_base + p * DPLANE];
+        if (bias_wave) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) accb = MFMA16B(af[p], ones, accb);
+        }
+        // B fragments of group g = (tap, ci tile) are requested one group ahead of their MFMAs
+        const bf16x8* Lb[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          int rr = rb - a.q_of[t];
+          rr = rr < 0 ? rr + a.RB : rr;
+          Lb[t] = L + b_copy[t] + rr * 64;
+        }
+        bf16x8 bf[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[0][p] = Lb[0][p * xplane];
+#pragma unroll
+        for (int g = 0; g < 2 * T; ++g) {
+          const int t = g >> 1, j = g & 1;
+          if (g + 1 < 2 * T) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[(g + 1) & 1][p] = Lb[(g + 1) >> 1][((g + 1) & 1) * a.RB * 64 + p * xplane];
+          }
+          f32x4 c = acc[j][t];
+          c = MFMA16B(af[2], bf[g & 1][0], c);  // l.h
+          c = MFMA16B(af[0], bf[g & 1][2], c);  // h.l
+          c = MFMA16B(af[1], bf[g & 1][1], c);  // m.m
+          c = MFMA16B(af[1], bf[g & 1][0], c);  // m.h
+          c = MFMA16B(af[0], bf[g & 1][1], c);  // h.m
+          c = MFMA16B(af[0], bf[g & 1][0], c);  // h.h
+          acc[j][t] = c;
+        }
+      }
+      PG_WR_ADVANCE(unit, s)
+      rb = (s == -a.P) ? 0 : (rb + 1 == a.RB ? 0 : rb + 1);
+    }
+  }
+#undef PG_WR_ISSUE
+#undef PG_WR_COMMIT_X
+#undef PG_WR_ADVANCE
+
+  // ---- this workgroup's row of partial sums: D[row = (lane >> 4) * 4 + r][col = lane & 15]
+  float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
+  const int co_b = co0 + wc * 16 + (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ci = ci0 + (wi * 2 + j) * 16 + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) prow[((size_t)(co_b + r) * a.Cin + ci) * T + t] = acc[j][t][r];
+  }
+  if (bias_wave && (lane & 15) == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[(size_t)a.Cout * a.Cin * T + co_b + r] = accb[r];
+  }
+}
+
 // ---- "shifted dy" variant: 32 co x 32 ci per workgroup, full NR x NC tap grids ---------------------------
 // Same GEMM, the column shift moved to the OTHER operand:
 //   dw[co][ci][dr, dc] = sum_{r, c'} dy[r][c' - dc] * act(x)[r + dr][c']
@@ -670,6 +894,49 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   for (int v = a.ndc; v < 3; ++v) a.dcs[v] = 0;
   const int hr = max_dr - min_dr;
   const int PBR = (OW + 7) / 8;  // W % 8 == 4: the last pixel block of a row is half full
+  // row-ring kernel (round 6; PG_WGRAD_B3_RING=0 for A/B): 32-pixel rows, 64 x 64 channels, a row halo or three taps
+  static const bool ring_on = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_RING"); return !(e && e[0] == '0'); }();
+  if (ring_on && OW == 32 && Cout % 64 == 0 && Cin % 64 == 0 && T >= 2 && T <= 4 && (hr >= 1 || T == 3) && hr <= 2) {
+    WrArgs r;
+    r.ndc = a.ndc;
+    for (int v = 0; v < 3; ++v) r.dcs[v] = a.dcs[v];
+    r.RB = hr + 1; r.P = hr; r.max_dr = max_dr;
+    const int xplane = 4 * r.RB * 64;
+    r.x_off16 = 3 * 256;
+    const size_t shmem = ((size_t)r.x_off16 + (size_t)r.ndc * 3 * xplane) * 16;
+    if (shmem <= (size_t)WB_LDS_BUDGET) {
+      r.x = x; r.dy = dy; r.part = part; r.part_stride = part_stride;
+      r.N = N; r.Cin = Cin; r.Cout = Cout; r.H = OH; r.W = OW; r.T = T;
+      r.in_act = in_act; r.has_bias = has_bias;
+#ifdef PG_ABLATE
+      { const char* e = getenv("PG_WB_DBG"); r.dbg = e ? atoi(e) : 0; }
+#else
+      r.dbg = 0;
+#endif
+      for (int t = 0; t < 4; ++t) {
+        r.copy_of[t] = t < T ? copy_of[t] : 0;
+        r.q_of[t] = t < T ? max_dr - tap_dr[t] : 0;
+      }
+      const int co_chunks = Cout / 64, ci_chunks = Cin / 64;
+      long G = 512 / ((long)co_chunks * ci_chunks);
+      if (G < 16) G = 16;
+      // work units = (image, segment of rows): whole images when there are enough of them, otherwise segments of >= 8 rows
+      // (every segment starts with hr x-only steps)
+      int nseg = 1;
+      while ((long)N * nseg < G && OH % (2 * nseg) == 0 && OH / (2 * nseg) >= 8) nseg *= 2;
+      r.nseg = nseg; r.seg_rows = OH / nseg; r.units = N * nseg;
+      if (G > r.units) G = r.units;
+      if (G > max_rows) G = max_rows;
+      dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
+      switch (T) {
+        case 2: hipLaunchKernelGGL((conv_wgrad_b3r_kernel<2>), grid, dim3(512), shmem, st, r); break;
+        case 3: hipLaunchKernelGGL((conv_wgrad_b3r_kernel<3>), grid, dim3(512), shmem, st, r); break;
+        default: hipLaunchKernelGGL((conv_wgrad_b3r_kernel<4>), grid, dim3(512), shmem, st, r); break;
+      }
+      if (hipGetLastError() != hipSuccess) return -1;
+      return (int)G;
+    }
+  }
   // 64 dy channels per workgroup: 8 waves (four per SIMD, 2 staging slots per thread); PG_WGRAD_B3_WAVES=4 for A/B
   static const int env_waves = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
   // tile rows: K steps of 4 pixel blocks, staging slots within the per-thread caps, LDS within budget

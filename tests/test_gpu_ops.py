@@ -54,6 +54,12 @@ CONV_CASES = [
     (2, 32, 10, 16, 128, 1, 3, 0, 1, None, None, "gelu", True, True),   # 3 taps, two co chunks
     (2, 96, 7, 24, 64, 2, 1, 2, 0, "hw", None, "elu", False, True),     # 2 taps, ragged last row tile
     (1, 32, 64, 64, 64, 2, 2, 1, 1, "hw", None, None, False, True),     # 64 wide: one row per tile
+    # round 6: the row-ring weight-gradient kernel (conv_wgrad_b3r_kernel: 32-wide rows, 64 x 64 channels, x rows kept in an LDS ring).
+    # Few images = row segments that start mid-image (their halo rows are loaded, not zero); 3 images = an idle tail of the grid
+    (3, 64, 32, 32, 64, 2, 2, 1, 1, "hw", None, "elu", False, True),     # 2x2: two column copies, one halo row; 4 segments per image
+    (1, 128, 32, 32, 64, 2, 1, 2, 0, "hw", None, "relu", True, True),    # 2x1: two taps, one copy, two ci chunks
+    (2, 64, 32, 32, 128, 1, 3, 0, 1, None, None, None, False, True),     # 1x3: three copies, no halo (ring of one row), two co chunks
+    (20, 64, 32, 32, 64, 2, 2, 1, 1, "hw", None, None, False, False),    # 20 images: whole-image units + segments, no bias
     # round 6: the overlapped 16-wave kernel (conv_b3q_kernel.h), two tiles per workgroup sharing one weight slab: 6 taps with >= 256
     # channels on one side (PixelCNN++'s 2x3 convolutions); odd batch = an idle half in the last round, Cout % 64 != 0 = a partial chunk
     (3, 320, 32, 32, 160, 2, 3, 1, 1, "hw", None, None, False, True),    # forward on Q (Cin 320), data gradient 160 -> 320 on Q too
