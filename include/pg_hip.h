@@ -113,6 +113,18 @@ int pg_conv_gate_fusable(int Cin, int Cout, int OH, int OW, int T, const int* ta
 int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const float* bias, float* out, int N, int Cin, int IH, int IW,
                         int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc, int in_act, int gate,
                         const float* gate_res, float* gate_out, void* stream);
+/* Round 6: the "dual" 1x1 data gradient of PixelSNAIL's block tail (pixel_snail.py:109-119: both = elu(conv_a(..)) + r,
+ * out = elu(conv_o(elu(both))) + x). conv_o's data gradient owes BOTH producers of its input their ELU derivatives (they were
+ * called with the out_pre_scaled protocol). in = dy of conv_o (N, Cin, OH, OW), wfrag = pg_pack_conv_weight_frag(transpose = 1,
+ * PG_CONV_FMT_B3), dact_src = both, r (N, Cout, OH, OW):
+ *   d    = conv1x1(in) * act'(dact_src)                      (dact: PG_ACT_ELU for conv_o's own input activation)
+ *   out  = d * elu'(a)  with elu(a) = dact_src - r           (gradient of conv_a's pre-activation)
+ *   out2 = d * elu'(r's pre-activation)                      (gradient of r's producer's pre-activation)
+ * both derivatives from the stored ELU outputs (y > 0 ? 1 : y + 1). Replaces two pg_act_bwd_from_out launches.
+ * pg_conv_dual_ok() returns 1 for the shapes the bf16x3 1x1 kernel takes (<= 64 input channels of the forward convolution). */
+int pg_conv_dual_ok(int Cin, int Cout, int OH, int OW);
+int pg_conv2d_mfma_dual(const float* in, const float* wfrag, float* out, float* out2, int N, int Cin, int OH, int OW, int Cout,
+                        const float* dact_src, int dact, const float* r, void* stream);
 /* Two arithmetic back ends share this entry point; they differ in the weight-fragment FORMAT:
  *   PG_CONV_FMT_F32: v_mfma_f32_16x16x4_f32 on fp32 fragments (csrc/conv_mfma.hip);
  *   PG_CONV_FMT_B3:  every fp32 product as six v_mfma_f32_16x16x32_bf16 on exact three-way bf16

@@ -227,6 +227,13 @@ size_t pg_b3_frag_floats(int Kc, int M, int T) {
   return (size_t)b3_chunks(M) * (Kc / pl.CIB) * pl.ksteps * pl.MT * 3 * 64 * 4;
 }
 
+// the 1x1 kernel's multi-stream instantiation takes the launch (the conditions of pg_b3_conv's routing, restated)
+int pg_b3_dual_ok(int Cin, int Cout, int OH, int OW) {
+  const B3Plan pl = b3_plan(Cin, Cout, 1);
+  if (!pl.ok || pl.MT != 4 || pl.ksteps != 1 || (OH * OW) % 2 != 0 || OH * OW < 16 || OW > 256) return 0;
+  return (size_t)(Cin / pl.CIB) * pl.MT * 3 * 1024 <= 24 * 1024;
+}
+
 int pg_b3_gate_fusable(int Cin, int Cout, int T, int OH, int OW, int hr, int hc) {
   if (Cout != 2 * B3_CO_CHUNK || T < 2 || OW > 256 || OH * OW < 16) return 0;  // (one tap with <= 64 input channels runs without an x tile)
   const B3Plan pl = b3_plan(Cin, Cout, T);
@@ -279,9 +286,12 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
                int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
                const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
                const float* res2, long res_bs, long res2_bs, hipStream_t st, int gate, const float* gate_res,
-               float* gate_out) {
+               float* gate_out, float* dual_out2) {
   B3Args a;
   a.gate = gate; a.gate_res = gate_res; a.gate_out = gate_out;
+  a.out2 = dual_out2;
+  PG_REQUIRE(!dual_out2 || (res && dact_src && !res2 && !gate && out_act == PG_ACT_NONE && !bias && T == 1), PG_EINVAL,
+             "pg_conv2d_mfma_dual: a 1x1 data gradient with a derivative source and r, nothing else");
   PG_REQUIRE(gate == 0 || (gate_out && !res && !res2 && !dact_src && out_act == PG_ACT_NONE &&
                            (gate == 1 + PG_GATE_TANH || gate == 1 + PG_GATE_IDENTITY)), PG_EINVAL,
              "pg_conv2d_mfma_gate: the fused gate takes no residual / derivative / output activation of the convolution itself");
@@ -325,7 +335,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
     // both residual operands the SAME tensor (PixelCNN's x + (x + net(x)) and the two equal skip gradients of its
     // backward): one stream, added twice
     const bool twice = res2 != nullptr && res2 == res && a.res2_bs == a.res_bs;
-    const bool ms_pw = twice ? ((dact_src != nullptr) || a.res_bs != (long)Cout * OH * OW) : ms;
+    const bool ms_pw = twice ? ((dact_src != nullptr) || a.res_bs != (long)Cout * OH * OW) : ms;  // (dual: res + dact_src => ms)
     if (pw_on && !gate && (!ms_pw || pl.MT == 4) && T == 1 && pl.ksteps == 1 && tap_dr[0] == 0 && tap_dc[0] == 0 && IH == OH && IW == OW &&
         (OH * OW) % 2 == 0 && (((uintptr_t)in) & 7) == 0 && wbytes <= 24 * 1024) {
       a.TR = 0; a.tile_h = a.tile_w = a.plane16 = a.tiles_per_img = 0;
@@ -353,6 +363,7 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
       PG_LAUNCH_CHECK("pg_conv2d_mfma(bf16x3, 1x1)");
       return 0;
     }
+    PG_REQUIRE(!dual_out2, PG_ESHAPE, "pg_conv2d_mfma_dual: shape not on the 1x1 kernel (pg_conv_dual_ok)");
   }
   if (T > 1 && !pl.pipelined) {
     // conv_b3_kernel: the staged tile may be larger than the format-level 352 pixels if THIS launch's LDS has the room

@@ -34,6 +34,11 @@ struct B3Args {
   const float* gate_res;
   float* gate_out;
   int gate;
+  // "dual" data gradient (round 6, conv_b3_pw_kernel<.., MS = true>; pixel_snail.py:109-119): the convolution's input was
+  // x = elu(a) + r with both producers' ELU derivatives owed by THIS launch (out_pre_scaled protocol). With d = conv * act'(dact_src),
+  // dact_src = x and res = r:   out = d * elu'(a) with elu(a) = x - r (the gradient of a's pre-activation),   out2 = d * elu'(r's
+  // pre-activation) — the derivatives from the stored ELU outputs (y > 0 ? 1 : y + 1). res is NOT added in this mode.
+  float* out2;
   int dbg;                        // ablation switches (PG_B3_DBG; -DPG_ABLATE builds only), 0 otherwise
   int g_tapoff[B3_MAXG];          // per group: tap offset in tile pixels
   int g_cg[B3_MAXG];              // per group: channel group of the chunk
@@ -1349,7 +1354,16 @@ if constexpr (GL) {
           break;
         default: break;
       }
+      float v2[MS ? 8 : 1];
       if constexpr (MS) {
+        if (a.out2) {  // dual data gradient (B3Args::out2): two outputs, the residual stream is r, not an addend
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float d = v[c];
+            v2[c] = d * pg_act_grad(o1[c], PG_ACT_ELU_OUT);
+            v[c] = d * pg_act_grad(o0[c] - o1[c], PG_ACT_ELU_OUT);
+          }
+        } else {
         if (st1) {
 #pragma unroll
           for (int c = 0; c < 8; ++c) v[c] = fmaf(o1[c], a.res_scale, v[c]);
@@ -1357,6 +1371,7 @@ if constexpr (GL) {
         if (st2) {
 #pragma unroll
           for (int c = 0; c < 8; ++c) v[c] += o2[c];
+        }
         }
       } else {
         if (st1) {
@@ -1373,6 +1388,15 @@ if constexpr (GL) {
         for (int c = 0; c < 8; ++c) {
           const int cc = m * 16 + c;
           if (cc < cvalid) (outp + (size_t)cc * cstride)[lo] = v[c];
+        }
+        if constexpr (MS) {
+          if (a.out2) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const int cc = m * 16 + c;
+              if (cc < cvalid) (a.out2 + so + (size_t)cc * cstride)[lo] = v2[c];
+            }
+          }
         }
       }
     }

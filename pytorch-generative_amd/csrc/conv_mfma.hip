@@ -486,7 +486,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
                int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
                const int* tap_dc, int in_act, const float* dact_src, int dact, int out_act,
                const float* res2, long res_bs, long res2_bs, hipStream_t st, int gate = 0, const float* gate_res = nullptr,
-               float* gate_out = nullptr);
+               float* gate_out = nullptr, float* dual_out2 = nullptr);
+int pg_b3_dual_ok(int Cin, int Cout, int OH, int OW);
 int pg_b3_gate_fusable(int Cin, int Cout, int T, int OH, int OW, int hr, int hc);
 
 // Geometry of one fp32-MFMA launch: pixel tile, channel chunk, LDS layout. Needs a.N / Cin / IW / Cout / OH / OW / T; hr / hc = row /
@@ -664,6 +665,27 @@ PG_EXPORT int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const flo
              "pg_conv2d_mfma_gate: shape not covered (pg_conv_gate_fusable)");
   return pg_b3_conv(in, wfrag, bias, nullptr, out, N, Cin, IH, IW, Cout, OH, OW, T, tap_dr, tap_dc, in_act, nullptr, PG_ACT_NONE,
                     PG_ACT_NONE, nullptr, 0, 0, (hipStream_t)stream, 1 + gate, gate_res, gate_out);
+}
+
+// Round 6: the "dual" 1x1 data gradient of PixelSNAIL's block tail (pixel_snail.py:109-119: both = elu(conv_a(..)) + r_out,
+// out = elu(conv_o(elu(both))) + x): conv_o's data gradient owes both producers their ELU derivatives. With
+// d = conv1x1(in) * act'(dact_src) (dact_src = both):  out = d * elu'(a) where elu(a) = both - r,  out2 = d * elu'(r) — the
+// derivatives from the stored ELU outputs (y > 0 ? 1 : y + 1). Replaces two pg_act_bwd_from_out launches (7 streams) by one more
+// read and one more write in this launch's epilogue.
+PG_EXPORT int pg_conv_dual_ok(int Cin, int Cout, int OH, int OW) {
+  static const bool on = []() { const char* e = PG_AB_ENV("PG_CONV_DUAL"); return !(e && e[0] == '0'); }();
+  return on && pg_b3_dual_ok(Cin, Cout, OH, OW);
+}
+
+PG_EXPORT int pg_conv2d_mfma_dual(const float* in, const float* wfrag, float* out, float* out2, int N, int Cin, int OH, int OW,
+                                  int Cout, const float* dact_src, int dact, const float* r, void* stream) {
+  PG_REQUIRE(in && wfrag && out && out2 && dact_src && r, PG_EINVAL, "pg_conv2d_mfma_dual: null pointer");
+  PG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0, PG_EINVAL, "pg_conv2d_mfma_dual: non-positive dimension");
+  PG_REQUIRE(dact >= PG_ACT_NONE && dact <= PG_ACT_ELU_OUT && dact != PG_ACT_GELU, PG_EINVAL, "pg_conv2d_mfma_dual: bad derivative id");
+  PG_REQUIRE(pg_b3_dual_ok(Cin, Cout, OH, OW), PG_ESHAPE, "pg_conv2d_mfma_dual: shape not covered (pg_conv_dual_ok)");
+  const int zero = 0;
+  return pg_b3_conv(in, wfrag, nullptr, r, out, N, Cin, OH, OW, Cout, OH, OW, 1, &zero, &zero, PG_ACT_NONE, dact_src, dact,
+                    PG_ACT_NONE, nullptr, 0, 0, (hipStream_t)stream, 0, nullptr, nullptr, out2);
 }
 
 PG_EXPORT int pg_conv2d_mfma(const float* in, const float* wfrag, const float* bias,

@@ -431,12 +431,10 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
   const int d_ent = (s_ct * 4 + s_cb) * 16 + s_i;
   const int x_ent = a.x_off16 + (s_ct * a.RB * 4 + s_cb) * 16 + s_i;   // + ring row * 64
   float4 v0[D], v1[D];
-  float e0[D], e1[D];  // the pixel left / right of the slot's 8 (x slots)
   bool ok[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     v0[k] = v1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    e0[k] = e1[k] = 0.f;
     ok[k] = false;
   }
 
@@ -451,9 +449,8 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
     const int row_ = (u_ - n_ * a.nseg) * a.seg_rows + (S);                                        \
     int go_ = goff;                                                                                \
     asm volatile("" : "+v"(go_));                                                                  \
-    /* both roles issue the SAME four loads per set (the dy waves' two neighbour loads are unused): the compiler's     */ \
-    /* wait in front of a commit is then vmcnt(4 (D - 1)) for every wave — with 2 loads on one path and 4 on the other */ \
-    /* it merged the paths to vmcnt(4), which made the x waves wait for the set they had issued one step earlier       */ \
+    /* both roles issue the SAME two loads per set: the compiler's wait in front of a commit is then vmcnt(2 (D - 1))  */ \
+    /* for every wave (with different counts per path it merges them to the smaller one)                               */ \
     const int ir_ = is_x ? row_ + a.max_dr : row_;                                                 \
     ok[K] = is_x ? (ir_ >= 0 && ir_ < a.H) : (S) >= 0;                                             \
     const int rc_ = ir_ < 0 ? 0 : (ir_ >= a.H ? a.H - 1 : ir_);                                    \
@@ -461,14 +458,16 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
                             : a.dy + ((long)n_ * a.Cout + co0) * a.H * (long)a.W) + (long)rc_ * a.W + go_; \
     const float4* p_ = reinterpret_cast<const float4*>(q_);                                        \
     v0[K] = p_[0]; v1[K] = p_[1];                                                                  \
-    /* the pixel left / right of the slot: edge slots load an in-row neighbour instead (zeroed at commit) */ \
-    e0[K] = q_[s_cb == 0 ? 0 : -1];                                                                \
-    e1[K] = q_[s_cb == 3 ? 7 : 8];                                                                 \
   }
 
 #define PG_WR_COMMIT_X(K, ACT, ROW)                                                                \
   {                                                                                                \
     const float r_[8] = {v0[K].x, v0[K].y, v0[K].z, v0[K].w, v1[K].x, v1[K].y, v1[K].z, v1[K].w};  \
+    /* the pixel left / right of the slot's 8 = the last / first pixel of the neighbouring column block, which lane   */ \
+    /* -+ 16 of this wave holds (ds_bpermute: no memory access; two more vector loads per thread and step measured     */ \
+    /* slower — the launch carried ~0.9 us per step of load ISSUE cost even with cache-resident rows)                  */ \
+    const float e0_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane - 16) & 63) << 2, __builtin_bit_cast(int, r_[7]))); \
+    const float e1_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __builtin_bit_cast(int, r_[0]))); \
     float x_[8];                                                                                   \
     _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = ok[K] ? pg_apply_act(r_[c], ACT) : 0.f;  \
     u32x4 p_[3];                                                                                   \
@@ -483,7 +482,7 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
         } else {                                                                                   \
           unsigned int s_[3];                                                                      \
           const bool edge_ = dc_ < 0 ? s_cb == 0 : s_cb == 3;                                      \
-          split1(ok[K] && !edge_ ? pg_apply_act(dc_ < 0 ? e0[K] : e1[K], ACT) : 0.f, s_[0], s_[1], s_[2]); \
+          split1(ok[K] && !edge_ ? pg_apply_act(dc_ < 0 ? e0_ : e1_, ACT) : 0.f, s_[0], s_[1], s_[2]); \
           _Pragma("unroll") for (int q = 0; q < 3; ++q)                                            \
             dst_[q * xplane] = dc_ < 0 ? shift_right1(p_[q], s_[q]) : shift_left1(p_[q], s_[q]);   \
         }                                                                                          \
@@ -522,13 +521,8 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
       if (unit >= a.units) break;
       __syncthreads();  // the previous step's fragment reads are done
       // every register of THIS set is "used" here: one counted s_waitcnt vmcnt at this point (the younger sets stay in flight)
-      if (!PG_DBG_BIT(a.dbg, 8))
       asm volatile("" :: "v"(v0[k].x), "v"(v0[k].y), "v"(v0[k].z), "v"(v0[k].w), "v"(v1[k].x), "v"(v1[k].y), "v"(v1[k].z),
-                         "v"(v1[k].w), "v"(e0[k]), "v"(e1[k]));
-      if (PG_DBG_BIT(a.dbg, 8)) {  // ablation: the loads stay in flight, the commit works on constants (no wait for them)
-        v0[k] = v1[k] = make_float4(1.f, 2.f, 3.f, 4.f);
-        e0[k] = e1[k] = 0.5f;
-      }
+                         "v"(v1[k].w));
       if (PG_DBG_BIT(a.dbg, 2)) {
       } else if (!is_x) {
         if (s >= 0) {

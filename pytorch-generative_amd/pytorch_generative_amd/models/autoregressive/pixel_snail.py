@@ -100,9 +100,18 @@ class PixelSNAILBlock(nn.Module):
                 res = rb(res)
         if add_input and x_skip is None:
             x_skip = x
-        r_out, res_skip = _elu_conv_elu(self._residual_out, res, n_skip=1)
+        # round 6: both = elu(a) + elu(r) has one reader, the last convolution — its data gradient's epilogue multiplies by the two
+        # ELU derivatives (from both and r_out) and writes BOTH producers' gradients (ops.GradSlot carries the second); the two
+        # producers skip their pg_act_bwd_from_out launches (out_pre_scaled). Forward launches are the same either way.
+        dual = (res.requires_grad and self._out.dual_ok(res) and self._residual_out.mfma_ok(res)
+                and self._attention_out.mfma_ok(res))  # (mfma_ok reads the image size only: the attention output has it too)
+        r_out, res_skip = self._residual_out(res, in_act="elu", out_act="elu", out_pre_scaled=dual, n_skip=1)
         pos = pg_nn.image_positional_encoding(input_img.shape, res.device)
         attn = self._attention((pos, res_skip), input_img)  # cat(pos, res[, img]) happens inside, once
+        if dual:
+            slot = ops.GradSlot()
+            both = self._attention_out(attn, in_act="elu", out_act="elu", res=r_out, out_pre_scaled=True, res_slot=slot)
+            return self._out(both, in_act="elu", out_act="elu", res=x_skip if add_input else None, in_sum=(r_out, slot))
         both = _elu_conv_elu(self._attention_out, attn, res=r_out)  # elu(conv(elu(attn))) + res
         return _elu_conv_elu(self._out, both, res=x_skip if add_input else None)
 

@@ -128,12 +128,29 @@ class Conv2d(nn.Conv2d):
         """True if forward(..., gate=...) can run this convolution's GatedActivation in the same launch (ops.conv_gate_ok)."""
         return (not self._down2) and ops.RowDecode.current is None and ops.conv_gate_ok(x, self.weight, self._conv_spec(), crop)
 
+    def dual_ok(self, x, crop=None):
+        """True if forward(x, in_act="elu", in_sum=(r, slot)) can compute both gradients of x = elu(a) + r in its data gradient's
+        epilogue (ops.conv_dual_ok: a 1x1 convolution on the bf16x3 1x1 kernel; training graph only)."""
+        return ((not self._down2) and ops.RowDecode.current is None and crop is None and self.mfma_ok(x, crop)
+                and ops.conv_dual_ok(x, self.weight, self._conv_spec()))
+
     def forward(self, x, *, crop=None, in_act=None, res=None, out_act=None, out_pre_scaled=False,
-                in_post=None, n_skip=0, res2=None, gate=None, gate_res=None):
+                in_post=None, n_skip=0, res2=None, gate=None, gate_res=None, res_slot=None, in_sum=None):
         """n_skip > 0 (extension) returns (y, x_1, .., x_n): pass-through aliases of x for the skip
         connections that also read x, see ops.conv2d_taps.
         gate = ops.GATE_TANH / GATE_IDENTITY (extension, round 6; only where gate_ok()): returns the GatedActivation of this
-        convolution's output (+ gate_res) — half the channels — from the same launch."""
+        convolution's output (+ gate_res) — half the channels — from the same launch.
+        in_sum = (r, slot) / res_slot = slot (extension, round 6; only where the consumer's dual_ok()): the two ends of the dual
+        data gradient, see ops.GradSlot. Forward values do not change."""
+        if res_slot is not None or in_sum is not None:
+            if (gate is not None or res2 is not None or n_skip or self._down2 or ops.RowDecode.current is not None
+                    or not self.mfma_ok(x, crop)):
+                raise ValueError("Conv2d: res_slot / in_sum need the plain matrix-core training path (check dual_ok first)")
+            return ops.conv2d_taps(
+                x, self.weight, self.bias, self._conv_spec(), out_hw=crop, in_act=_ACTS[in_act],
+                res=res, weight_param=self.weight, bias_param=self.bias, out_act=_ACTS[out_act],
+                out_pre_scaled=out_pre_scaled, in_post=_ACTS[in_post], res_slot=res_slot, in_sum=in_sum,
+            )
         if gate is not None:
             if res is not None or res2 is not None or out_act is not None or out_pre_scaled or not self.gate_ok(x, crop):
                 raise ValueError("Conv2d: gate= needs a plain convolution on a shape gate_ok() accepts")

@@ -75,6 +75,9 @@ from pytorch_generative_amd.ops.conv import (  # noqa: F401
     conv_two_residuals_ok,
     conv2d_taps,
     conv_gate_ok,
+    conv_dual_ok,
+    GradSlot,
+    FUSE_DUAL,
     FUSE_GATE,
 )
 from pytorch_generative_amd.ops.gpt_block import (  # noqa: F401

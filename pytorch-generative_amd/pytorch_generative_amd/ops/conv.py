@@ -125,12 +125,36 @@ def _pack(lib, weight, spec, transpose):
     return wpk
 
 
+class GradSlot:
+    """One gradient tensor handed from a consumer's backward to a producer's backward outside autograd's own edges: the "dual"
+    data gradient (conv2d_taps(..., in_sum=(r, slot))) computes TWO gradients for its one input x = elu(a) + r — autograd carries
+    the first (a's), the second (r's, already multiplied by r's ELU derivative) waits here for the backward of the convolution that
+    added r (conv2d_taps(..., out_pre_scaled=True, res=r, res_slot=slot)), which returns it as r's gradient. Filled and emptied
+    once per backward pass; taking from an empty slot raises (the consumer's backward did not run first, or took another path)."""
+
+    def __init__(self):
+        self._g = None
+
+    def put(self, g):
+        if self._g is not None:
+            raise RuntimeError("GradSlot: filled twice in one backward pass")
+        self._g = g
+
+    def take(self):
+        g, self._g = self._g, None
+        if g is None:
+            raise RuntimeError("GradSlot: empty — the dual data gradient that fills it has not run")
+        return g
+
+
 class _ConvTaps(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, res, spec, out_hw, in_act, gw, gb, out_act=ACT_NONE,
-                out_pre_scaled=False, in_post=ACT_NONE, n_skip=0, res2=None, gate=None, gate_res=None):
+                out_pre_scaled=False, in_post=ACT_NONE, n_skip=0, res2=None, gate=None, gate_res=None, res_slot=None,
+                in_sum=None):
         lib = _lib.load()
         ctx.gate = gate
+        ctx.res_slot, ctx.in_sum_slot = res_slot, None
         x = _chk(x, "conv2d.x")
         weight = _chk(weight, "conv2d.weight")
         n, cin, ih, iw = x.shape
@@ -154,7 +178,12 @@ class _ConvTaps(torch.autograd.Function):
             if not (mfma == CONV_FMT_B3 and cout >= 64):
                 raise ValueError("conv2d: a second residual needs the bf16x3 kernel with >= 64 output channels "
                                  "(check ops.conv_two_residuals_ok first)")
-        if out_pre_scaled and res is not None:
+        if out_pre_scaled and res is not None and res_slot is not None:
+            # the consumer is a dual data gradient (in_sum): it recovers this activation's output as (its input - res) and hands
+            # res's gradient back through the slot
+            if out_act != ACT_ELU or res2 is not None:
+                raise ValueError("conv2d: res_slot needs out_act='elu' and a single residual")
+        elif out_pre_scaled and res is not None:
             # the consumer (in_post) recovers act' from THIS output: a residual added behind the activation would change
             # the value it reads and with it every gradient upstream (found by tests/test_gpu_ops.py::test_conv_protocol_matrix)
             raise ValueError("conv2d: out_pre_scaled cannot be combined with a residual (the consumer's in_post derivative "
@@ -221,11 +250,20 @@ class _ConvTaps(torch.autograd.Function):
                 ),
                 "pg_conv2d_taps",
             )
+        if in_sum is not None:
+            r_sum, ctx.in_sum_slot = in_sum
+            if gate is not None or n_skip or in_act != ACT_ELU or tuple(r_sum.shape) != tuple(x.shape):
+                raise ValueError("conv2d: in_sum needs in_act='elu', no skip aliases and r of the input's shape")
+            if not conv_dual_ok(x, weight, spec):
+                raise ValueError("conv2d: in_sum on a shape the dual data gradient does not take (check ops.conv_dual_ok first)")
+            r_sum = _chk(r_sum, "conv2d.in_sum")
         if out_act != ACT_NONE and not out_pre_scaled:
             # backward recovers act' from the output: v = out - res
-            ctx.save_for_backward(x, weight, out, res) if res is not None else ctx.save_for_backward(x, weight, out)
+            tensors = (x, weight, out, res) if res is not None else (x, weight, out)
         else:
-            ctx.save_for_backward(x, weight)
+            tensors = (x, weight)
+        ctx.n_own = len(tensors)
+        ctx.save_for_backward(*(tensors + ((r_sum,) if in_sum is not None else ())))
         ctx.spec, ctx.in_act, ctx.has_bias, ctx.has_res = spec, in_act, bias is not None, res is not None
         ctx.has_res2 = res2 is not None
         ctx.gw, ctx.gb = gw, gb
@@ -255,7 +293,7 @@ class _ConvTaps(torch.autograd.Function):
         return _ConvTaps.backward_impl(ctx, dy, need[0], need[1], ctx.has_bias and need[2],
                                        d_skips=d_skips) + (None, None, None, None,
                                                            dy if getattr(ctx, "has_res2", False) else None,
-                                                           None, d_gate_res)
+                                                           None, d_gate_res, None, None)
 
     @staticmethod
     def backward_impl(ctx, dy, need_dx, need_w, need_b, d_skips=()):
@@ -264,6 +302,8 @@ class _ConvTaps(torch.autograd.Function):
         spec = ctx.spec
         dy = _chk(dy, "conv2d.dy")
         dres = dy if ctx.has_res else None
+        if ctx.has_res and getattr(ctx, "res_slot", None) is not None:
+            dres = ctx.res_slot.take()  # the residual's gradient, already through ITS producer's ELU (dual data gradient)
         out_act = getattr(ctx, "out_act", ACT_NONE)
         in_post = getattr(ctx, "in_post", ACT_NONE)
         if out_act != ACT_NONE and not ctx.out_pre_scaled:
@@ -304,7 +344,16 @@ class _ConvTaps(torch.autograd.Function):
                     fused_skips.append(g if _dense_per_image(g) else _chk(g, "conv2d.d_skip"))
             r1 = fused_skips[0] if fused_skips else None
             r2 = fused_skips[1] if len(fused_skips) > 1 else None
-            _lib.check(
+            slot = getattr(ctx, "in_sum_slot", None)
+            if slot is not None:
+                # dual: dx = the gradient of a's pre-activation (x = elu(a) + r), the second output that of r's producer
+                r_sum = ctx.saved_tensors[ctx.n_own]
+                dx2 = torch.empty_like(x)
+                _lib.check(lib.pg_conv2d_mfma_dual(dy.data_ptr(), wfrag_t.data_ptr(), dx.data_ptr(), dx2.data_ptr(), n, cout, oh, ow,
+                                                   cin, x.data_ptr(), dact, r_sum.data_ptr(), _stream()), "pg_conv2d_mfma_dual")
+                slot.put(dx2)
+            else:
+              _lib.check(
                 lib.pg_conv2d_mfma_ex(
                     dy.data_ptr(), wfrag_t.data_ptr(), 0, _p(r1), dx.data_ptr(), n, cout, oh, ow, cin,
                     ih, iw, len(spec.fwd_taps), spec.f_ndr, spec.f_ndc, ACT_NONE,
@@ -312,7 +361,7 @@ class _ConvTaps(torch.autograd.Function):
                     r1.stride(0) if r1 is not None else 0, r2.stride(0) if r2 is not None else 0, _stream(),
                 ),
                 "pg_conv2d_mfma(dgrad)",
-            )
+              )
             for g in skips:  # more than two, or not the bf16x3 format
                 dx = add(dx, _chk(g, "conv2d.d_skip"))
         elif need_dx:
@@ -458,7 +507,7 @@ def conv_two_residuals_ok(x, weight, spec, out_hw=None):
 
 def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
                 weight_param=None, bias_param=None, out_act=ACT_NONE, out_pre_scaled=False,
-                in_post=ACT_NONE, n_skip=0, res2=None, gate=None, gate_res=None):
+                in_post=ACT_NONE, n_skip=0, res2=None, gate=None, gate_res=None, res_slot=None, in_sum=None):
     """y = out_act(conv(in_act(x)) + bias) (+ res), cropped to out_hw (defaults to the full extent).
 
     out_act (matrix-core path only): activation fused into the epilogue; its backward recovers act'
@@ -479,11 +528,30 @@ def conv2d_taps(x, weight, bias, spec, out_hw=None, in_act=ACT_NONE, res=None,
         raise ValueError(f"conv2d: requested output {out_hw} exceeds the full extent {full}")
     if n_skip and not FUSE_SKIP:
         y = _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act, _sink(weight_param),
-                            _sink(bias_param), out_act, bool(out_pre_scaled), in_post, 0, res2, gate, gate_res)
+                            _sink(bias_param), out_act, bool(out_pre_scaled), in_post, 0, res2, gate, gate_res, res_slot,
+                            in_sum)
         return (y,) + (x,) * int(n_skip)
     return _ConvTaps.apply(x, weight, bias, res, spec, tuple(out_hw), in_act,
                            _sink(weight_param), _sink(bias_param), out_act, bool(out_pre_scaled),
-                           in_post, int(n_skip), res2, gate, gate_res)
+                           in_post, int(n_skip), res2, gate, gate_res, res_slot, in_sum)
+
+
+FUSE_DUAL = os.environ.get("PG_FUSE_DUAL", "1") != "0"  # A/B: 0 = pg_act_bwd_from_out launches behind the block tail's convolutions
+
+
+def conv_dual_ok(x, weight, spec):
+    """True if conv2d_taps(x, ..., in_act=elu, in_sum=(r, slot)) can deliver both producers' gradients from its data
+    gradient's epilogue (pg_conv_dual_ok: a 1x1 convolution whose data gradient runs on the bf16x3 1x1 kernel)."""
+    if not FUSE_DUAL or not x.is_cuda or x.dtype != torch.float32 or tuple(weight.shape[2:]) != (1, 1):
+        return False
+    if len(spec.fwd_taps) != 1 or spec.f_dr[0] != 0 or spec.f_dc[0] != 0:
+        return False
+    lib = _lib.load()
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    h, w = int(x.shape[2]), int(x.shape[3])
+    if _use_mfma(lib, cout, cin, spec, (h, w), w) != CONV_FMT_B3:
+        return False
+    return bool(lib.pg_conv_dual_ok(cout, cin, h, w))
 
 
 FUSE_GATE = os.environ.get("PG_FUSE_GATE", "1") != "0"  # A/B: 0 = the standalone gate kernel behind the convolution

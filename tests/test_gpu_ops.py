@@ -634,6 +634,53 @@ def test_gated_conv_fused_gate_equals_separate_kernels(dev, case, monkeypatch):
         _util.assert_close(a, b.cpu(), 2e-6, what)
 
 
+@pytest.mark.parametrize("n,c,ca,h,w", [(3, 64, 32, 32, 32), (2, 64, 32, 9, 10), (1, 64, 64, 4, 4)])
+def test_dual_data_gradient_of_block_tail(dev, n, c, ca, h, w, monkeypatch):
+    """PixelSNAIL's block tail (pixel_snail.py:109-119): r = elu(conv_r(elu(x1))), both = elu(conv_a(elu(x2))) + r,
+    out = elu(conv_o(elu(both))) + x3 with the dual data gradient (ops.GradSlot: conv_o's epilogue writes both producers'
+    gradients, they skip pg_act_bwd_from_out) against the same composition in torch on the CPU — output and every gradient —
+    and against the unfused graph (PG_FUSE_DUAL=0) on the GPU."""
+    from pytorch_generative_amd import nn as pg_nn
+    from pytorch_generative_amd import ops
+    from pytorch_generative_amd.ops import conv as ops_conv
+
+    torch.manual_seed(0)
+    conv_r, conv_a, conv_o = pg_nn.Conv2d(c, c, 1), pg_nn.Conv2d(ca, c, 1), pg_nn.Conv2d(c, c, 1)
+    x1, x2, x3 = _rand(n, c, h, w, seed=1), _rand(n, ca, h, w, seed=2), _rand(n, c, h, w, seed=3)
+    g = _rand(n, c, h, w, seed=4)
+    ref_in = [t.clone().requires_grad_(True) for t in (x1, x2, x3)]
+    ref_p = [p.detach().clone().requires_grad_(True) for m in (conv_r, conv_a, conv_o) for p in (m.weight, m.bias)]
+    r = F.elu(F.conv2d(F.elu(ref_in[0]), ref_p[0], ref_p[1]))
+    both = F.elu(F.conv2d(F.elu(ref_in[1]), ref_p[2], ref_p[3])) + r
+    want = F.elu(F.conv2d(F.elu(both), ref_p[4], ref_p[5])) + ref_in[2]
+    want.backward(g)
+    mods = [m.to(dev) for m in (conv_r, conv_a, conv_o)]
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops_conv, "FUSE_DUAL", fused)
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+        xs = [t.to(dev).requires_grad_(True) for t in (x1, x2, x3)]
+        dual = mods[2].dual_ok(xs[0])
+        assert dual == fused, "the 1x1 64 -> 64 data gradient is on the bf16x3 1x1 kernel: the dual epilogue must take it"
+        r_g = mods[0](xs[0], in_act="elu", out_act="elu", out_pre_scaled=dual)
+        if dual:
+            slot = ops.GradSlot()
+            both_g = mods[1](xs[1], in_act="elu", out_act="elu", res=r_g, out_pre_scaled=True, res_slot=slot)
+            out = mods[2](both_g, in_act="elu", out_act="elu", res=xs[2], in_sum=(r_g, slot))
+        else:
+            both_g = mods[1](xs[1], in_act="elu", out_act="elu", res=r_g)
+            out = mods[2](both_g, in_act="elu", out_act="elu", res=xs[2])
+        out.backward(g.to(dev))
+        got[fused] = [out.detach()] + [t.grad for t in xs] + [p.grad.clone() for m in mods for p in (m.weight, m.bias)]
+    want_all = [want.detach()] + [t.grad for t in ref_in] + [p.grad for p in ref_p]
+    names = ["out", "dx1", "dx2", "dx3", "dw_r", "db_r", "dw_a", "db_a", "dw_o", "db_o"]
+    for a, b, what in zip(got[True], want_all, names):
+        _util.assert_close(a, b, TOL, what + " (dual vs torch)")
+    for a, b, what in zip(got[True], got[False], names):
+        _util.assert_close(a, b.cpu(), 5e-6, what + " (dual vs separate kernels)")
+
+
 def test_add_and_broadcast_add(dev):
     from pytorch_generative_amd import ops
 
