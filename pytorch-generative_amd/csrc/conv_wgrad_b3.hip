@@ -410,69 +410,93 @@ struct WrArgs {
   int copy_of[4], q_of[4];     // per tap: its x copy; rows back from the newest ring row (max_dr - dr)
 };
 
-template <int T, int D = 3>
-__global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) {
-  // D = prefetch distance in steps (register sets in flight). A step is short (one row: ~1.5 us of MFMA for the CU's two
-  // workgroups), the loaded-HBM latency is not: with one set in flight the phases added up — ablation on the 2x2 64 -> 64 at
-  // batch 1024 (profiles/r06_wgrad_ring_ablation.txt): launch 282 us = 39 (empty loop + reduce) + 105 loads + 45 commit + 117 MFMA.
+// staging slot kind of slot index k (slots e = tid + 512 k; the dy slots come first): 0 dy, 1 x, 2 none for EVERY thread, or -1 mixed
+// (decided per wave at run time) — compile-time kinds keep the unrolled commit code to the branches that can occur
+constexpr int wr_kind(int k, int dslots, int xslots) {
+  return (k + 1) * 512 <= dslots ? 0 : (k * 512 >= dslots + xslots ? 2 : ((k * 512 >= dslots && (k + 1) * 512 <= dslots + xslots) ? 1 : -1));
+}
+
+// WM x WN = 16-channel dy tiles x ci tiles per WAVE; the 8 waves form a 4 (dy) x 2 (x) grid, so a workgroup owns 64 WM dy channels
+// x 32 WN x channels: (1, 2) = 64 x 64 (two workgroups per CU: the k x k shapes with a row halo), (2, 2) = 128 x 64,
+// (4, 4) = 256 x 128 (one tap: every dy / x row is staged ONCE for GatedPixelCNN's 1x1 128 -> 256; one workgroup per CU).
+// D = prefetch distance in steps (register sets in flight). A step is short (one row: ~1.5 us of MFMA for the CU's two
+// workgroups), the loaded-HBM latency is not.
+template <int T, int WM = 1, int WN = 2, int D = 3>
+__global__ void __launch_bounds__(512, WM == 1 ? 4 : 2) conv_wgrad_b3r_kernel(const WrArgs a) {
+  constexpr int COT = 4 * WM, CIT = 2 * WN;            // channel tiles per workgroup
+  constexpr int DSLOTS = COT * 64, XSLOTS = CIT * 64;  // 8-pixel staging slots per row: [channel tile][4 column blocks][16 channels]
+  constexpr int NS = (DSLOTS + XSLOTS + 511) / 512;    // slots per thread
+  constexpr int DPLANE = COT * 64;                     // entries per dy piece plane
+  constexpr int X_OFF = 3 * DPLANE;                    // first entry of the x area
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 3, wi = wave >> 2;   // dy channel tile; pair of ci tiles
-  const bool is_x = wave >= 4;               // staging role (wave-uniform)
-  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
-  constexpr int DPLANE = 4 * 4 * 16;         // entries per dy piece plane: 4 channel tiles x 4 pixel blocks x 16 channels
-  const int xplane = 4 * a.RB * 4 * 16;      // entries per x (copy, piece) plane: [ci tile][ring row][pixel block][16 channels]
-  // this thread's staging slot: 8 pixels (column block cb) of channel 16 ct + i of the row
-  const int se = tid & 255;
-  const int s_i = se & 15, s_cb = (se >> 4) & 3, s_ct = se >> 6;
-  const int goff = (s_ct * 16 + s_i) * a.H * a.W + 8 * s_cb;
-  const int d_ent = (s_ct * 4 + s_cb) * 16 + s_i;
-  const int x_ent = a.x_off16 + (s_ct * a.RB * 4 + s_cb) * 16 + s_i;   // + ring row * 64
-  float4 v0[D], v1[D];
-  bool ok[D];
+  const int wc = wave & 3, wi = wave >> 2;   // group of WM dy tiles; group of WN ci tiles
+  const int co0 = blockIdx.y * (16 * COT), ci0 = blockIdx.z * (16 * CIT);
+  const int xplane = CIT * a.RB * 64;        // entries per x (copy, piece) plane: [ci tile][ring row][pixel block][16 channels]
+  // this thread's staging slots: 8 pixels (column block cb) of channel 16 ct + i of the row
+  int kind[NS], goff[NS], ent[NS], s_cb[NS];
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    v0[k] = v1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ok[k] = false;
+  for (int k = 0; k < NS; ++k) {
+    const int e = tid + k * 512;
+    constexpr int dsl = DSLOTS, xsl = XSLOTS;
+    const int kc = wr_kind(k, dsl, xsl);
+    kind[k] = kc >= 0 ? kc : __builtin_amdgcn_readfirstlane(e < DSLOTS ? 0 : (e < DSLOTS + XSLOTS ? 1 : 2));  // wave-uniform (multiples of 64)
+    const int el = kind[k] == 1 ? e - DSLOTS : (kind[k] == 0 ? e : 0);
+    const int i = el & 15, cb = (el >> 4) & 3, ct = el >> 6;
+    s_cb[k] = cb;
+    goff[k] = (ct * 16 + i) * a.H * a.W + 8 * cb;
+    ent[k] = kind[k] == 1 ? X_OFF + (ct * a.RB * 4 + cb) * 16 + i : (ct * 4 + cb) * 16 + i;   // x: + ring row * 64
   }
+  float4 v0[D][NS], v1[D][NS];
+  bool ok[D][NS];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      v0[d][k] = v1[d][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ok[d][k] = false;
+    }
 
   // step (unit, s): s in [-P, seg_rows): output row seg * seg_rows + s; the x row staged with it is that row + max_dr
 #define PG_WR_ISSUE(K, UNIT, S)                                                                    \
   {                                                                                                \
     /* UNCONDITIONAL loads straight into set K (a load under `if (ok)` becomes load-to-temporary + select, i.e. a      */ \
     /* s_waitcnt vmcnt right behind the issue: measured, the loads then never overlap the MFMA phase); rows outside the */ \
-    /* image / segment and steps past the workgroup's last are clamped to a valid address and zeroed at commit          */ \
+    /* image / segment, steps past the workgroup's last and unused slots are clamped to a valid address and dropped at  */ \
+    /* commit. Every wave issues the SAME 2 NS loads per set: the compiler's wait in front of a commit is then          */ \
+    /* vmcnt(2 NS (D - 1)) for every wave (with different counts per path it merges them to the smaller one)            */ \
     const int u_ = PG_DBG_BIT(a.dbg, 16) ? 0 : ((UNIT) < a.units ? (UNIT) : a.units - 1);   /* 16: cache-resident loads */ \
     const int n_ = u_ / a.nseg;                                                                    \
     const int row_ = (u_ - n_ * a.nseg) * a.seg_rows + (S);                                        \
-    int go_ = goff;                                                                                \
-    asm volatile("" : "+v"(go_));                                                                  \
-    /* both roles issue the SAME two loads per set: the compiler's wait in front of a commit is then vmcnt(2 (D - 1))  */ \
-    /* for every wave (with different counts per path it merges them to the smaller one)                               */ \
-    const int ir_ = is_x ? row_ + a.max_dr : row_;                                                 \
-    ok[K] = is_x ? (ir_ >= 0 && ir_ < a.H) : (S) >= 0;                                             \
-    const int rc_ = ir_ < 0 ? 0 : (ir_ >= a.H ? a.H - 1 : ir_);                                    \
-    const float* q_ = (is_x ? a.x + ((long)n_ * a.Cin + ci0) * a.H * (long)a.W                     \
-                            : a.dy + ((long)n_ * a.Cout + co0) * a.H * (long)a.W) + (long)rc_ * a.W + go_; \
-    const float4* p_ = reinterpret_cast<const float4*>(q_);                                        \
-    v0[K] = p_[0]; v1[K] = p_[1];                                                                  \
+    _Pragma("unroll") for (int sk_ = 0; sk_ < NS; ++sk_) {  /* (not `k`: the caller passes its own k as K) */                                               \
+      int go_ = goff[sk_];                                                                           \
+      asm volatile("" : "+v"(go_));                                                                \
+      const bool isx_ = kind[sk_] == 1;                                                              \
+      const int ir_ = isx_ ? row_ + a.max_dr : row_;                                               \
+      ok[K][sk_] = kind[sk_] == 2 ? false : (isx_ ? (ir_ >= 0 && ir_ < a.H) : (S) >= 0);               \
+      const int rc_ = ir_ < 0 ? 0 : (ir_ >= a.H ? a.H - 1 : ir_);                                  \
+      const float* q_ = (isx_ ? a.x + ((long)n_ * a.Cin + ci0) * a.H * (long)a.W                   \
+                              : a.dy + ((long)n_ * a.Cout + co0) * a.H * (long)a.W) + (long)rc_ * a.W + go_; \
+      const float4* p_ = reinterpret_cast<const float4*>(q_);                                      \
+      v0[K][sk_] = p_[0]; v1[K][sk_] = p_[1];                                                          \
+    }                                                                                              \
   }
 
-#define PG_WR_COMMIT_X(K, ACT, ROW)                                                                \
+#define PG_WR_COMMIT_X(K, KS, ACT, ROW)                                                            \
   {                                                                                                \
-    const float r_[8] = {v0[K].x, v0[K].y, v0[K].z, v0[K].w, v1[K].x, v1[K].y, v1[K].z, v1[K].w};  \
+    const float r_[8] = {v0[K][KS].x, v0[K][KS].y, v0[K][KS].z, v0[K][KS].w, v1[K][KS].x, v1[K][KS].y, v1[K][KS].z, v1[K][KS].w}; \
     /* the pixel left / right of the slot's 8 = the last / first pixel of the neighbouring column block, which lane   */ \
     /* -+ 16 of this wave holds (ds_bpermute: no memory access; two more vector loads per thread and step measured     */ \
     /* slower — the launch carried ~0.9 us per step of load ISSUE cost even with cache-resident rows)                  */ \
     const float e0_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane - 16) & 63) << 2, __builtin_bit_cast(int, r_[7]))); \
     const float e1_ = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __builtin_bit_cast(int, r_[0]))); \
     float x_[8];                                                                                   \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = ok[K] ? pg_apply_act(r_[c], ACT) : 0.f;  \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = ok[K][KS] ? pg_apply_act(r_[c], ACT) : 0.f; \
     u32x4 p_[3];                                                                                   \
     split8(x_, p_[0], p_[1], p_[2]);                                                               \
-    const int ent_ = x_ent + (ROW) * 64;                                                           \
+    const int ent_ = ent[KS] + (ROW) * 64;                                                         \
     _Pragma("unroll") for (int v = 0; v < 3; ++v) {                                                \
       if (v < a.ndc) {                                                                             \
         const int dc_ = a.dcs[v];                                                                  \
@@ -481,8 +505,8 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
           _Pragma("unroll") for (int q = 0; q < 3; ++q) dst_[q * xplane] = p_[q];                  \
         } else {                                                                                   \
           unsigned int s_[3];                                                                      \
-          const bool edge_ = dc_ < 0 ? s_cb == 0 : s_cb == 3;                                      \
-          split1(ok[K] && !edge_ ? pg_apply_act(dc_ < 0 ? e0_ : e1_, ACT) : 0.f, s_[0], s_[1], s_[2]); \
+          const bool edge_ = dc_ < 0 ? s_cb[KS] == 0 : s_cb[KS] == 3;                              \
+          split1(ok[K][KS] && !edge_ ? pg_apply_act(dc_ < 0 ? e0_ : e1_, ACT) : 0.f, s_[0], s_[1], s_[2]); \
           _Pragma("unroll") for (int q = 0; q < 3; ++q)                                            \
             dst_[q * xplane] = dc_ < 0 ? shift_right1(p_[q], s_[q]) : shift_left1(p_[q], s_[q]);   \
         }                                                                                          \
@@ -491,21 +515,25 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
   }
 #define PG_WR_ADVANCE(U, S) { (S) += 1; if ((S) == a.seg_rows) { (U) += (int)gridDim.x; (S) = -a.P; } }
 
-  f32x4 acc[2][T];
-  f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[WM][WN][T];
+  f32x4 accb[WM];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int m = 0; m < WM; ++m) {
+    accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[m][j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const bool bias_wave = a.has_bias && wi == 0 && blockIdx.z == 0;  // wave-uniform
   bf16x8 ones;
 #pragma unroll
   for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.0f;
   const bf16x8* L = reinterpret_cast<const bf16x8*>(lds16) + lane;
-  const int a_base = wc * 64;
+  const int a_base = wc * WM * 64;
   int b_copy[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) b_copy[t] = a.x_off16 + a.copy_of[t] * 3 * xplane + wi * 2 * a.RB * 64;
+  for (int t = 0; t < T; ++t) b_copy[t] = X_OFF + a.copy_of[t] * 3 * xplane + wi * WN * a.RB * 64;
 
   int unit = blockIdx.x, s = -a.P;   // the step being committed / multiplied
   int unit_i = unit, s_i2 = s;       // the step whose loads are issued next (D steps ahead)
@@ -521,35 +549,45 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
       if (unit >= a.units) break;
       __syncthreads();  // the previous step's fragment reads are done
       // every register of THIS set is "used" here: one counted s_waitcnt vmcnt at this point (the younger sets stay in flight)
-      asm volatile("" :: "v"(v0[k].x), "v"(v0[k].y), "v"(v0[k].z), "v"(v0[k].w), "v"(v1[k].x), "v"(v1[k].y), "v"(v1[k].z),
-                         "v"(v1[k].w));
-      if (PG_DBG_BIT(a.dbg, 2)) {
-      } else if (!is_x) {
-        if (s >= 0) {
-          const float r[8] = {v0[k].x, v0[k].y, v0[k].z, v0[k].w, v1[k].x, v1[k].y, v1[k].z, v1[k].w};
-          u32x4 h, m, l;
-          split8(r, h, m, l);
-          u32x4* dst = lds16 + d_ent;
-          dst[0] = h; dst[DPLANE] = m; dst[2 * DPLANE] = l;
-        }
-      } else {
-        switch (a.in_act) {  // wave-uniform
-          case PG_ACT_RELU: PG_WR_COMMIT_X(k, PG_ACT_RELU, rb) break;
-          case PG_ACT_ELU:  PG_WR_COMMIT_X(k, PG_ACT_ELU, rb) break;
-          case PG_ACT_GELU: PG_WR_COMMIT_X(k, PG_ACT_GELU, rb) break;
-          default:          PG_WR_COMMIT_X(k, PG_ACT_NONE, rb) break;
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+        asm volatile("" :: "v"(v0[k][ks].x), "v"(v0[k][ks].y), "v"(v0[k][ks].z), "v"(v0[k][ks].w), "v"(v1[k][ks].x), "v"(v1[k][ks].y),
+                           "v"(v1[k][ks].z), "v"(v1[k][ks].w));
+      if (!PG_DBG_BIT(a.dbg, 2)) {
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+          if (kind[ks] == 0) {
+            if (s >= 0) {
+              const float r[8] = {v0[k][ks].x, v0[k][ks].y, v0[k][ks].z, v0[k][ks].w, v1[k][ks].x, v1[k][ks].y, v1[k][ks].z, v1[k][ks].w};
+              u32x4 h, m, l;
+              split8(r, h, m, l);
+              u32x4* dst = lds16 + ent[ks];
+              dst[0] = h; dst[DPLANE] = m; dst[2 * DPLANE] = l;
+            }
+          } else if (kind[ks] == 1) {
+            switch (a.in_act) {  // wave-uniform
+              case PG_ACT_RELU: PG_WR_COMMIT_X(k, ks, PG_ACT_RELU, rb) break;
+              case PG_ACT_ELU:  PG_WR_COMMIT_X(k, ks, PG_ACT_ELU, rb) break;
+              case PG_ACT_GELU: PG_WR_COMMIT_X(k, ks, PG_ACT_GELU, rb) break;
+              default:          PG_WR_COMMIT_X(k, ks, PG_ACT_NONE, rb) break;
+            }
+          }
         }
       }
       __syncthreads();
       if (!PG_DBG_BIT(a.dbg, 1)) PG_WR_ISSUE(k, unit_i, s_i2)
       PG_WR_ADVANCE(unit_i, s_i2)
       if (s >= 0 && !PG_DBG_BIT(a.dbg, 4)) {
-        bf16x8 af[3];
+        bf16x8 af[WM][3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[p] = L[a_base + p * DPLANE];
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) af[m][p] = L[a_base + m * 64 + p * DPLANE];
         if (bias_wave) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) accb = MFMA16B(af[p], ones, accb);
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) accb[m] = MFMA16B(af[m][p], ones, accb[m]);
         }
         // B fragments of group g = (tap, ci tile) are requested one group ahead of their MFMAs
         const bf16x8* Lb[T];
@@ -563,20 +601,23 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
 #pragma unroll
         for (int p = 0; p < 3; ++p) bf[0][p] = Lb[0][p * xplane];
 #pragma unroll
-        for (int g = 0; g < 2 * T; ++g) {
-          const int t = g >> 1, j = g & 1;
-          if (g + 1 < 2 * T) {
+        for (int g = 0; g < WN * T; ++g) {
+          const int t = g / WN, j = g % WN;
+          if (g + 1 < WN * T) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[(g + 1) & 1][p] = Lb[(g + 1) >> 1][((g + 1) & 1) * a.RB * 64 + p * xplane];
+            for (int p = 0; p < 3; ++p) bf[(g + 1) & 1][p] = Lb[(g + 1) / WN][((g + 1) % WN) * a.RB * 64 + p * xplane];
           }
-          f32x4 c = acc[j][t];
-          c = MFMA16B(af[2], bf[g & 1][0], c);  // l.h
-          c = MFMA16B(af[0], bf[g & 1][2], c);  // h.l
-          c = MFMA16B(af[1], bf[g & 1][1], c);  // m.m
-          c = MFMA16B(af[1], bf[g & 1][0], c);  // m.h
-          c = MFMA16B(af[0], bf[g & 1][1], c);  // h.m
-          c = MFMA16B(af[0], bf[g & 1][0], c);  // h.h
-          acc[j][t] = c;
+#pragma unroll
+          for (int m = 0; m < WM; ++m) {
+            f32x4 c = acc[m][j][t];
+            c = MFMA16B(af[m][2], bf[g & 1][0], c);  // l.h
+            c = MFMA16B(af[m][0], bf[g & 1][2], c);  // h.l
+            c = MFMA16B(af[m][1], bf[g & 1][1], c);  // m.m
+            c = MFMA16B(af[m][1], bf[g & 1][0], c);  // m.h
+            c = MFMA16B(af[m][0], bf[g & 1][1], c);  // h.m
+            c = MFMA16B(af[m][0], bf[g & 1][0], c);  // h.h
+            acc[m][j][t] = c;
+          }
         }
       }
       PG_WR_ADVANCE(unit, s)
@@ -589,18 +630,21 @@ __global__ void __launch_bounds__(512, 4) conv_wgrad_b3r_kernel(const WrArgs a) 
 
   // ---- this workgroup's row of partial sums: D[row = (lane >> 4) * 4 + r][col = lane & 15]
   float* prow = a.part + (size_t)blockIdx.x * a.part_stride;
-  const int co_b = co0 + wc * 16 + (lane >> 4) * 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int ci = ci0 + (wi * 2 + j) * 16 + (lane & 15);
+  for (int m = 0; m < WM; ++m) {
+    const int co_b = co0 + (wc * WM + m) * 16 + (lane >> 4) * 4;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int j = 0; j < WN; ++j) {
+      const int ci = ci0 + (wi * WN + j) * 16 + (lane & 15);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) prow[((size_t)(co_b + r) * a.Cin + ci) * T + t] = acc[j][t][r];
-  }
-  if (bias_wave && (lane & 15) == 0) {
+      for (int t = 0; t < T; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) prow[(size_t)a.Cout * a.Cin * T + co_b + r] = accb[r];
+        for (int r = 0; r < 4; ++r) prow[((size_t)(co_b + r) * a.Cin + ci) * T + t] = acc[m][j][t][r];
+    }
+    if (bias_wave && (lane & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) prow[(size_t)a.Cout * a.Cin * T + co_b + r] = accb[m][r];
+    }
   }
 }
 
@@ -888,19 +932,36 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   for (int v = a.ndc; v < 3; ++v) a.dcs[v] = 0;
   const int hr = max_dr - min_dr;
   const int PBR = (OW + 7) / 8;  // W % 8 == 4: the last pixel block of a row is half full
-  // row-ring kernel (round 6; PG_WGRAD_B3_RING=0 for A/B): 32-pixel rows, 64 x 64 channels, a row halo or three taps
+  // row-ring kernel (round 6; PG_WGRAD_B3_RING=0 for A/B): 32-pixel rows; wave tiles (WM x WN 16-channel tiles) by shape:
+  //   (1, 2) = 64 x 64 per workgroup, two workgroups per CU: the shapes with a row halo or three taps;
+  //   (2, 2) = 128 x 64 when Cout % 128 == 0: dy AND x of a 64 -> 128 layer staged once;
+  //   (4, 4) = 256 x 128 for one tap (GatedPixelCNN's 1x1 128 -> 256 / 256 -> 256), one workgroup per CU.
+  // PG_WGRAD_B3_RING_CFG=<WM><WN> forces a tile in the ab library.
   static const bool ring_on = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_RING"); return !(e && e[0] == '0'); }();
-  if (ring_on && OW == 32 && Cout % 64 == 0 && Cin % 64 == 0 && T >= 2 && T <= 4 && (hr >= 1 || T == 3) && hr <= 2) {
+  static const int ring_cfg = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_RING_CFG"); return e ? atoi(e) : 0; }();
+  if (ring_on && OW == 32 && Cout % 64 == 0 && Cin % 64 == 0 && T >= (ring_cfg ? 1 : 2) && T <= 4 && hr <= 2) {
+    // measured (tools/exp/r06_ring_cfg_sweep.sh, profiles/r06_wgrad_ring_cfg_sweep.txt; ms, tiles 64x64 / 128x64 / 256x64 / old kernel):
+    //   2x2 64->128 b1024 0.537 / 0.496 / - / 0.641;  2x1 256->256 b512 1.226 / 1.140 / 0.953 / 1.247;  1x3 128->256 0.896 / 0.840 / - / 1.010;
+    //   1x2 128->256 0.719 / 0.652 / 0.840 / 0.684;  2x1 128->256 0.664 / 0.608 / 0.791 / 0.683.
+    // One tap stays on the old 128 x 64 big-tile kernel (two workgroups per CU): 1x1 128->256 0.355 against 0.540 / 0.491 / 0.372 /
+    // 0.446 (256 x 128) here — the larger tiles run ONE workgroup per CU (148-238 registers) and lose its phase overlap.
+    int WM = 1, WN = 2;
+    if (T == 2 && Cout % 256 == 0 && Cin % 256 == 0) { WM = 4; WN = 2; }
+    else if (Cout % 128 == 0) { WM = 2; WN = 2; }
+    if (ring_cfg) { WM = ring_cfg / 10; WN = ring_cfg % 10; }
+    const bool cfg_ok = (WM == 1 && WN == 2) || (WM == 2 && WN == 2) || (WM == 4 && WN == 4 && T == 1) || (WM == 4 && WN == 2 && T <= 2);
+    const bool shape_ok = cfg_ok && Cout % (64 * WM) == 0 && Cin % (32 * WN) == 0;
     WrArgs r;
     r.ndc = a.ndc;
     for (int v = 0; v < 3; ++v) r.dcs[v] = a.dcs[v];
     r.RB = hr + 1; r.P = hr; r.max_dr = max_dr;
-    const int xplane = 4 * r.RB * 64;
-    r.x_off16 = 3 * 256;
-    const size_t shmem = ((size_t)r.x_off16 + (size_t)r.ndc * 3 * xplane) * 16;
-    if (shmem <= (size_t)WB_LDS_BUDGET) {
+    const int dplane = 4 * WM * 64, xplane = 2 * WN * r.RB * 64;
+    const size_t shmem = ((size_t)3 * dplane + (size_t)r.ndc * 3 * xplane) * 16;
+    const bool one_wg = WM > 1;   // the kernel's launch bounds: two waves per SIMD (one 8-wave workgroup per CU)
+    if (shape_ok && shmem <= (one_wg ? (size_t)150 * 1024 : (size_t)WB_LDS_BUDGET)) {
       r.x = x; r.dy = dy; r.part = part; r.part_stride = part_stride;
       r.N = N; r.Cin = Cin; r.Cout = Cout; r.H = OH; r.W = OW; r.T = T;
+      r.x_off16 = 3 * dplane;
       r.in_act = in_act; r.has_bias = has_bias;
 #ifdef PG_ABLATE
       { const char* e = getenv("PG_WB_DBG"); r.dbg = e ? atoi(e) : 0; }
@@ -911,8 +972,8 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
         r.copy_of[t] = t < T ? copy_of[t] : 0;
         r.q_of[t] = t < T ? max_dr - tap_dr[t] : 0;
       }
-      const int co_chunks = Cout / 64, ci_chunks = Cin / 64;
-      long G = 512 / ((long)co_chunks * ci_chunks);
+      const int co_chunks = Cout / (64 * WM), ci_chunks = Cin / (32 * WN);
+      long G = (one_wg ? 256 : 512) / ((long)co_chunks * ci_chunks);
       if (G < 16) G = 16;
       // work units = (image, segment of rows): whole images when there are enough of them, otherwise segments of >= 8 rows
       // (every segment starts with hr x-only steps)
@@ -922,11 +983,26 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
       if (G > r.units) G = r.units;
       if (G > max_rows) G = max_rows;
       dim3 grid((unsigned)G, (unsigned)co_chunks, (unsigned)ci_chunks);
-      switch (T) {
-        case 2: hipLaunchKernelGGL((conv_wgrad_b3r_kernel<2>), grid, dim3(512), shmem, st, r); break;
-        case 3: hipLaunchKernelGGL((conv_wgrad_b3r_kernel<3>), grid, dim3(512), shmem, st, r); break;
-        default: hipLaunchKernelGGL((conv_wgrad_b3r_kernel<4>), grid, dim3(512), shmem, st, r); break;
-      }
+#define PG_WR_LAUNCH(TT, M_, N_)                                                                                  \
+  {                                                                                                               \
+    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_b3r_kernel<TT, M_, N_>), \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  \
+    if (attr_ != hipSuccess) return -1;                                                                           \
+    hipLaunchKernelGGL((conv_wgrad_b3r_kernel<TT, M_, N_>), grid, dim3(512), shmem, st, r);                       \
+  }
+#define PG_WR_BY_T(M_, N_)                                         \
+  switch (T) {                                                     \
+    case 1: PG_WR_LAUNCH(1, M_, N_) break;                         \
+    case 2: PG_WR_LAUNCH(2, M_, N_) break;                         \
+    case 3: PG_WR_LAUNCH(3, M_, N_) break;                         \
+    default: PG_WR_LAUNCH(4, M_, N_) break;                        \
+  }
+      if (WM == 4 && WN == 4) PG_WR_LAUNCH(1, 4, 4)
+      else if (WM == 4) { if (T == 1) PG_WR_LAUNCH(1, 4, 2) else PG_WR_LAUNCH(2, 4, 2) }
+      else if (WM == 2) PG_WR_BY_T(2, 2)
+      else PG_WR_BY_T(1, 2)
+#undef PG_WR_BY_T
+#undef PG_WR_LAUNCH
       if (hipGetLastError() != hipSuccess) return -1;
       return (int)G;
     }

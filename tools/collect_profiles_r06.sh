@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 MODE=${1:-pmc}
 if [ "$MODE" = "stats" ]; then
-  for spec in image_gpt:1024 image_gpt:64 pixel_snail:1024 pixel_cnn:1024 gated_pixel_cnn:512 pixel_cnn_pp:64 beta_vae:1024 vd_vae:512; do
+  for spec in ${SPECS:-image_gpt:1024 image_gpt:64 pixel_snail:1024 pixel_cnn:1024 gated_pixel_cnn:512 pixel_cnn_pp:64 beta_vae:1024 vd_vae:512}; do
     M=${spec%%:*}; B=${spec##*:}; TAG=$M; [ "$spec" = "image_gpt:64" ] && TAG=image_gpt_b64
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o p -- \
       python $R/bench.py --model $M --steps 10 --warmup 3 --batch $B --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1 || echo "[$TAG] rc=$?"

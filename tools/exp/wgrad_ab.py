@@ -21,6 +21,9 @@ CASES = [
     ("gated 1x2 128->256 b512", 512, 128, 256, 32, (1, 2, 0, 1)),
     ("gated 2x3 128->256 b512", 512, 128, 256, 32, (2, 3, 1, 1)),
     ("gated 1x1 128->256 b512", 512, 128, 256, 32, (1, 1, 0, 0)),
+    ("gated 1x1 256->256 b512", 512, 256, 256, 32, (1, 1, 0, 0)),
+    ("snail 1x1 64->64 b1024", 1024, 64, 64, 32, (1, 1, 0, 0)),
+    ("gated 2x1 128->256 b512", 512, 128, 256, 32, (2, 1, 2, 0)),
     ("pcnnpp 2x2 320->320 16x16 b64", 64, 320, 320, 16, (2, 2, 1, 1)),
 ]
 SEL = sys.argv[1:]

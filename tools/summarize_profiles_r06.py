@@ -57,10 +57,11 @@ json.dump({"what": "ImageGPT's attention kernels (4 heads, d_k = d_v = 4, L = 78
           open(os.path.join(dst, "r06_traffic.json"), "w"), indent=1)
 
 act = lambda n, c: n * c * 32 * 32 * 4  # noqa: E731
-wg = dict([rec("conv_wgrad_b3_kernel<4, 2, 8, 2>", act(1024, 64) * 2, 64 * 64 * 4 * 4, 2.0 * 1024 * 1024 * 64 * 64 * 4),
+wg = dict([rec("conv_wgrad_b3r_kernel<4", act(1024, 64) * 2, 64 * 64 * 4 * 4, 2.0 * 1024 * 1024 * 64 * 64 * 4),
            rec("conv_wgrad_b3_kernel<1, 4, 8, 4>", act(512, 128) + act(512, 256), 128 * 256 * 4, 2.0 * 512 * 1024 * 128 * 256),
            rec("conv_wgrad_b3_kernel<6, 2, 4, 2>", act(512, 128) + act(512, 256), 128 * 256 * 6 * 4, 2.0 * 512 * 1024 * 128 * 256 * 6)])
-json.dump({"what": "bf16x3 weight-gradient kernels: 2x2 64->64 at batch 1024 (PixelSNAIL, <4, 2, 8>), 1x1 128->256 (<1, 4, 8, 4>: the 128 x 64 tile) and "
+json.dump({"what": "bf16x3 weight-gradient kernels: 2x2 64->64 at batch 1024 (PixelSNAIL; the row-ring kernel conv_wgrad_b3r_kernel<4, 3> — the record of "
+                   "conv_wgrad_b3_kernel<4, 2, 8, 2> it replaced is profiles/r06_wgrad_pmc_before_ring.json), 1x1 128->256 (<1, 4, 8, 4>: the 128 x 64 tile) and "
                    "2x3 128->256 (<6, 2, 4>) at batch 512 (GatedPixelCNN), 32x32 images, 3 launches each (tools/exp/pmc_launch.py); "
                    "algorithmic bytes = x and dy read once; writes = the partial rows (reduced by wgrad_reduce_kernel)",
            "calibration": calib, "kernels": wg}, open(os.path.join(dst, "r06_wgrad_pmc.json"), "w"), indent=1)
@@ -71,7 +72,7 @@ json.dump({"what": "PixelSNAIL's dominant convolution (2x2 64->64, ELU prologue,
           open(os.path.join(dst, "r06_snail_conv_pmc.json"), "w"), indent=1)
 # round 6: the overlapped 16-wave kernel on the shape it is routed for, and the wide kernel on GatedPixelCNN's 2x1 / 1x1 256 -> 256
 qk = dict([rec("conv_b3q_kernel", act(64, 160), act(64, 320), 2.0 * 64 * 1024 * 160 * 320 * 6),  # five output chunks each stage x: what L2 does not catch shows as traffic
-           rec("conv_b3_kernel<false, 4, 4, 2, false, false>", act(512, 256), act(512, 256), None)])
+           rec("conv_b3_kernel<false, 4, 4, 2, false, false, false>", act(512, 256), act(512, 256), None)])
 json.dump({"what": "conv_b3q_kernel (16 waves, two tiles per workgroup) on PixelCNN++'s 2x3 160->320 at batch 64, and the wide kernel's "
                    "launches of the same pass (GatedPixelCNN's 1x1 and 2x1 256->256 at batch 512 share the instantiation: per-dispatch "
                    "means over both), round-6 library; algorithmic bytes: x read once, out written once",
