@@ -445,7 +445,7 @@ def conv_kernel_roofline(batch, device, cin=64, cout=64, hw=32):
 
 
 def wgrad_kernel_roofline(batch, device, cin=64, cout=64, hw=32, k=(2, 2, 1, 1)):
-    """The weight gradient of the same 2x2 64 -> 64 convolution (conv_wgrad_b3_kernel<4> +
+    """The weight gradient of the same 2x2 64 -> 64 convolution (conv_wgrad_b3r_kernel<4, 1, 2>, the row-ring kernel of round 6, +
     wgrad_reduce_kernel behind pg_conv2d_wgrad), timed through the C-ABI with HIP events.
     k = (kh, kw, pad_h, pad_w) selects another window (profiling helper: tools/exp/pmc_launch.py)."""
     from pytorch_generative_amd import _lib, ops
@@ -1037,7 +1037,7 @@ def main():
                     "traffic": snail_traffic,
                     "traffic_source": snail_src,
                     "traffic_algorithmic": 2.0 * args.snail_batch * 64 * 32 * 32 * 4,
-                    "other_kernels": {"conv_wgrad_b3_kernel<4> + wgrad_reduce_kernel": w,
+                    "other_kernels": {"conv_wgrad_b3r_kernel<4, 1, 2> (row ring) + wgrad_reduce_kernel": w,
                                       "attn_fwd_k4_kernel": a["fwd"],
                                       "attn_delta_k4 + attn_bwd_k4_kernel (fused backward)": a.get("bwd"),
                                       "two_kernel_backward (pg_attn_fused_bwd(0) = ops.set_deterministic)": {"attn_dq_k4_kernel": a["dq"],

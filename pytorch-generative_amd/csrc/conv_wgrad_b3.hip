@@ -421,6 +421,8 @@ constexpr int wr_kind(int k, int dslots, int xslots) {
 // (4, 4) = 256 x 128 (one tap: every dy / x row is staged ONCE for GatedPixelCNN's 1x1 128 -> 256; one workgroup per CU).
 // D = prefetch distance in steps (register sets in flight). A step is short (one row: ~1.5 us of MFMA for the CU's two
 // workgroups), the loaded-HBM latency is not.
+// (128 x 64 tiles with two taps fit 123 registers with D = 2, i.e. two workgroups per CU: measured no faster — 0.949 / 0.669 / 0.631 ms
+// against 0.952 / 0.653 / 0.613 on GatedPixelCNN's 2x1 256->256 / 1x2 128->256 / 2x1 128->256 — and dropped)
 template <int T, int WM = 1, int WN = 2, int D = 3>
 __global__ void __launch_bounds__(512, WM == 1 ? 4 : 2) conv_wgrad_b3r_kernel(const WrArgs a) {
   constexpr int COT = 4 * WM, CIT = 2 * WN;            // channel tiles per workgroup
