@@ -407,7 +407,7 @@ struct WrArgs {
   int x_off16;                 // first 16-byte entry of the x area
   int in_act, has_bias;
   int dbg;                     // ablation switches (PG_WB_DBG: 1 no loads, 2 no commit, 4 no MFMA, 8 no fragment reads either), 0 in production
-  int copy_of[4], q_of[4];     // per tap: its x copy; rows back from the newest ring row (max_dr - dr)
+  int copy_of[6], q_of[6];     // per tap: its x copy; rows back from the newest ring row (max_dr - dr)
 };
 
 // staging slot kind of slot index k (slots e = tid + 512 k; the dy slots come first): 0 dy, 1 x, 2 none for EVERY thread, or -1 mixed
@@ -941,7 +941,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   // PG_WGRAD_B3_RING_CFG=<WM><WN> forces a tile in the ab library.
   static const bool ring_on = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_RING"); return !(e && e[0] == '0'); }();
   static const int ring_cfg = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_RING_CFG"); return e ? atoi(e) : 0; }();
-  if (ring_on && OW == 32 && Cout % 64 == 0 && Cin % 64 == 0 && T >= (ring_cfg ? 1 : 2) && T <= 4 && hr <= 2) {
+  if (ring_on && OW == 32 && Cout % 64 == 0 && Cin % 64 == 0 && T >= (ring_cfg ? 1 : 2) && (T <= 4 || T == 6) && hr <= 2) {
     // measured (tools/exp/r06_ring_cfg_sweep.sh, profiles/r06_wgrad_ring_cfg_sweep.txt; ms, tiles 64x64 / 128x64 / 256x64 / old kernel):
     //   2x2 64->128 b1024 0.537 / 0.496 / - / 0.641;  2x1 256->256 b512 1.226 / 1.140 / 0.953 / 1.247;  1x3 128->256 0.896 / 0.840 / - / 1.010;
     //   1x2 128->256 0.719 / 0.652 / 0.840 / 0.684;  2x1 128->256 0.664 / 0.608 / 0.791 / 0.683.
@@ -949,9 +949,9 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
     // 0.446 (256 x 128) here — the larger tiles run ONE workgroup per CU (148-238 registers) and lose its phase overlap.
     int WM = 1, WN = 2;
     if (T == 2 && Cout % 256 == 0 && Cin % 256 == 0) { WM = 4; WN = 2; }
-    else if (Cout % 128 == 0) { WM = 2; WN = 2; }
+    else if (Cout % 128 == 0 && T <= 4) { WM = 2; WN = 2; }
     if (ring_cfg) { WM = ring_cfg / 10; WN = ring_cfg % 10; }
-    const bool cfg_ok = (WM == 1 && WN == 2) || (WM == 2 && WN == 2) || (WM == 4 && WN == 4 && T == 1) || (WM == 4 && WN == 2 && T <= 2);
+    const bool cfg_ok = (WM == 1 && WN == 2) || (WM == 2 && WN == 2 && T <= 4) || (WM == 4 && WN == 4 && T == 1) || (WM == 4 && WN == 2 && T <= 2);
     const bool shape_ok = cfg_ok && Cout % (64 * WM) == 0 && Cin % (32 * WN) == 0;
     WrArgs r;
     r.ndc = a.ndc;
@@ -959,7 +959,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
     r.RB = hr + 1; r.P = hr; r.max_dr = max_dr;
     const int dplane = 4 * WM * 64, xplane = 2 * WN * r.RB * 64;
     const size_t shmem = ((size_t)3 * dplane + (size_t)r.ndc * 3 * xplane) * 16;
-    const bool one_wg = WM > 1;   // the kernel's launch bounds: two waves per SIMD (one 8-wave workgroup per CU)
+    const bool one_wg = WM > 1 || shmem > (size_t)WB_LDS_BUDGET;   // the kernel's launch bounds / an LDS footprint above half a CU: two waves per SIMD (one 8-wave workgroup per CU)
     if (shape_ok && shmem <= (one_wg ? (size_t)150 * 1024 : (size_t)WB_LDS_BUDGET)) {
       r.x = x; r.dy = dy; r.part = part; r.part_stride = part_stride;
       r.N = N; r.Cin = Cin; r.Cout = Cout; r.H = OH; r.W = OW; r.T = T;
@@ -970,7 +970,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
 #else
       r.dbg = 0;
 #endif
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < 6; ++t) {
         r.copy_of[t] = t < T ? copy_of[t] : 0;
         r.q_of[t] = t < T ? max_dr - tap_dr[t] : 0;
       }
@@ -1002,6 +1002,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
       if (WM == 4 && WN == 4) PG_WR_LAUNCH(1, 4, 4)
       else if (WM == 4) { if (T == 1) PG_WR_LAUNCH(1, 4, 2) else PG_WR_LAUNCH(2, 4, 2) }
       else if (WM == 2) PG_WR_BY_T(2, 2)
+      else if (T == 6) PG_WR_LAUNCH(6, 1, 2)
       else PG_WR_BY_T(1, 2)
 #undef PG_WR_BY_T
 #undef PG_WR_LAUNCH

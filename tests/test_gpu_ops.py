@@ -60,6 +60,10 @@ CONV_CASES = [
     (1, 128, 32, 32, 64, 2, 1, 2, 0, "hw", None, "relu", True, True),    # 2x1: two taps, one copy, two ci chunks
     (2, 64, 32, 32, 128, 1, 3, 0, 1, None, None, None, False, True),     # 1x3: three copies, no halo (ring of one row), two co chunks
     (20, 64, 32, 32, 64, 2, 2, 1, 1, "hw", None, None, False, False),    # 20 images: whole-image units + segments, no bias
+    (3, 128, 32, 32, 64, 2, 3, 1, 1, "hw", None, "relu", True, True),    # 2x3: six taps, three copies, 84 KB ring (one workgroup per CU)
+    (2, 64, 32, 32, 64, 3, 3, 1, 1, None, "A", None, False, True),       # masked 3x3 type A: four taps over three column copies
+    (2, 128, 32, 32, 256, 2, 1, 2, 0, "hw", None, None, False, True),    # two taps: 128 x 64 wave tiles, two ci chunks
+    (2, 256, 32, 32, 256, 1, 2, 0, 1, "hw", None, "elu", False, True),   # two taps 256 -> 256: the 256 x 64 tile
     # round 6: the overlapped 16-wave kernel (conv_b3q_kernel.h), two tiles per workgroup sharing one weight slab: 6 taps with >= 256
     # channels on one side (PixelCNN++'s 2x3 convolutions); odd batch = an idle half in the last round, Cout % 64 != 0 = a partial chunk
     (3, 320, 32, 32, 160, 2, 3, 1, 1, "hw", None, None, False, True),    # forward on Q (Cin 320), data gradient 160 -> 320 on Q too
