@@ -423,8 +423,8 @@ constexpr int wr_kind(int k, int dslots, int xslots) {
 // workgroups), the loaded-HBM latency is not.
 // (128 x 64 tiles with two taps fit 123 registers with D = 2, i.e. two workgroups per CU: measured no faster — 0.949 / 0.669 / 0.631 ms
 // against 0.952 / 0.653 / 0.613 on GatedPixelCNN's 2x1 256->256 / 1x2 128->256 / 2x1 128->256 — and dropped)
-template <int T, int WM = 1, int WN = 2, int D = 3>
-__global__ void __launch_bounds__(512, WM == 1 ? 4 : 2) conv_wgrad_b3r_kernel(const WrArgs a) {
+template <int T, int WM = 1, int WN = 2, int D = ((WM == 2 && WN == 4) ? 2 : 3)>
+__global__ void __launch_bounds__(512, (WM == 1 || (WM == 2 && WN == 4)) ? 4 : 2) conv_wgrad_b3r_kernel(const WrArgs a) {
   constexpr int COT = 4 * WM, CIT = 2 * WN;            // channel tiles per workgroup
   constexpr int DSLOTS = COT * 64, XSLOTS = CIT * 64;  // 8-pixel staging slots per row: [channel tile][4 column blocks][16 channels]
   constexpr int NS = (DSLOTS + XSLOTS + 511) / 512;    // slots per thread
@@ -941,17 +941,22 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
   // PG_WGRAD_B3_RING_CFG=<WM><WN> forces a tile in the ab library.
   static const bool ring_on = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_RING"); return !(e && e[0] == '0'); }();
   static const int ring_cfg = []() { const char* e = PG_AB_ENV("PG_WGRAD_B3_RING_CFG"); return e ? atoi(e) : 0; }();
-  if (ring_on && OW == 32 && Cout % 64 == 0 && Cin % 64 == 0 && T >= (ring_cfg ? 1 : 2) && (T <= 4 || T == 6) && hr <= 2) {
+  const bool ring_one_tap = T == 1 && Cout % 128 == 0 && Cin % 128 == 0;  // 128 x 128 tiles, two workgroups per CU: 0.357 / 0.672 ms against the
+                                                                          // big-tile kernel's 0.366 / 0.702 on 1x1 128->256 / 256->256 at batch 512
+  if (ring_on && OW == 32 && Cout % 64 == 0 && Cin % 64 == 0 && (T >= 2 || ring_one_tap || ring_cfg) && (T <= 4 || T == 6) && hr <= 2) {
     // measured (tools/exp/r06_ring_cfg_sweep.sh, profiles/r06_wgrad_ring_cfg_sweep.txt; ms, tiles 64x64 / 128x64 / 256x64 / old kernel):
     //   2x2 64->128 b1024 0.537 / 0.496 / - / 0.641;  2x1 256->256 b512 1.226 / 1.140 / 0.953 / 1.247;  1x3 128->256 0.896 / 0.840 / - / 1.010;
     //   1x2 128->256 0.719 / 0.652 / 0.840 / 0.684;  2x1 128->256 0.664 / 0.608 / 0.791 / 0.683.
-    // One tap stays on the old 128 x 64 big-tile kernel (two workgroups per CU): 1x1 128->256 0.355 against 0.540 / 0.491 / 0.372 /
-    // 0.446 (256 x 128) here — the larger tiles run ONE workgroup per CU (148-238 registers) and lose its phase overlap.
+    // One tap: 1x1 128->256 on the old 128 x 64 big-tile kernel (two workgroups per CU) 0.355 against 0.540 / 0.491 / 0.372 / 0.446 (256 x 128)
+    // here — the larger tiles run ONE workgroup per CU (148-238 registers) and lose its phase overlap; only the 128 x 128 tile at two register
+    // sets (124 registers, two workgroups per CU) is level with it (0.357) and reads less, so it takes the shapes it divides.
     int WM = 1, WN = 2;
-    if (T == 2 && Cout % 256 == 0 && Cin % 256 == 0) { WM = 4; WN = 2; }
+    if (ring_one_tap) { WM = 2; WN = 4; }
+    else if (T == 2 && Cout % 256 == 0 && Cin % 256 == 0) { WM = 4; WN = 2; }
     else if (Cout % 128 == 0 && T <= 4) { WM = 2; WN = 2; }
     if (ring_cfg) { WM = ring_cfg / 10; WN = ring_cfg % 10; }
-    const bool cfg_ok = (WM == 1 && WN == 2) || (WM == 2 && WN == 2 && T <= 4) || (WM == 4 && WN == 4 && T == 1) || (WM == 4 && WN == 2 && T <= 2);
+    const bool cfg_ok = (WM == 1 && WN == 2) || (WM == 2 && WN == 2 && T <= 4) || (WM == 4 && WN == 4 && T == 1) || (WM == 4 && WN == 2 && T <= 2) ||
+                        (WM == 2 && WN == 4 && T == 1);
     const bool shape_ok = cfg_ok && Cout % (64 * WM) == 0 && Cin % (32 * WN) == 0;
     WrArgs r;
     r.ndc = a.ndc;
@@ -959,7 +964,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
     r.RB = hr + 1; r.P = hr; r.max_dr = max_dr;
     const int dplane = 4 * WM * 64, xplane = 2 * WN * r.RB * 64;
     const size_t shmem = ((size_t)3 * dplane + (size_t)r.ndc * 3 * xplane) * 16;
-    const bool one_wg = WM > 1 || shmem > (size_t)WB_LDS_BUDGET;   // the kernel's launch bounds / an LDS footprint above half a CU: two waves per SIMD (one 8-wave workgroup per CU)
+    const bool one_wg = (WM > 1 && !(WM == 2 && WN == 4)) || shmem > (size_t)WB_LDS_BUDGET;   // the kernel's launch bounds / an LDS footprint above half a CU: two waves per SIMD (one 8-wave workgroup per CU)
     if (shape_ok && shmem <= (one_wg ? (size_t)150 * 1024 : (size_t)WB_LDS_BUDGET)) {
       r.x = x; r.dy = dy; r.part = part; r.part_stride = part_stride;
       r.N = N; r.Cin = Cin; r.Cout = Cout; r.H = OH; r.W = OW; r.T = T;
@@ -1000,6 +1005,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
     default: PG_WR_LAUNCH(4, M_, N_) break;                        \
   }
       if (WM == 4 && WN == 4) PG_WR_LAUNCH(1, 4, 4)
+      else if (WM == 2 && WN == 4) PG_WR_LAUNCH(1, 2, 4)
       else if (WM == 4) { if (T == 1) PG_WR_LAUNCH(1, 4, 2) else PG_WR_LAUNCH(2, 4, 2) }
       else if (WM == 2) PG_WR_BY_T(2, 2)
       else if (T == 6) PG_WR_LAUNCH(6, 1, 2)
