@@ -105,13 +105,14 @@ int pg_conv2d_mfma_ex(const float* in, const float* wfrag, const float* bias, co
                       int dact, int out_act, int fmt, const float* res2, long res_bs, long res2_bs,
                       void* stream);
 /* Round 6: the convolution of a gated block together with its GatedActivation (+ residual) — nn/convolution.py:62-66 behind the
- * 2C-channel convolution of pixel_snail.py:41-56: out (N, 128, OH, OW) = conv(in_act(in)) + bias is written as usual (the gate's
- * backward, pg_gated_bwd, reads it) and gate_out (N, 64, OH, OW) = gate_res + act(out[:, :64]) * sigmoid(out[:, 64:]); gate_res may be
- * NULL. Exactly 128 output channels on the bf16x3 format's wide kernel (the two 64-channel chunks of a workgroup are the gate's
- * halves); pg_conv_gate_fusable() returns 1 for the shapes it takes. wfrag: pg_pack_conv_weight_frag(fmt = PG_CONV_FMT_B3_GATE). */
+ * 2C-channel convolution of pixel_snail.py:41-56 and gated_pixel_cnn.py:63-96: out (N, 2C, OH, OW) = conv(in_act(in)) + bias + res is
+ * written as usual (the gate's backward, pg_gated_bwd, reads it; res = the convolution's own residual — GatedPixelCNN's link and
+ * vertical-stack sums — or NULL) and gate_out (N, C, OH, OW) = gate_res + act(out[:, :C]) * sigmoid(out[:, C:]); gate_res may be
+ * NULL. 2C must be a multiple of 128 on the bf16x3 format's wide kernel; pg_conv_gate_fusable() returns 1 for the shapes it takes.
+ * wfrag: pg_pack_conv_weight_frag(fmt = PG_CONV_FMT_B3_GATE). */
 int pg_conv_gate_fusable(int Cin, int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc);
-int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const float* bias, float* out, int N, int Cin, int IH, int IW,
-                        int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc, int in_act, int gate,
+int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const float* bias, const float* res, float* out, int N, int Cin,
+                        int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc, int in_act, int gate,
                         const float* gate_res, float* gate_out, void* stream);
 /* Round 6: the "dual" 1x1 data gradient of PixelSNAIL's block tail (pixel_snail.py:109-119: both = elu(conv_a(..)) + r,
  * out = elu(conv_o(elu(both))) + x). conv_o's data gradient owes BOTH producers of its input their ELU derivatives (they were
@@ -133,8 +134,8 @@ int pg_conv2d_mfma_dual(const float* in, const float* wfrag, float* out, float* 
  * input rows of IW, tap-list extent hr x hc) problem, or 0 (call pg_conv2d_taps instead). */
 #define PG_CONV_FMT_F32 1
 #define PG_CONV_FMT_B3 2
-/* pack-only (forward orientation, Cout == 128): PG_CONV_FMT_B3 fragments with the output channels ordered so that each 64-channel
- * chunk holds 32 gate channels' two halves — tile m of chunk c = channels 64 (m >> 1) + 32 c + 16 (m & 1) + 0..15. The format
+/* pack-only (forward orientation, Cout % 128 == 0): PG_CONV_FMT_B3 fragments with the output channels ordered so that each 64-channel
+ * chunk holds 32 gate channels' two halves — tile m of chunk c = channels (Cout / 2) (m >> 1) + 32 c + 16 (m & 1) + 0..15. The format
  * pg_conv2d_mfma_gate reads (one wave then owns both operands of its gate channels); `out` is still written in natural order. */
 #define PG_CONV_FMT_B3_GATE 3
 int pg_conv_mfma_supported(int Cin, int Cout, int T, int OH, int OW, int IW, int hr, int hc);

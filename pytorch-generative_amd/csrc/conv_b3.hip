@@ -35,7 +35,7 @@ namespace {
 struct B3PackJob {
   unsigned int* wfrag;
   int transpose, M, Kc, MT, chunks, CIB, cgs, groups, ksteps, nchunk;
-  int gate_order;  // PG_CONV_FMT_B3_GATE (M == 128): m-tile m of chunk c holds channels 64 (m >> 1) + 32 c + 16 (m & 1) + ..,
+  int gate_order;  // PG_CONV_FMT_B3_GATE (M % 128 == 0): m-tile m of chunk c holds channels (M / 2) (m >> 1) + 32 c + 16 (m & 1) + ..,
                    // i.e. each chunk = 32 gate channels' [a | b] halves (conv_b3_kernel<.., GT = true> gates inside one wave)
   long total;  // lanes (pieces inside)
 };
@@ -60,7 +60,7 @@ __global__ void b3_pack_kernel(const B3PackArgs a) {
     const int ks = (int)(rest % p.ksteps); rest /= p.ksteps;
     const int j = (int)(rest % p.nchunk);
     const int chunk = (int)(rest / p.nchunk);
-    const int o = p.gate_order ? (m >> 1) * B3_CO_CHUNK + chunk * 32 + (m & 1) * 16 + (lane & 15)
+    const int o = p.gate_order ? (m >> 1) * (p.M >> 1) + chunk * 32 + (m & 1) * 16 + (lane & 15)
                                : chunk * B3_CO_CHUNK + m * 16 + (lane & 15);
     const int g = 4 * ks + (lane >> 4);
     float x[8];
@@ -235,8 +235,10 @@ int pg_b3_dual_ok(int Cin, int Cout, int OH, int OW) {
 }
 
 int pg_b3_gate_fusable(int Cin, int Cout, int T, int OH, int OW, int hr, int hc) {
-  if (Cout != 2 * B3_CO_CHUNK || T < 2 || OW > 256 || OH * OW < 16) return 0;  // (one tap with <= 64 input channels runs without an x tile)
+  if (Cout % (2 * B3_CO_CHUNK) != 0 || OW > 256 || OH * OW < 16) return 0;
   const B3Plan pl = b3_plan(Cin, Cout, T);
+  // (one tap whose weights fit the 1x1 kernel runs without an x tile: pg_b3_conv's routing, restated)
+  if (T == 1 && pl.ok && pl.ksteps == 1 && (size_t)(Cin / pl.CIB) * pl.MT * 3 * 1024 <= 24 * 1024) return 0;
   return pl.ok && !pl.pipelined && !pl.w9 && pl.MT == 4 && b3_rows(T, OH, OW, hr, hc, pl.px_cap) >= 1;
 }
 
@@ -244,8 +246,8 @@ static int b3_pack_job(B3PackJob& p, float* wfrag, int Cout, int Cin, int T, int
   p.wfrag = reinterpret_cast<unsigned int*>(wfrag);
   p.transpose = transpose;
   p.gate_order = gate_order;
-  PG_REQUIRE(!gate_order || (!transpose && Cout == 2 * B3_CO_CHUNK), PG_ESHAPE,
-             "pg_pack_conv_weight_frag: the gate-interleaved order is for forward fragments with 128 output channels");
+  PG_REQUIRE(!gate_order || (!transpose && Cout % (2 * B3_CO_CHUNK) == 0), PG_ESHAPE,
+             "pg_pack_conv_weight_frag: the gate-interleaved order is for forward fragments with a multiple of 128 output channels");
   p.M = transpose ? Cin : Cout;
   p.Kc = transpose ? Cout : Cin;
   const B3Plan pl = b3_plan(p.Kc, p.M, T);
@@ -279,8 +281,8 @@ int pg_b3_pack2(const float* w, float* wfrag_fwd, float* wfrag_dgrad, int Cout, 
   return 0;
 }
 
-// gate != 0 (1 + PG_GATE_*; round 6): the launch must be the wide kernel's plain epilogue with Cout == 128 — it then also writes
-// gate_out = gate_res + act(a) * sigmoid(b) for [a | b] = out; pg_b3_gate_fusable() says beforehand whether a shape qualifies
+// gate != 0 (1 + PG_GATE_*; round 6): the launch must be the wide kernel (Cout % 128 == 0, at most one dense residual) — it then also writes
+// gate_out = gate_res + act(a) * sigmoid(b) for [a | b] = out (+ res); pg_b3_gate_fusable() says beforehand whether a shape qualifies
 int pg_b3_gate_fusable(int Cin, int Cout, int T, int OH, int OW, int hr, int hc);
 int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const float* res, float* out,
                int N, int Cin, int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr,
@@ -292,9 +294,9 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.out2 = dual_out2;
   PG_REQUIRE(!dual_out2 || (res && dact_src && !res2 && !gate && out_act == PG_ACT_NONE && !bias && T == 1), PG_EINVAL,
              "pg_conv2d_mfma_dual: a 1x1 data gradient with a derivative source and r, nothing else");
-  PG_REQUIRE(gate == 0 || (gate_out && !res && !res2 && !dact_src && out_act == PG_ACT_NONE &&
+  PG_REQUIRE(gate == 0 || (gate_out && !res2 && !dact_src && out_act == PG_ACT_NONE &&
                            (gate == 1 + PG_GATE_TANH || gate == 1 + PG_GATE_IDENTITY)), PG_EINVAL,
-             "pg_conv2d_mfma_gate: the fused gate takes no residual / derivative / output activation of the convolution itself");
+             "pg_conv2d_mfma_gate: the fused gate takes one residual of the convolution, no second one / derivative / output activation");
   a.in = in; a.wfrag = wfrag; a.bias = bias; a.res = res; a.dact_src = dact_src; a.out = out;
   PG_REQUIRE(res2 == nullptr || res != nullptr, PG_EINVAL, "pg_conv2d_mfma(bf16x3): res2 without res");
   // the weight slabs are moved by LDS-DMA in 16-byte units (conv_b3_kernel, round 5)
@@ -383,8 +385,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   a.TR = TR; a.tile_h = TR + hr; a.tile_w = OW + hc;
   a.plane16 = ((a.tile_h * a.tile_w + 15) / 16) * 16;
   a.tiles_per_img = (OH + TR - 1) / TR;
-  PG_REQUIRE(!gate || (!pl.pipelined && !pl.w9 && pl.MT == 4 && Cout == 2 * B3_CO_CHUNK && !gelu), PG_ESHAPE,
-             "pg_conv2d_mfma_gate: the fused gate needs the wide bf16x3 kernel with exactly 128 output channels");
+  PG_REQUIRE(!gate || (!pl.pipelined && !pl.w9 && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0 && !gelu), PG_ESHAPE,
+             "pg_conv2d_mfma_gate: the fused gate needs the wide bf16x3 kernel with a multiple of 128 output channels");
   if (pl.pipelined && a.tile_h * a.tile_w <= B3P_PX) {
     // ---- the pipelined kernel: LDS = x[2][3 pieces][plane16] | dump entry | w[2][768] | 4 x epilogue scratch | bias, taps
     for (int g = 0; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }

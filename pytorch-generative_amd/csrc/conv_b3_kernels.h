@@ -231,7 +231,9 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
   // zero the x planes once (halo / out-of-image entries are never written afterwards)
   for (int i = tid; i < a.cgs * 3 * a.plane16; i += THREADS) lds16[i] = u32x4{0u, 0u, 0u, 0u};
   if (tid < B3_CO_CHUNK * CG) {
-    const int co = CG == 1 ? co0 + tid : blockIdx.y * CG * B3_CO_CHUNK + tid;
+    int co = CG == 1 ? co0 + tid : blockIdx.y * CG * B3_CO_CHUNK + tid;
+    if constexpr (GT)  // the bias of the gate-interleaved channel this (chunk, tile, row) slot holds
+      co = ((tid >> 5) & 1) * (a.Cout >> 1) + (blockIdx.y * 2 + (tid >> 6)) * 32 + (tid & 31);
     lds[a.b_off + tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
   }
 
@@ -428,28 +430,36 @@ __global__ void __launch_bounds__(B3_THREADS * CG, CG == 1 ? 2 : 1) conv_b3_kern
     }                                                                         \
   }
       if constexpr (GT) {
-        // Gate-interleaved fragments (PG_CONV_FMT_B3_GATE): tile m of this wave's chunk holds z channels
-        // 64 (m >> 1) + 32 cgp + 16 (m & 1) + 0..15 — tiles h and 2 + h are the [a | b] halves of gate channels 32 cgp + 16 h + 0..15,
-        // so the gate needs no exchange between waves. z goes out in its natural channel order (backward reads it), y beside it.
+        // Gate-interleaved fragments (PG_CONV_FMT_B3_GATE), G = Cout / 2 gate channels: chunk cg = 2 blockIdx.y + cgp holds gate channels
+        // 32 cg .. 32 cg + 31; its tile m = z channels G (m >> 1) + 32 cg + 16 (m & 1) + 0..15 — tiles h and 2 + h are the [a | b] halves
+        // of gate channels 32 cg + 16 h + 0..15, so the gate needs no exchange between waves. z (+ the convolution's own residual,
+        // GatedPixelCNN's link / vertical-stack sums) goes out in its natural channel order (backward reads it), y beside it.
+        const int G = a.Cout >> 1;
+        const int cg32 = (blockIdx.y * 2 + cgp) * 32;
         float* zb = a.out + (size_t)n_img * a.Cout * Lv;
-        const size_t go = (size_t)n_img * B3_CO_CHUNK * Lv;
-        const float* ball = lds + a.b_off;
+        const float* zres = has_res ? a.res + (size_t)n_img * a.res_bs : nullptr;
+        const size_t go = (size_t)n_img * G * Lv;
 #define PG_B3_TILE_T(M, V, CH0)                                                                  \
   _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                 \
   _Pragma("unroll") for (int r = 0; r < 4; ++r) ep[(kq * 4 + r) * EPS + n * 16 + (lane & 15)] = acc[M][n][r]; \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
-  _Pragma("unroll") for (int c = 0; c < 16; ++c) V[c] = ep[c * EPS + lane] + ball[(CH0) + c];    \
+  _Pragma("unroll") for (int c = 0; c < 16; ++c) V[c] += ep[c * EPS + lane] + bl[(M) * 16 + c];  \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
   if (sok) { _Pragma("unroll") for (int c = 0; c < 16; ++c) (zb + (size_t)((CH0) + c) * Lv)[lane_px] = V[c]; }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int gc0 = cgp * 32 + h * 16;  // uniform
+          const int gc0 = cg32 + h * 16;  // uniform
           float r[16], va[16], vb[16];
-          // the residual's loads first: they are in flight over both transpositions
+          // the residuals' loads first: they are in flight over both transpositions
 #pragma unroll
           for (int c = 0; c < 16; ++c) r[c] = (a.gate_res && sok) ? (a.gate_res + go + (size_t)(gc0 + c) * Lv)[lane_px] : 0.f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            va[c] = (zres && sok) ? (zres + (size_t)(gc0 + c) * Lv)[lane_px] : 0.f;
+            vb[c] = (zres && sok) ? (zres + (size_t)(G + gc0 + c) * Lv)[lane_px] : 0.f;
+          }
           PG_B3_TILE_T(h, va, gc0)
-          PG_B3_TILE_T(2 + h, vb, B3_CO_CHUNK + gc0)
+          PG_B3_TILE_T(2 + h, vb, G + gc0)
 #pragma unroll
           for (int c = 0; c < 16; ++c) {
             const float f = a.gate == 1 + PG_GATE_TANH ? tanhf(va[c]) : va[c];

@@ -640,8 +640,9 @@ PG_EXPORT int pg_pack_conv_weight_frag(const float* w, float* wfrag, int Cout, i
 }
 
 // Round 6: convolution + GatedActivation (+ the block's residual) in one launch — nn/convolution.py:62-66 behind a 2C-channel
-// convolution, pixel_snail.py:41-56. out (N, 128, OH, OW) = the convolution (kept: the gate's backward reads it), gate_out
-// (N, 64, OH, OW) = gate_res + act(out[:, :64]) * sigmoid(out[:, 64:]) (gate_res may be NULL).
+// convolution (pixel_snail.py:41-56; gated_pixel_cnn.py:63-96, where the convolution carries a residual of its own: the link /
+// vertical-stack sums). out (N, 2C, OH, OW) = the convolution + res (kept: the gate's backward reads it), gate_out
+// (N, C, OH, OW) = gate_res + act(out[:, :C]) * sigmoid(out[:, C:]) (res, gate_res may be NULL); 2C a multiple of 128.
 PG_EXPORT int pg_conv_gate_fusable(int Cin, int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc) {
   if (!tap_dr || !tap_dc || T < 1 || T > PG_MAX_TAPS) return 0;
   int a0 = tap_dr[0], a1 = tap_dr[0], b0 = tap_dc[0], b1 = tap_dc[0];
@@ -652,8 +653,8 @@ PG_EXPORT int pg_conv_gate_fusable(int Cin, int Cout, int OH, int OW, int T, con
   return pg_b3_gate_fusable(Cin, Cout, T, OH, OW, a1 - a0, b1 - b0);
 }
 
-PG_EXPORT int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const float* bias, float* out, int N, int Cin, int IH,
-                                  int IW, int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc, int in_act,
+PG_EXPORT int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const float* bias, const float* res, float* out, int N, int Cin,
+                                  int IH, int IW, int Cout, int OH, int OW, int T, const int* tap_dr, const int* tap_dc, int in_act,
                                   int gate, const float* gate_res, float* gate_out, void* stream) {
   PG_REQUIRE(in && wfrag && out && gate_out && tap_dr && tap_dc, PG_EINVAL, "pg_conv2d_mfma_gate: null pointer");
   PG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, PG_EINVAL,
@@ -663,7 +664,7 @@ PG_EXPORT int pg_conv2d_mfma_gate(const float* in, const float* wfrag, const flo
   PG_REQUIRE(gate == PG_GATE_TANH || gate == PG_GATE_IDENTITY, PG_EINVAL, "pg_conv2d_mfma_gate: bad gate id");
   PG_REQUIRE(pg_conv_gate_fusable(Cin, Cout, OH, OW, T, tap_dr, tap_dc), PG_ESHAPE,
              "pg_conv2d_mfma_gate: shape not covered (pg_conv_gate_fusable)");
-  return pg_b3_conv(in, wfrag, bias, nullptr, out, N, Cin, IH, IW, Cout, OH, OW, T, tap_dr, tap_dc, in_act, nullptr, PG_ACT_NONE,
+  return pg_b3_conv(in, wfrag, bias, res, out, N, Cin, IH, IW, Cout, OH, OW, T, tap_dr, tap_dc, in_act, nullptr, PG_ACT_NONE,
                     PG_ACT_NONE, nullptr, 0, 0, (hipStream_t)stream, 1 + gate, gate_res, gate_out);
 }
 

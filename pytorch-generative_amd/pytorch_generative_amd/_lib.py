@@ -45,7 +45,7 @@ SIGNATURES = {
     "pg_conv_dual_ok": (c_i, [c_i] * 4),
     "pg_conv2d_mfma_dual": (c_i, [c_f] * 4 + [c_i] * 5 + [c_f, c_i, c_f, c_s]),
     "pg_conv_gate_fusable": (c_i, [c_i, c_i, c_i, c_i, c_i, c_ip, c_ip]),
-    "pg_conv2d_mfma_gate": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_i, c_f, c_f, c_s]),
+    "pg_conv2d_mfma_gate": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_i, c_f, c_f, c_s]),
     "pg_conv_mfma_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "pg_conv_frag_floats": (c_z, [c_i, c_i, c_i, c_i]),
     "pg_pack_conv_weight_frag": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_i, c_i, c_s]),

@@ -65,10 +65,19 @@ class GatedPixelCNNLayer(nn.Module):
         t, vin = self._vstack_1xN(vstack_input, n_skip=1)
         vconv = self._vstack_Nx1(t, crop=(h, w))
         link, vconv_s = self._link(vconv, n_skip=1)
-        vstack = self._activation(self._vstack_1x1(vin, res=vconv_s))
+        # round 6: both gates run in the epilogue of the convolution that produces their input where Conv2d.gate_ok (the wide bf16x3
+        # kernel, gate-interleaved fragments): the gate kernel read the 2C-channel tensor back
+        gate = self._activation._gate
+        if self._vstack_1x1.gate_ok(vin):
+            vstack = self._vstack_1x1(vin, res=vconv_s, gate=gate)
+        else:
+            vstack = self._activation(self._vstack_1x1(vin, res=vconv_s))
         # horizontal stack
-        hx, hin = self._hstack_1xN(hstack_input, crop=(h, w), res=link, n_skip=1)
-        hstack = self._activation(hx)
+        if self._hstack_1xN.gate_ok(hstack_input, (h, w)):
+            hstack, hin = self._hstack_1xN(hstack_input, crop=(h, w), res=link, n_skip=1, gate=gate)
+        else:
+            hx, hin = self._hstack_1xN(hstack_input, crop=(h, w), res=link, n_skip=1)
+            hstack = self._activation(hx)
         skip, hstack_s = self._hstack_skip(hstack, res=skip_acc, n_skip=1)
         # a causal (mask_center) layer must not see its own input through the residual
         hstack = self._hstack_residual(hstack_s, res=None if self._mask_center else hin)

@@ -139,7 +139,7 @@ class Conv2d(nn.Conv2d):
         """n_skip > 0 (extension) returns (y, x_1, .., x_n): pass-through aliases of x for the skip
         connections that also read x, see ops.conv2d_taps.
         gate = ops.GATE_TANH / GATE_IDENTITY (extension, round 6; only where gate_ok()): returns the GatedActivation of this
-        convolution's output (+ gate_res) — half the channels — from the same launch.
+        convolution's output (conv + res, + gate_res behind the gate) — half the channels — from the same launch.
         in_sum = (r, slot) / res_slot = slot (extension, round 6; only where the consumer's dual_ok()): the two ends of the dual
         data gradient, see ops.GradSlot. Forward values do not change."""
         if res_slot is not None or in_sum is not None:
@@ -152,9 +152,14 @@ class Conv2d(nn.Conv2d):
                 out_pre_scaled=out_pre_scaled, in_post=_ACTS[in_post], res_slot=res_slot, in_sum=in_sum,
             )
         if gate is not None:
-            if res is not None or res2 is not None or out_act is not None or out_pre_scaled or not self.gate_ok(x, crop):
-                raise ValueError("Conv2d: gate= needs a plain convolution on a shape gate_ok() accepts")
-            return ops.conv2d_taps(x, self.weight, self.bias, self._conv_spec(), out_hw=crop, in_act=_ACTS[in_act],
+            if res2 is not None or out_act is not None or out_pre_scaled or not self.gate_ok(x, crop):
+                raise ValueError("Conv2d: gate= needs a convolution (at most one residual) on a shape gate_ok() accepts")
+            if n_skip and not x.requires_grad:
+                y = ops.conv2d_taps(x, self.weight, self.bias, self._conv_spec(), out_hw=crop, in_act=_ACTS[in_act], res=res,
+                                    weight_param=self.weight, bias_param=self.bias, in_post=_ACTS[in_post],
+                                    gate=gate, gate_res=gate_res)
+                return (y,) + (x,) * n_skip
+            return ops.conv2d_taps(x, self.weight, self.bias, self._conv_spec(), out_hw=crop, in_act=_ACTS[in_act], res=res,
                                    weight_param=self.weight, bias_param=self.bias, in_post=_ACTS[in_post], n_skip=n_skip,
                                    gate=gate, gate_res=gate_res)
         if res2 is not None and not self.two_residuals_ok(x, crop):

@@ -197,8 +197,8 @@ class _ConvTaps(torch.autograd.Function):
         if gate is not None:
             # GatedActivation (+ the residual behind it) in the convolution's epilogue: `out` keeps the pre-gate values for
             # backward, y is what the caller sees
-            if mfma != CONV_FMT_B3 or res is not None or res2 is not None or out_act != ACT_NONE:
-                raise ValueError("conv2d: gate= needs a plain bf16x3 convolution (check ops.conv_gate_ok first)")
+            if mfma != CONV_FMT_B3 or res2 is not None or out_act != ACT_NONE:
+                raise ValueError("conv2d: gate= needs a bf16x3 convolution with at most one residual (check ops.conv_gate_ok first)")
             if gate_res is not None:
                 gate_res = _chk(gate_res, "conv2d.gate_res")
                 if tuple(gate_res.shape) != (n, cout // 2, oh, ow):
@@ -212,13 +212,14 @@ class _ConvTaps(torch.autograd.Function):
             y = torch.empty((n, cout // 2, oh, ow), device=x.device, dtype=torch.float32)
             _lib.check(
                 lib.pg_conv2d_mfma_gate(
-                    x.data_ptr(), wfrag.data_ptr(), _p(bias), out.data_ptr(), n, cin, ih, iw, cout, oh, ow,
+                    x.data_ptr(), wfrag.data_ptr(), _p(bias), _p(res), out.data_ptr(), n, cin, ih, iw, cout, oh, ow,
                     len(spec.fwd_taps), spec.f_dr, spec.f_dc, in_act, gate, _p(gate_res), y.data_ptr(), _stream(),
                 ),
                 "pg_conv2d_mfma_gate",
             )
             ctx.save_for_backward(x, weight, out)
-            ctx.spec, ctx.in_act, ctx.has_bias, ctx.has_res, ctx.has_res2 = spec, in_act, bias is not None, False, False
+            # (the convolution's own residual is part of the stored pre-gate tensor; its gradient is the gate's input gradient)
+            ctx.spec, ctx.in_act, ctx.has_bias, ctx.has_res, ctx.has_res2 = spec, in_act, bias is not None, res is not None, False
             ctx.has_gate_res = gate_res is not None
             ctx.gw, ctx.gb = gw, gb
             ctx.out_act, ctx.out_pre_scaled, ctx.in_post = ACT_NONE, False, in_post
@@ -559,7 +560,7 @@ FUSE_GATE = os.environ.get("PG_FUSE_GATE", "1") != "0"  # A/B: 0 = the standalon
 
 def conv_gate_ok(x, weight, spec, out_hw=None):
     """True if conv2d_taps(..., gate=...) can fuse the GatedActivation that follows this convolution into its launch
-    (pg_conv_gate_fusable: bf16x3 format, exactly 128 output channels, at least two taps)."""
+    (pg_conv_gate_fusable: bf16x3 format on the wide kernel, a multiple of 128 output channels)."""
     if not FUSE_GATE or not x.is_cuda or x.dtype != torch.float32:
         return False
     lib = _lib.load()

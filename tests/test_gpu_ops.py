@@ -568,7 +568,7 @@ GATED_CONV_CASES = [
     (5, 32, 12, 12, 64, 3, 1, False, "tanh", None, True),        # masked type B: 5 taps, tanh gate, several images per tile
     (2, 128, 9, 11, 64, 3, 1, True, "tanh", "relu", True),       # type A: 4 taps, odd sizes
 ]
-FUSED_GATE_CASES = {0, 4, 5, 6}  # indices of GATED_CONV_CASES the fused epilogue must take (asserted: a routing change is a finding)
+FUSED_GATE_CASES = {0, 1, 4, 5, 6}  # indices of GATED_CONV_CASES the fused epilogue must take (asserted: a routing change is a finding)
 
 
 @pytest.mark.parametrize("case", GATED_CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
@@ -636,6 +636,48 @@ def test_gated_conv_fused_gate_equals_separate_kernels(dev, case, monkeypatch):
         got[fused] = (y.detach(), xg.grad, m.conv.weight.grad.clone(), m.conv.bias.grad.clone())
     for a, b, what in zip(got[True], got[False], ("y", "dx", "dw", "db")):
         _util.assert_close(a, b.cpu(), 2e-6, what)
+
+
+@pytest.mark.parametrize("case", [(2, 128, 32, 32, 128, 1, 1, 0, 0, 0), (3, 128, 32, 32, 128, 1, 2, 0, 1, 1), (1, 64, 12, 20, 64, 2, 2, 1, 1, 0)],
+                         ids=["gated_vstack_1x1", "gated_hstack_1x2_alias", "ragged"])
+def test_gate_behind_a_convolution_with_its_own_residual(dev, case, monkeypatch):
+    """GatedPixelCNN's two gates (gated_pixel_cnn.py:63-96): gate(conv(x) + r) with r the link / vertical-stack sum, fused into the
+    convolution's epilogue (2C = 256 channels: two pairs of gate-interleaved chunks) against torch on the CPU — y, dx, dr, dw, db, the
+    pass-through alias of x — and against the unfused kernels."""
+    from pytorch_generative_amd import nn as pg_nn
+    from pytorch_generative_amd import ops
+    from pytorch_generative_amd.ops import conv as ops_conv
+
+    n, cin, h, w, c, kh, kw, ph, pw, n_skip = case
+    torch.manual_seed(0)
+    conv = pg_nn.Conv2d(cin, 2 * c, (kh, kw), padding=(ph, pw))
+    x, r, g = _rand(n, cin, h, w, seed=1), _rand(n, 2 * c, h, w, seed=2), _rand(n, c, h, w, seed=3)
+    g2 = _rand(n, cin, h, w, seed=4)
+    xo, ro = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    wo, bo = conv.weight.detach().clone().requires_grad_(True), conv.bias.detach().clone().requires_grad_(True)
+    z = F.conv2d(xo, wo, bo, padding=(ph, pw))[:, :, :h, :w] + ro
+    yo = torch.tanh(z[:, :c]) * torch.sigmoid(z[:, c:])
+    (yo * g).sum().backward() if not n_skip else ((yo * g).sum() + (xo * g2).sum()).backward()
+    conv = conv.to(dev)
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops_conv, "FUSE_GATE", fused)
+        conv.zero_grad(set_to_none=True)
+        xg, rg = x.to(dev).requires_grad_(True), r.to(dev).requires_grad_(True)
+        assert conv.gate_ok(xg, (h, w)) == fused
+        if fused:
+            out = conv(xg, crop=(h, w), res=rg, n_skip=n_skip, gate=ops.GATE_TANH)
+        else:
+            out = conv(xg, crop=(h, w), res=rg, n_skip=n_skip)
+            out = (ops.gated_activation(out[0], ops.GATE_TANH),) + tuple(out[1:]) if n_skip else ops.gated_activation(out, ops.GATE_TANH)
+        y = out[0] if n_skip else out
+        loss = (y * g.to(dev)).sum() + ((out[1] * g2.to(dev)).sum() if n_skip else 0.0)
+        loss.backward()
+        got[fused] = [y.detach(), xg.grad, rg.grad, conv.weight.grad.clone(), conv.bias.grad.clone()]
+    for a, b, what in zip(got[True], [yo.detach(), xo.grad, ro.grad, wo.grad, bo.grad], ("y", "dx", "dr", "dw", "db")):
+        _util.assert_close(a, b, TOL, what + " (fused vs torch)")
+    for a, b, what in zip(got[True], got[False], ("y", "dx", "dr", "dw", "db")):
+        _util.assert_close(a, b.cpu(), 5e-6, what + " (fused vs separate kernels)")
 
 
 @pytest.mark.parametrize("n,c,ca,h,w", [(3, 64, 32, 32, 32), (2, 64, 32, 9, 10), (1, 64, 64, 4, 4)])
