@@ -557,7 +557,9 @@ static long wgrad_max_rows(int Cout, int Cin, int T) {
   const long chunks = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
   // one tap with Cout % 128 == 0 and Cin % 64 == 0: conv_wgrad_b3's 128 x 64 tiles — half as many (co, ci) chunks, so
   // twice the partial rows for the same number of workgroups
-  const long g = ((T == 1 && Cout % 128 == 0 && Cin % 64 == 0) ? 1024 : 512) / chunks;
+  // (round 6) one tap with Cout % 128 == 0 and Cin % 128 == 0: the ring kernel's 128 x 128 tiles — a quarter of the chunks, two
+  // workgroups per CU want 512 / (chunks / 4) rows
+  const long g = ((T == 1 && Cout % 128 == 0 && Cin % 128 == 0) ? 2048 : (T == 1 && Cout % 128 == 0 && Cin % 64 == 0) ? 1024 : 512) / chunks;
   return g > 64 ? g : 64;
 }
 

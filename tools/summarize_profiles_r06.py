@@ -58,11 +58,11 @@ json.dump({"what": "ImageGPT's attention kernels (4 heads, d_k = d_v = 4, L = 78
 
 act = lambda n, c: n * c * 32 * 32 * 4  # noqa: E731
 wg = dict([rec("conv_wgrad_b3r_kernel<4", act(1024, 64) * 2, 64 * 64 * 4 * 4, 2.0 * 1024 * 1024 * 64 * 64 * 4),
-           rec("conv_wgrad_b3_kernel<1, 4, 8, 4>", act(512, 128) + act(512, 256), 128 * 256 * 4, 2.0 * 512 * 1024 * 128 * 256),
+           rec("conv_wgrad_b3r_kernel<1, 2, 4", act(512, 128) + act(512, 256), 128 * 256 * 4, 2.0 * 512 * 1024 * 128 * 256),
            rec("conv_wgrad_b3r_kernel<6", act(512, 128) + act(512, 256), 128 * 256 * 6 * 4, 2.0 * 512 * 1024 * 128 * 256 * 6)])
 json.dump({"what": "bf16x3 weight-gradient kernels: 2x2 64->64 at batch 1024 (PixelSNAIL; the row-ring kernel conv_wgrad_b3r_kernel<4, 3> — the record of "
-                   "conv_wgrad_b3_kernel<4, 2, 8, 2> / <6, 2, 4, 2> they replaced is profiles/r06_wgrad_pmc_before_ring.json), 1x1 128->256 (<1, 4, 8, 4>: the 128 x 64 tile, "
-                   "unchanged) and 2x3 128->256 (conv_wgrad_b3r_kernel<6, 1, 2, 3>: 84 KB ring, one workgroup per CU) at batch 512, 32x32 images, 3 launches each (tools/exp/pmc_launch.py); "
+                   "conv_wgrad_b3_kernel<4, 2, 8, 2> / <1, 4, 8, 4> / <6, 2, 4, 2> they replaced is profiles/r06_wgrad_pmc_before_ring.json), 1x1 128->256 "
+                   "(conv_wgrad_b3r_kernel<1, 2, 4, 2>: 128 x 128 tiles, two workgroups per CU) and 2x3 128->256 (conv_wgrad_b3r_kernel<6, 1, 2, 3>: 84 KB ring, one workgroup per CU) at batch 512, 32x32 images, 3 launches each (tools/exp/pmc_launch.py); "
                    "algorithmic bytes = x and dy read once; writes = the partial rows (reduced by wgrad_reduce_kernel)",
            "calibration": calib, "kernels": wg}, open(os.path.join(dst, "r06_wgrad_pmc.json"), "w"), indent=1)
 
