@@ -559,7 +559,7 @@ static long wgrad_max_rows(int Cout, int Cin, int T) {
   // twice the partial rows for the same number of workgroups
   // (round 6) one tap with Cout % 128 == 0 and Cin % 128 == 0: the ring kernel's 128 x 128 tiles — a quarter of the chunks, two
   // workgroups per CU want 512 / (chunks / 4) rows
-  const long g = ((T == 1 && Cout % 128 == 0 && Cin % 128 == 0) ? 2048 : (T == 1 && Cout % 128 == 0 && Cin % 64 == 0) ? 1024 : 512) / chunks;
+  const long g = ((T == 1 && Cout % 128 == 0 && Cin % 128 == 0) ? 2048 : (Cout % 128 == 0 && Cin % 64 == 0) ? 1024 : 512) / chunks;  // (any tap count: the ring's 128 x 64 tiles)
   return g > 64 ? g : 64;
 }
 

@@ -421,10 +421,12 @@ constexpr int wr_kind(int k, int dslots, int xslots) {
 // (4, 4) = 256 x 128 (one tap: every dy / x row is staged ONCE for GatedPixelCNN's 1x1 128 -> 256; one workgroup per CU).
 // D = prefetch distance in steps (register sets in flight). A step is short (one row: ~1.5 us of MFMA for the CU's two
 // workgroups), the loaded-HBM latency is not.
-// (128 x 64 tiles with two taps fit 123 registers with D = 2, i.e. two workgroups per CU: measured no faster — 0.949 / 0.669 / 0.631 ms
-// against 0.952 / 0.653 / 0.613 on GatedPixelCNN's 2x1 256->256 / 1x2 128->256 / 2x1 128->256 — and dropped)
-template <int T, int WM = 1, int WN = 2, int D = ((WM == 2 && WN == 4) ? 2 : 3)>
-__global__ void __launch_bounds__(512, (WM == 1 || (WM == 2 && WN == 4)) ? 4 : 2) conv_wgrad_b3r_kernel(const WrArgs a) {
+// (A first measurement of the two-workgroup 128 x 64 two-tap tile said "no faster" and was WRONG: the weight-gradient workspace rule capped the
+// grid at one workgroup per CU either way. With the rows it needs: 1x2 128->256 0.657 -> 0.552 ms, 2x1 128->256 0.620 -> 0.536.)
+// two register sets and <= 128 registers (= two workgroups per CU) where that fits: the 128 x 128 one-tap tile (124) and the 128 x 64 tile with
+// one / two taps (123)
+template <int T, int WM = 1, int WN = 2, int D = ((WM == 2 && WN == 4) || (WM == 2 && WN == 2 && T <= 2) ? 2 : 3)>
+__global__ void __launch_bounds__(512, (WM == 1 || (WM == 2 && WN == 4) || (WM == 2 && WN == 2 && T <= 2)) ? 4 : 2) conv_wgrad_b3r_kernel(const WrArgs a) {
   constexpr int COT = 4 * WM, CIT = 2 * WN;            // channel tiles per workgroup
   constexpr int DSLOTS = COT * 64, XSLOTS = CIT * 64;  // 8-pixel staging slots per row: [channel tile][4 column blocks][16 channels]
   constexpr int NS = (DSLOTS + XSLOTS + 511) / 512;    // slots per thread
@@ -964,7 +966,7 @@ int pg_wgrad_b3_launch(const float* x, const float* dy, float* part, long part_s
     r.RB = hr + 1; r.P = hr; r.max_dr = max_dr;
     const int dplane = 4 * WM * 64, xplane = 2 * WN * r.RB * 64;
     const size_t shmem = ((size_t)3 * dplane + (size_t)r.ndc * 3 * xplane) * 16;
-    const bool one_wg = (WM > 1 && !(WM == 2 && WN == 4)) || shmem > (size_t)WB_LDS_BUDGET;   // the kernel's launch bounds / an LDS footprint above half a CU: two waves per SIMD (one 8-wave workgroup per CU)
+    const bool one_wg = (WM > 1 && !(WM == 2 && WN == 4) && !(WM == 2 && WN == 2 && T <= 2)) || shmem > (size_t)WB_LDS_BUDGET;   // the kernel's launch bounds / an LDS footprint above half a CU: two waves per SIMD (one 8-wave workgroup per CU)
     if (shape_ok && shmem <= (one_wg ? (size_t)150 * 1024 : (size_t)WB_LDS_BUDGET)) {
       r.x = x; r.dy = dy; r.part = part; r.part_stride = part_stride;
       r.N = N; r.Cin = Cin; r.Cout = Cout; r.H = OH; r.W = OW; r.T = T;
