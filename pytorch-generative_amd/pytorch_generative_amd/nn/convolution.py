@@ -248,11 +248,14 @@ class ConvTranspose2d(nn.ConvTranspose2d):
                 if k == 0 and x.requires_grad:
                     # x has four readers: the other three read pass-through aliases, whose gradients the first
                     # convolution's data-gradient kernel adds in its epilogue (ops.conv2d_taps, n_skip)
+                    # (bias_param: with a flat-gradient sink the four bias gradients are added by the kernels — without it autograd
+                    # summed them with three ATen adds per layer)
                     y, *al = ops.conv2d_taps(x, wph[k], self.bias, spec, out_hw=x.shape[2:], in_act=_ACTS[in_act],
-                                             n_skip=3)
+                                             n_skip=3, bias_param=self.bias)
                     xs = [x] + list(al)
                 else:
-                    y = ops.conv2d_taps(xs[k], wph[k], self.bias, spec, out_hw=x.shape[2:], in_act=_ACTS[in_act])
+                    y = ops.conv2d_taps(xs[k], wph[k], self.bias, spec, out_hw=x.shape[2:], in_act=_ACTS[in_act],
+                                        bias_param=self.bias)
                 phases.append(y)
         return ops.phase_merge4(phases)  # interleaves the four phase outputs without a stacked copy
 
