@@ -388,8 +388,8 @@ int pg_b3_conv(const float* in, const float* wfrag, const float* bias, const flo
   PG_REQUIRE(!gate || (!pl.pipelined && !pl.w9 && pl.MT == 4 && Cout % (2 * B3_CO_CHUNK) == 0 && !gelu), PG_ESHAPE,
              "pg_conv2d_mfma_gate: the fused gate needs the wide bf16x3 kernel with a multiple of 128 output channels");
   // (Round 6, measured and NOT shipped: a row-ring forward kernel with register-resident weights for the 64-channel 4-tap layers —
-  // tools/exp/rejected/conv_b3r_kernel.h, the host block that routed it is in git history (commit "ring forward kernel: measured") — parity
-  // green, 225 against 235 us on the 2x2 64 -> 64 at batch 1024, PixelSNAIL +0.3 %: profiles/r06_conv_ring_forward_ab.txt.)
+  // tools/exp/rejected/conv_b3r_kernel.h (its README has the routing block that stood here) — parity green, 225 against 235 us on the
+  // 2x2 64 -> 64 at batch 1024, PixelSNAIL +0.3 %: profiles/r06_conv_ring_forward_ab.txt.)
   if (pl.pipelined && a.tile_h * a.tile_w <= B3P_PX) {
     // ---- the pipelined kernel: LDS = x[2][3 pieces][plane16] | dump entry | w[2][768] | 4 x epilogue scratch | bias, taps
     for (int g = 0; g < B3_MAXG; ++g) { a.g_tapoff[g] = 0; a.g_cg[g] = 0; }
